@@ -1,0 +1,666 @@
+/*
+ * scopa_oracle.c -- CPU ORACLE (test infrastructure; see scopa_oracle.h for the rules
+ * on who may call it).  Literal restatement of the reference's Python; every block cites
+ * the reference lines it follows (paths relative to /root/reference/).
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared -lm   (no implicit FMA contraction: the
+ * reference's float64 arithmetic is numpy's, one rounding per operation; the one place numpy
+ * itself fuses -- np.dot through OpenBLAS -- is written as an explicit fma() chain below).
+ */
+#include "scopa_oracle.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ===== cards ======================================================================= */
+/* MiniDeck.suits / .ranks, src/envs/mini_scopa_game.py:17-23 */
+static const int  RANK_OF[16] = {2, 5, 8, 10, 2, 5, 7, 9, 3, 6, 8, 9, 3, 6, 7, 10};
+static const char SUIT_CHAR[4] = {'c', 'f', 'p', 'b'}; /* cuori fiori picche bello */
+
+int  og_card_rank(int card) { return RANK_OF[card & 15]; }
+char og_card_suit_char(int card) { return SUIT_CHAR[(card >> 2) & 3]; }
+
+/* ===== CPython random.seed(int) + random.shuffle =================================== */
+/* MT19937 as in CPython's _randommodule.c: seed(int) -> init_by_array(32-bit words of |seed|) */
+typedef struct { uint32_t mt[624]; int idx; } mt_t;
+
+static void mt_init_genrand(mt_t *m, uint32_t s) {
+    m->mt[0] = s;
+    for (int i = 1; i < 624; i++)
+        m->mt[i] = 1812433253u * (m->mt[i - 1] ^ (m->mt[i - 1] >> 30)) + (uint32_t)i;
+    m->idx = 624;
+}
+static void mt_init_by_array(mt_t *m, const uint32_t *key, int klen) {
+    mt_init_genrand(m, 19650218u);
+    int i = 1, j = 0;
+    int k = 624 > klen ? 624 : klen;
+    for (; k; k--) {
+        m->mt[i] = (m->mt[i] ^ ((m->mt[i - 1] ^ (m->mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+        i++; j++;
+        if (i >= 624) { m->mt[0] = m->mt[623]; i = 1; }
+        if (j >= klen) j = 0;
+    }
+    for (k = 623; k; k--) {
+        m->mt[i] = (m->mt[i] ^ ((m->mt[i - 1] ^ (m->mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+        i++;
+        if (i >= 624) { m->mt[0] = m->mt[623]; i = 1; }
+    }
+    m->mt[0] = 0x80000000u;
+}
+static uint32_t mt_u32(mt_t *m) {
+    if (m->idx >= 624) {
+        uint32_t *mt = m->mt;
+        int kk;
+        for (kk = 0; kk < 624 - 397; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + 397] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        for (; kk < 623; kk++) {
+            uint32_t y = (mt[kk] & 0x80000000u) | (mt[kk + 1] & 0x7fffffffu);
+            mt[kk] = mt[kk + (397 - 624)] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        uint32_t y = (mt[623] & 0x80000000u) | (mt[0] & 0x7fffffffu);
+        mt[623] = mt[396] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        m->idx = 0;
+    }
+    uint32_t y = m->mt[m->idx++];
+    y ^= (y >> 11);
+    y ^= (y << 7) & 0x9d2c5680u;
+    y ^= (y << 15) & 0xefc60000u;
+    y ^= (y >> 18);
+    return y;
+}
+/* Random._randbelow_with_getrandbits: k = n.bit_length(); r = getrandbits(k) until r < n */
+static uint32_t py_randbelow(mt_t *m, uint32_t n) {
+    int k = 0;
+    for (uint32_t t = n; t; t >>= 1) k++;
+    uint32_t r;
+    do { r = mt_u32(m) >> (32 - k); } while (r >= n);
+    return r;
+}
+
+void og_deal_py_seed(int64_t seed, uint8_t perm[16]) {
+    /* mini_scopa_game.py:25-28: cards in suit-major order, random.seed(seed), random.shuffle */
+    uint64_t a = seed < 0 ? (uint64_t)(-seed) : (uint64_t)seed; /* seed(int) uses abs() */
+    uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+    mt_t m;
+    mt_init_by_array(&m, key, key[1] ? 2 : 1);
+    for (int i = 0; i < 16; i++) perm[i] = (uint8_t)i;
+    for (int i = 15; i >= 1; i--) { /* shuffle: for i in reversed(range(1, n)): j = randbelow(i+1) */
+        uint32_t j = py_randbelow(&m, (uint32_t)i + 1);
+        uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+}
+
+/* ===== game rules ================================================================== */
+void og_reset(og_state *s, const uint8_t perm[16]) {
+    /* MiniScopaGame.reset, mini_scopa_game.py:56-64; MiniScopaEnv.reset :131-138 */
+    memset(s, 0, sizeof *s);
+    for (int p = 0; p < 2; p++) {
+        for (int i = 0; i < 4; i++) s->hand[p][i] = (int8_t)perm[p * 4 + i];
+        s->nh[p] = 4;
+    }
+    memset(s->table, -1, sizeof s->table);
+}
+
+int og_is_terminal(const og_state *s) {
+    /* mini_scopa_game.py:160 */
+    return (s->nh[0] == 0 && s->nh[1] == 0) || s->step >= 8;
+}
+
+int og_current_player(const og_state *s) {
+    /* agent_selection rotates every step (:167); TERMINAL = -4 (openspiel…:17-20) */
+    return og_is_terminal(s) ? -4 : (s->step & 1);
+}
+
+int og_legal(const og_state *s, int player, int out[4]) {
+    /* openspiel_mini_scopa.py:22-47 */
+    if (og_is_terminal(s)) return 0;
+    if (player < 0) player = og_current_player(s);
+    int n = 0;
+    for (int i = 0; i < s->nh[player]; i++) out[n++] = s->hand[player][i];
+    if (n == 0) { out[0] = 0; n = 1; } /* "Fallback to avoid empty list" */
+    return n;
+}
+
+int og_capture(const og_state *s, int card, int cap_idx[8]) {
+    /* card_in_table, mini_scopa_game.py:66-91 */
+    int target = RANK_OF[card];
+    if (target <= 0 || s->nt == 0) return 0;
+    for (int i = 0; i < s->nt; i++) /* :72-74 first exact match in table order */
+        if (RANK_OF[s->table[i]] == target) { cap_idx[0] = i; return 1; }
+    /* :76-85 0/1 subset-sum, first-found wins */
+    int have[11];      /* comb_sums[s] is not None */
+    int len[11];
+    int comb[11][8];
+    memset(have, 0, sizeof have);
+    have[0] = 1; len[0] = 0;
+    for (int idx = 0; idx < s->nt; idx++) {
+        int r = RANK_OF[s->table[idx]];
+        for (int sum = target; sum >= r; sum--) {
+            if (!have[sum] && have[sum - r]) {
+                have[sum] = 1;
+                len[sum] = len[sum - r] + 1;
+                memcpy(comb[sum], comb[sum - r], sizeof(int) * (size_t)len[sum - r]);
+                comb[sum][len[sum] - 1] = idx;
+            }
+        }
+    }
+    if (!have[target]) return 0;
+    for (int i = 0; i < len[target]; i++) cap_idx[i] = comb[target][i];
+    return len[target];
+}
+
+static void play_card(og_state *s, int p, int hand_pos) {
+    /* play_card, mini_scopa_game.py:93-104 */
+    int card = s->hand[p][hand_pos];
+    int cap[8];
+    int nc = og_capture(s, card, cap);
+    if (nc > 0) {
+        int8_t keep[8]; int nk = 0;
+        for (int i = 0; i < s->nt; i++) {
+            int taken = 0;
+            for (int j = 0; j < nc; j++) if (cap[j] == i) taken = 1;
+            if (!taken) keep[nk++] = s->table[i];
+        }
+        memset(s->table, -1, sizeof s->table);
+        memcpy(s->table, keep, (size_t)nk);
+        s->nt = (int8_t)nk;
+        s->ncap[p] = (int8_t)(s->ncap[p] + nc + 1);
+        if (s->nt == 0) s->scopas[p]++;
+    } else {
+        s->table[s->nt++] = (int8_t)card;
+    }
+    for (int i = hand_pos; i + 1 < s->nh[p]; i++) s->hand[p][i] = s->hand[p][i + 1];
+    s->nh[p]--;
+    s->hand[p][s->nh[p]] = 0;
+}
+
+void og_step(og_state *s, int action) {
+    /* MiniScopaEnv.step, mini_scopa_game.py:140-167 */
+    if (og_is_terminal(s)) return; /* _was_dead_step */
+    int p = s->step & 1;
+    int pos = -1;
+    for (int i = 0; i < s->nh[p]; i++) /* :155 first card in hand with that (rank, suit) */
+        if (s->hand[p][i] == action) { pos = i; break; }
+    if (pos >= 0) play_card(s, p, pos); /* else: silent no-op (:156) */
+    s->step++;
+}
+
+void og_rewards_x2(const og_state *s, int r2[2]) {
+    /* evaluate_game, mini_scopa_game.py:106-114; rewards stay 0 until terminal (openspiel…:78-81) */
+    if (!og_is_terminal(s)) { r2[0] = r2[1] = 0; return; }
+    int r0 = s->ncap[0] + 2 * s->scopas[0], r1 = s->ncap[1] + 2 * s->scopas[1];
+    int total = r0 + r1;
+    if (total == 0) { r2[0] = r2[1] = 0; return; }
+    r2[0] = 2 * r0 - total; /* 2*(r - total/2) */
+    r2[1] = 2 * r1 - total;
+}
+
+int og_infoset_string(const og_state *s, int player, char *buf) {
+    /* information_state_string, openspiel_mini_scopa.py:86-95 */
+    if (player < 0) player = og_current_player(s);
+    if (og_is_terminal(s) || player < 0) return sprintf(buf, "TERMINAL");
+    char *w = buf;
+    w += sprintf(w, "P%d:H[", player);
+    for (int i = 0; i < s->nh[player]; i++)
+        w += sprintf(w, "%s%d%c", i ? "-" : "", RANK_OF[s->hand[player][i]], SUIT_CHAR[s->hand[player][i] >> 2]);
+    w += sprintf(w, "]_T[");
+    for (int i = 0; i < s->nt; i++)
+        w += sprintf(w, "%s%d%c", i ? "-" : "", RANK_OF[s->table[i]], SUIT_CHAR[s->table[i] >> 2]);
+    w += sprintf(w, "]");
+    return (int)(w - buf);
+}
+
+/* ===== tree ======================================================================== */
+#define MAXN 2229 /* 1653 decision + 576 terminal, deal-independent (4/4/3/3/2/2/1/1 legal profile) */
+
+static int tree_rec(og_tree *t, const og_state *s, int depth) {
+    int idx = t->n_nodes++;
+    t->state[idx] = *s;
+    t->depth[idx] = (int8_t)depth;
+    int term = og_is_terminal(s);
+    t->term[idx] = (int8_t)term;
+    t->player[idx] = (int8_t)og_current_player(s);
+    int r2[2];
+    og_rewards_x2(s, r2);
+    t->r2[idx * 2] = (int8_t)r2[0];
+    t->r2[idx * 2 + 1] = (int8_t)r2[1];
+    for (int i = 0; i < 4; i++) { t->legal[idx * 4 + i] = -1; t->child[idx * 4 + i] = -1; }
+    if (term) { t->infoset[idx] = -1; t->nlegal[idx] = 0; return idx; }
+    t->n_decision++;
+    int legal[4];
+    int n = og_legal(s, -1, legal);
+    t->nlegal[idx] = (int8_t)n;
+    char key[64];
+    og_infoset_string(s, -1, key);
+    int id = -1;
+    for (int i = 0; i < t->n_infosets; i++)
+        if (strcmp(t->infoset_str[i], key) == 0) { id = i; break; }
+    if (id < 0) { /* dict insertion on first visit: vanilla_cfr.py:51-54 */
+        id = t->n_infosets++;
+        strcpy(t->infoset_str[id], key);
+        t->infoset_nlegal[id] = (int8_t)n;
+        t->infoset_player[id] = t->player[idx];
+        for (int i = 0; i < 4; i++) t->infoset_legal[id * 4 + i] = (int8_t)(i < n ? legal[i] : -1);
+    }
+    t->infoset[idx] = (int16_t)id;
+    for (int i = 0; i < n; i++) {
+        t->legal[idx * 4 + i] = (int8_t)legal[i];
+        og_state c = *s;          /* clone() */
+        og_step(&c, legal[i]);    /* apply_action */
+        t->child[idx * 4 + i] = tree_rec(t, &c, depth + 1);
+    }
+    return idx;
+}
+
+og_tree *og_tree_build(const uint8_t perm[16]) {
+    og_tree *t = (og_tree *)calloc(1, sizeof *t);
+    t->term = (int8_t *)calloc(MAXN, 1); t->player = (int8_t *)calloc(MAXN, 1);
+    t->nlegal = (int8_t *)calloc(MAXN, 1); t->depth = (int8_t *)calloc(MAXN, 1);
+    t->infoset = (int16_t *)calloc(MAXN, 2); t->legal = (int8_t *)calloc(MAXN * 4, 1);
+    t->child = (int32_t *)calloc(MAXN * 4, 4); t->r2 = (int8_t *)calloc(MAXN * 2, 1);
+    t->state = (og_state *)calloc(MAXN, sizeof(og_state));
+    t->infoset_str = (char(*)[64])calloc(MAXN, 64);
+    t->infoset_nlegal = (int8_t *)calloc(MAXN, 1); t->infoset_legal = (int8_t *)calloc(MAXN * 4, 1);
+    t->infoset_player = (int8_t *)calloc(MAXN, 1);
+    og_state s;
+    og_reset(&s, perm);
+    tree_rec(t, &s, 0);
+    return t;
+}
+
+void og_tree_free(og_tree *t) {
+    if (!t) return;
+    free(t->term); free(t->player); free(t->nlegal); free(t->depth); free(t->infoset); free(t->legal);
+    free(t->child); free(t->r2); free(t->state); free(t->infoset_str); free(t->infoset_nlegal);
+    free(t->infoset_legal); free(t->infoset_player); free(t);
+}
+
+int og_tree_counts(const og_tree *t, int *n_nodes, int *n_decision, int *n_infosets) {
+    *n_nodes = t->n_nodes; *n_decision = t->n_decision; *n_infosets = t->n_infosets;
+    return 0;
+}
+
+int og_tree_export(const og_tree *t, int8_t *term, int8_t *player, int8_t *nlegal, int8_t *depth,
+                   int16_t *infoset, int8_t *legal, int32_t *child, int8_t *r2) {
+    size_t n = (size_t)t->n_nodes;
+    memcpy(term, t->term, n); memcpy(player, t->player, n); memcpy(nlegal, t->nlegal, n);
+    memcpy(depth, t->depth, n); memcpy(infoset, t->infoset, n * 2); memcpy(legal, t->legal, n * 4);
+    memcpy(child, t->child, n * 16); memcpy(r2, t->r2, n * 2);
+    return 0;
+}
+
+int og_tree_states(const og_tree *t, int8_t *hands, int8_t *nh, int8_t *table, int8_t *nt, int8_t *ncap,
+                   int8_t *scopas, int8_t *step) {
+    for (int i = 0; i < t->n_nodes; i++) {
+        const og_state *s = &t->state[i];
+        for (int p = 0; p < 2; p++) {
+            for (int k = 0; k < 4; k++) hands[(i * 2 + p) * 4 + k] = (int8_t)(k < s->nh[p] ? s->hand[p][k] : -1);
+            nh[i * 2 + p] = s->nh[p]; ncap[i * 2 + p] = s->ncap[p]; scopas[i * 2 + p] = s->scopas[p];
+        }
+        for (int k = 0; k < 8; k++) table[i * 8 + k] = (int8_t)(k < s->nt ? s->table[k] : -1);
+        nt[i] = s->nt; step[i] = s->step;
+    }
+    return 0;
+}
+
+int og_tree_infoset_string(const og_tree *t, int id, char *buf) {
+    strcpy(buf, t->infoset_str[id]);
+    return (int)strlen(buf);
+}
+
+int og_tree_infoset_meta(const og_tree *t, int8_t *nlegal, int8_t *legal, int8_t *player) {
+    memcpy(nlegal, t->infoset_nlegal, (size_t)t->n_infosets);
+    memcpy(legal, t->infoset_legal, (size_t)t->n_infosets * 4);
+    memcpy(player, t->infoset_player, (size_t)t->n_infosets);
+    return 0;
+}
+
+/* ===== numpy float64 reductions on <= 4 elements =================================== */
+/* np.sum / ndarray.sum on a contiguous float64 vector of n < 8 elements: the add.reduce
+ * inner loop is DOUBLE_pairwise_sum's small-n branch, a left-to-right running sum
+ * (numpy/_core/src/umath/loops_utils.h.src).  Pinned bit-exactly by tests/golden/vanilla_cfr.npz. */
+static double np_sum(const double *a, int n) {
+    double r = a[0];
+    for (int i = 1; i < n; i++) r += a[i];
+    return r;
+}
+/* np.dot of two float64 vectors, n <= 4.  numpy hands this to cblas_ddot; with the numpy 2.2.6
+ * wheel used to generate the fixtures (scipy-openblas 0.3.29, x86-64 with FMA3) the n < 32 tail loop
+ * `dot += y[i]*x[i]` is FMA-contracted: a left-to-right chain r = fma(a[i], b[i], r) from r = 0.
+ * Determined empirically against np.dot (3000 random vectors per n: 100 % fma chain, 81-91 % mul+add)
+ * and pinned bit-exactly by tests/golden/mccfr.npz (9 runs up to 200 iterations). */
+static double np_dot(const double *a, const double *b, int n) {
+    double r = 0.0;
+    for (int i = 0; i < n; i++) r = fma(a[i], b[i], r);
+    return r;
+}
+
+/* ===== vanilla CFR, exact sequential semantics ===================================== */
+void og_tables_init(const og_tree *t, double *regret, double *strat, double *local) {
+    /* InfoNode.__post_init__, vanilla_cfr.py:15-21 */
+    for (int i = 0; i < t->n_infosets; i++) {
+        int n = t->infoset_nlegal[i];
+        for (int k = 0; k < 4; k++) {
+            if (regret) regret[i * 4 + k] = 0.0;
+            if (strat) strat[i * 4 + k] = 0.0;
+            if (local) local[i * 4 + k] = k < n ? 1.0 / (double)n : 0.0; /* np.ones(n)/n */
+        }
+    }
+}
+
+static void regret_match(const double *R, int n, double *out) {
+    /* InfoNode.get_strategy, vanilla_cfr.py:23-30 */
+    double pos[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) pos[i] = R[i] > 0.0 ? R[i] : 0.0; /* np.maximum(R, 0) */
+    double s = np_sum(pos, n);
+    if (s > 0.0) for (int i = 0; i < n; i++) out[i] = pos[i] / s;
+    else         for (int i = 0; i < n; i++) out[i] = 1.0 / (double)n;
+}
+
+static double cfr_rec(const og_tree *t, double *R, double *S, double *L, int node, int trav, double r0, double r1) {
+    /* CFRTrainer._cfr_recursive, vanilla_cfr.py:56-99 */
+    if (t->term[node]) return (double)t->r2[node * 2 + trav] * 0.5;
+    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node];
+    double *ls = L + I * 4;
+    double au[4], prod[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) { /* :79-85 */
+        int c = t->child[node * 4 + i];
+        au[i] = p == 0 ? cfr_rec(t, R, S, L, c, trav, r0 * ls[i], r1)
+                       : cfr_rec(t, R, S, L, c, trav, r0, r1 * ls[i]);
+    }
+    for (int i = 0; i < n; i++) prod[i] = ls[i] * au[i];
+    double v = np_sum(prod, n); /* :87 */
+    if (p == trav) { /* :89-95 */
+        double reach = trav == 0 ? r0 : r1, opp = trav == 0 ? r1 : r0;
+        for (int i = 0; i < n; i++) {
+            double regret = au[i] - v;
+            R[I * 4 + i] += opp * regret;
+            S[I * 4 + i] += reach * ls[i];
+        }
+    }
+    regret_match(R + I * 4, n, ls); /* :97, every visit */
+    return v;
+}
+
+void og_cfr_exact(const og_tree *t, double *regret, double *strat, double *local, int n_iters, double *root_values) {
+    /* CFRTrainer.train, vanilla_cfr.py:105-110 */
+    for (int it = 0; it < n_iters; it++)
+        for (int i = 0; i < 2; i++) {
+            double v = cfr_rec(t, regret, strat, local, 0, i, 1.0, 1.0);
+            if (root_values) root_values[it * 2 + i] = v;
+        }
+}
+
+/* ===== MCCFR replay (reference semantics, host-supplied uniforms) ================== */
+static int np_choice(const double *p, int n, double u) {
+    /* np.random.choice(a, p=p): cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(u, 'right') */
+    double cdf[4];
+    double c = 0.0;
+    for (int i = 0; i < n; i++) { c = i ? c + p[i] : p[0]; cdf[i] = c; }
+    double last = cdf[n - 1];
+    int idx = 0;
+    for (int i = 0; i < n; i++) { cdf[i] /= last; if (cdf[i] <= u) idx = i + 1; }
+    return idx < n ? idx : n - 1;
+}
+
+static void mc_strategy(const double *R, int n, double *sigma) {
+    /* InfoNode.current_strategy, mc_cfr.py:20-24 */
+    double pos[4] = {0, 0, 0, 0};
+    for (int i = 0; i < n; i++) pos[i] = R[i] > 0.0 ? R[i] : 0.0;
+    double s = np_sum(pos, n);
+    if (s == 0.0) for (int i = 0; i < n; i++) sigma[i] = 1.0 / (double)n;
+    else          for (int i = 0; i < n; i++) sigma[i] = pos[i] / s;
+}
+
+typedef struct { const double *u; int64_t pos, n; } ustream;
+
+static double mc_rec(const og_tree *t, double *R, double *S, int node, int trav, const double reach[2],
+                     const double samp[2], ustream *us) {
+    /* MCCFRTrainer._sample, mc_cfr.py:37-86 */
+    if (t->term[node]) return (double)t->r2[node * 2 + trav] * 0.5;
+    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node];
+    double sigma[4];
+    mc_strategy(R + I * 4, n, sigma);
+    double u = us->pos < us->n ? us->u[us->pos] : 0.0;
+    us->pos++;
+    int a = np_choice(sigma, n, u); /* :55 */
+    double nreach[2] = {reach[0], reach[1]}, nsamp[2] = {samp[0], samp[1]};
+    if (p == trav) nsamp[p] *= sigma[a];
+    else { nreach[p] *= sigma[a]; nsamp[p] *= sigma[a]; }
+    double util = mc_rec(t, R, S, t->child[node * 4 + a], trav, nreach, nsamp, us);
+    if (p == trav) { /* :69-84 */
+        double cfv[4];
+        for (int i = 0; i < n; i++) {
+            double ts[2] = {samp[0], samp[1]};
+            ts[p] *= sigma[i];
+            cfv[i] = mc_rec(t, R, S, t->child[node * 4 + i], trav, reach, ts, us);
+        }
+        double v = np_dot(sigma, cfv, n);
+        double opp_reach = reach[1 - p];
+        double weight = samp[p] > 0.0 ? opp_reach / samp[p] : 0.0;
+        for (int i = 0; i < n; i++) {
+            R[I * 4 + i] += weight * (cfv[i] - v);
+            S[I * 4 + i] += reach[p] * sigma[i];
+        }
+    }
+    return util;
+}
+
+int64_t og_mccfr_replay(const og_tree *t, double *regret, double *strat, int n_iters, const double *uniforms,
+                        int64_t n_uniforms) {
+    ustream us = {uniforms, 0, n_uniforms};
+    const double one[2] = {1.0, 1.0};
+    for (int it = 0; it < n_iters; it++)
+        for (int p = 0; p < 2; p++) /* iteration(), mc_cfr.py:88-92 */
+            mc_rec(t, regret, strat, 0, p, one, one, &us);
+    return us.pos;
+}
+
+/* ===== Philox4x32-10 (Salmon et al., SC'11; Random123 reference constants) ========= */
+void og_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]) {
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3], k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; r++) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0, p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0, n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1, n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+double og_philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
+    uint32_t ctr[4] = {c0, c1, c2, c3}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, o[4];
+    og_philox4x32_10(ctr, key, o);
+    /* 53-bit double in [0,1), the genrand_res53 construction numpy's random_sample uses */
+    return ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) / 9007199254740992.0;
+}
+
+/* ===== batched MCCFR (frozen tables, path-keyed RNG) ================================ */
+/* A node of one traversal's recursion tree is named by its depth and by the branch taken
+ * at each traverser node above it: digit 0 = the sampled child (mc_cfr.py:55-67),
+ * digit i+1 = the re-expansion of legal action i (:72-78).  code = depth + 16*sum(digit_k * 8^k).
+ * The uniform for that node is Philox(key=seed; ctr = (code, traversal id, iteration, traverser)). */
+typedef struct {
+    const og_tree *t; const double *R; double *dR, *dS;
+    uint64_t seed; uint32_t iter, b; int trav;
+    uint64_t dvis, tvis;
+    int32_t *tr_nodes; int8_t *tr_actions; int tr_n, tr_max;
+} bctx;
+
+static double mcb_rec(bctx *c, int node, uint32_t digits, int ntl, double reach_opp, double samp_trav) {
+    const og_tree *t = c->t;
+    if (t->term[node]) { c->tvis++; return (double)t->r2[node * 2 + c->trav] * 0.5; }
+    c->dvis++;
+    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node], depth = t->depth[node];
+    double sigma[4];
+    mc_strategy(c->R + I * 4, n, sigma);
+    double u = og_philox_uniform(c->seed, (uint32_t)depth + 16u * digits, c->b, c->iter, (uint32_t)c->trav);
+    int a = np_choice(sigma, n, u);
+    if (c->tr_nodes && c->tr_n < c->tr_max) { c->tr_nodes[c->tr_n] = node; c->tr_actions[c->tr_n] = (int8_t)a; }
+    c->tr_n++;
+    if (p != c->trav)
+        return mcb_rec(c, t->child[node * 4 + a], digits, ntl, reach_opp * sigma[a], samp_trav);
+    double util = mcb_rec(c, t->child[node * 4 + a], digits, ntl + 1, reach_opp, samp_trav * sigma[a]);
+    double cfv[4];
+    for (int i = 0; i < n; i++)
+        cfv[i] = mcb_rec(c, t->child[node * 4 + i], digits + ((uint32_t)(i + 1) << (3 * ntl)), ntl + 1, reach_opp,
+                         samp_trav * sigma[i]);
+    double v = np_dot(sigma, cfv, n);
+    double w = samp_trav > 0.0 ? reach_opp / samp_trav : 0.0;
+    if (c->dR)
+        for (int i = 0; i < n; i++) {
+            c->dR[I * 4 + i] += w * (cfv[i] - v);
+            c->dS[I * 4 + i] += sigma[i]; /* reach[traverser] is never multiplied: always 1.0 (mc_cfr.py:61-65) */
+        }
+    return util;
+}
+
+void og_mccfr_batched_delta(const og_tree *t, const double *regret, double *d_regret, double *d_strat, uint64_t seed,
+                            uint32_t iteration, uint32_t b0, uint32_t nb, uint64_t *decision_visits,
+                            uint64_t *terminal_visits) {
+    bctx c;
+    memset(&c, 0, sizeof c);
+    c.t = t; c.R = regret; c.dR = d_regret; c.dS = d_strat; c.seed = seed; c.iter = iteration;
+    for (uint32_t b = b0; b < b0 + nb; b++)
+        for (int p = 0; p < 2; p++) {
+            c.b = b; c.trav = p;
+            mcb_rec(&c, 0, 0, 0, 1.0, 1.0);
+        }
+    if (decision_visits) *decision_visits += c.dvis;
+    if (terminal_visits) *terminal_visits += c.tvis;
+}
+
+void og_mccfr_batched(const og_tree *t, double *regret, double *strat, uint64_t seed, uint32_t iter0, uint32_t n_iters,
+                      uint32_t batch, uint64_t *decision_visits) {
+    size_t cells = (size_t)t->n_infosets * 4;
+    double *dR = (double *)malloc(cells * 8), *dS = (double *)malloc(cells * 8);
+    for (uint32_t it = 0; it < n_iters; it++) {
+        memset(dR, 0, cells * 8); memset(dS, 0, cells * 8);
+        og_mccfr_batched_delta(t, regret, dR, dS, seed, iter0 + it, 0, batch, decision_visits, NULL);
+        for (size_t k = 0; k < cells; k++) { regret[k] += dR[k]; strat[k] += dS[k]; }
+    }
+    free(dR); free(dS);
+}
+
+int og_mccfr_batched_trace(const og_tree *t, const double *regret, uint64_t seed, uint32_t iteration, uint32_t b,
+                           int traverser, int32_t *nodes, int8_t *actions, int max_out) {
+    bctx c;
+    memset(&c, 0, sizeof c);
+    c.t = t; c.R = regret; c.seed = seed; c.iter = iteration; c.b = b; c.trav = traverser;
+    c.tr_nodes = nodes; c.tr_actions = actions; c.tr_max = max_out;
+    mcb_rec(&c, 0, 0, 0, 1.0, 1.0);
+    return c.tr_n;
+}
+
+/* ===== synchronous CFR (build-defined) ============================================= */
+static double sync_rec(const og_tree *t, const double *sig, double *dR, double *dS, int node, double r0, double r1,
+                       double *v1_out) {
+    /* returns value for P0; P1's value is the negation (zero-sum, evaluate_game :106-114) */
+    (void)v1_out;
+    if (t->term[node]) return (double)t->r2[node * 2] * 0.5;
+    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node];
+    const double *s = sig + I * 4;
+    double au[4];
+    for (int i = 0; i < n; i++)
+        au[i] = p == 0 ? sync_rec(t, sig, dR, dS, t->child[node * 4 + i], r0 * s[i], r1, NULL)
+                       : sync_rec(t, sig, dR, dS, t->child[node * 4 + i], r0, r1 * s[i], NULL);
+    double v = 0.0;
+    for (int i = 0; i < n; i++) v += s[i] * au[i];
+    double reach = p == 0 ? r0 : r1, opp = p == 0 ? r1 : r0, sgn = p == 0 ? 1.0 : -1.0;
+    for (int i = 0; i < n; i++) {
+        dR[I * 4 + i] += opp * (sgn * (au[i] - v));
+        dS[I * 4 + i] += reach * s[i];
+    }
+    return v;
+}
+
+void og_cfr_sync(const og_tree *t, double *regret, double *strat, int n_iters) {
+    size_t cells = (size_t)t->n_infosets * 4;
+    double *sig = (double *)calloc(cells, 8), *dR = (double *)malloc(cells * 8), *dS = (double *)malloc(cells * 8);
+    for (int it = 0; it < n_iters; it++) {
+        for (int i = 0; i < t->n_infosets; i++) regret_match(regret + i * 4, t->infoset_nlegal[i], sig + i * 4);
+        memset(dR, 0, cells * 8); memset(dS, 0, cells * 8);
+        sync_rec(t, sig, dR, dS, 0, 1.0, 1.0, NULL);
+        for (size_t k = 0; k < cells; k++) { regret[k] += dR[k]; strat[k] += dS[k]; }
+    }
+    free(sig); free(dR); free(dS);
+}
+
+/* ===== policies, value, exploitability (build-defined; parity unpinned) ============= */
+void og_average_policy(const og_tree *t, const double *strat, double *policy) {
+    /* InfoNode.policy, vanilla_cfr.py:32-39 */
+    for (int i = 0; i < t->n_infosets; i++) {
+        int n = t->infoset_nlegal[i];
+        double s = np_sum(strat + i * 4, n);
+        for (int k = 0; k < 4; k++)
+            policy[i * 4 + k] = k < n ? (s > 0.0 ? strat[i * 4 + k] / s : 1.0 / (double)n) : 0.0;
+    }
+}
+
+static double value_rec(const og_tree *t, const double *pol, int node) {
+    if (t->term[node]) return (double)t->r2[node * 2] * 0.5;
+    int I = t->infoset[node], n = t->nlegal[node];
+    double v = 0.0;
+    for (int i = 0; i < n; i++) v += pol[I * 4 + i] * value_rec(t, pol, t->child[node * 4 + i]);
+    return v;
+}
+
+double og_policy_value(const og_tree *t, const double *policy) { return value_rec(t, policy, 0); }
+
+/* Best response of `br` against `policy`, OpenSpiel's procedural definition: per infoset (string key),
+ * argmax_a sum_{h in I} opp_reach(h) * value(h.a), resolved deepest infosets first. */
+static void br_fill_reach(const og_tree *t, const double *pol, int br, int node, double opp, double *reach) {
+    reach[node] = opp;
+    if (t->term[node]) return;
+    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node];
+    for (int i = 0; i < n; i++)
+        br_fill_reach(t, pol, br, t->child[node * 4 + i], p == br ? opp : opp * pol[I * 4 + i], reach);
+}
+
+static double best_response_value(const og_tree *t, const double *pol, int br) {
+    int N = t->n_nodes;
+    double *reach = (double *)malloc((size_t)N * 8), *val = (double *)malloc((size_t)N * 8);
+    double *q = (double *)malloc((size_t)t->n_infosets * 4 * 8);
+    int8_t *choice = (int8_t *)malloc((size_t)t->n_infosets);
+    br_fill_reach(t, pol, br, 0, 1.0, reach);
+    for (int d = 8; d >= 0; d--) {
+        /* pass 1: accumulate q over the infosets of `br` at this depth (children are deeper: already valued) */
+        for (int i = 0; i < t->n_infosets * 4; i++) q[i] = 0.0;
+        for (int nd = 0; nd < N; nd++) {
+            if (t->depth[nd] != d) continue;
+            if (t->term[nd]) { val[nd] = (double)t->r2[nd * 2 + br] * 0.5; continue; }
+            if (t->player[nd] == br)
+                for (int i = 0; i < t->nlegal[nd]; i++) q[t->infoset[nd] * 4 + i] += reach[nd] * val[t->child[nd * 4 + i]];
+        }
+        for (int I = 0; I < t->n_infosets; I++) {
+            int best = 0;
+            for (int i = 1; i < t->infoset_nlegal[I]; i++) if (q[I * 4 + i] > q[I * 4 + best]) best = i;
+            choice[I] = (int8_t)best; /* overwritten only for infosets at this depth that matter below */
+        }
+        /* pass 2: node values at this depth */
+        for (int nd = 0; nd < N; nd++) {
+            if (t->depth[nd] != d || t->term[nd]) continue;
+            int I = t->infoset[nd], n = t->nlegal[nd];
+            if (t->player[nd] == br) val[nd] = val[t->child[nd * 4 + choice[I]]];
+            else {
+                double v = 0.0;
+                for (int i = 0; i < n; i++) v += pol[I * 4 + i] * val[t->child[nd * 4 + i]];
+                val[nd] = v;
+            }
+        }
+    }
+    double r = val[0];
+    free(reach); free(val); free(q); free(choice);
+    return r;
+}
+
+double og_exploitability(const og_tree *t, const double *policy, double *br_values) {
+    double b0 = best_response_value(t, policy, 0), b1 = best_response_value(t, policy, 1);
+    if (br_values) { br_values[0] = b0; br_values[1] = b1; }
+    return 0.5 * (b0 + b1); /* NashConv/2; v0(pi)+v1(pi)=0 */
+}
