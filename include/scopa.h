@@ -1,0 +1,155 @@
+/*
+ * scopa.h -- C ABI of libscopa_hip.so, the MI355X (gfx950) MiniScopa CFR traversal engine.
+ *
+ * The reference (rug-marl-group2/scopa) has no FFI: its boundary is a Python object protocol.
+ * Each entry point below therefore cites the reference Python interface it stands behind
+ * (paths relative to the reference repo root); INTEGRATION.md shows the ctypes binding a
+ * maintainer of the reference would add.
+ *
+ * Conventions
+ *   - plain C, every function returns int32 status: 0 = SCOPA_OK, negative = SCOPA_E*.
+ *     No exception or abort crosses the boundary; scopa_last_error(ctx) gives the detail string.
+ *   - opaque scopa_ctx: one context <-> one HIP device + one HIP stream (+ one deal / tree / table set).
+ *     A context is not thread-safe; distinct contexts are independent.
+ *   - bulk buffers are caller-owned and only borrowed for the duration of the call.  Arguments named
+ *     d_* are DEVICE pointers (e.g. torch.Tensor.data_ptr()), h_* are host pointers.
+ *   - solver entry points need a GPU: scopa_ctx_create fails with SCOPA_ENODEV when there is none.
+ *     There is no CPU fallback.  The scopa_state_* / scopa_deal_* helpers are host-side glue for the
+ *     single-state object protocol (State.apply_action etc.) and need no context.
+ */
+#ifndef SCOPA_H
+#define SCOPA_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SCOPA_ABI_VERSION 1
+
+enum {
+    SCOPA_OK = 0,
+    SCOPA_EINVAL = -1,   /* bad argument                                   */
+    SCOPA_ENODEV = -2,   /* no usable HIP device                           */
+    SCOPA_EHIP = -3,     /* a HIP runtime call failed (see last_error)     */
+    SCOPA_ESTATE = -4,   /* call order violated (e.g. no deal set)         */
+    SCOPA_ENOMEM = -5,
+    SCOPA_ELIMIT = -6    /* problem exceeds a compiled-in capacity         */
+};
+
+/* Deal-independent shape of MiniScopa (src/envs/mini_scopa_game.py:59,127): 2 players x 4 cards,
+ * 8 plies, legal-count profile 4,4,3,3,2,2,1,1. */
+#define SCOPA_N_CARDS 16
+#define SCOPA_N_PLIES 8
+#define SCOPA_N_DECISION 1653
+#define SCOPA_N_TERMINAL 576
+#define SCOPA_N_NODES 2229
+#define SCOPA_MAX_ACTIONS 4
+
+/* Packed game state, 16 bytes, the unit the kernels keep in HBM.  Hands and table are ORDERED lists of
+ * 4-bit card ids (card id = action id = suit*4 + rank_idx, mini_scopa_game.py:17-23,149-153); list order
+ * is part of the infoset identity (openspiel_mini_scopa.py:86-95).  Unused nibbles are zero.
+ * to_move = step & 1; terminal iff (nh[0]==0 && nh[1]==0) || step >= 8 (mini_scopa_game.py:160). */
+typedef struct scopa_state {
+    uint16_t hand[2];   /* nibble i = i-th card of the hand                  */
+    uint32_t table;     /* nibble i = i-th card on the table                 */
+    uint8_t  nh[2];     /* cards in hand                                     */
+    uint8_t  nt;        /* cards on table                                    */
+    uint8_t  step;      /* MiniScopaEnv.step_count                           */
+    uint8_t  ncap[2];   /* len(player.captures)                              */
+    uint8_t  scopas[2]; /* player.scopas                                     */
+} scopa_state;
+
+typedef struct scopa_ctx scopa_ctx;
+
+int32_t     scopa_abi_version(void);
+const char *scopa_strerror(int32_t status);
+const char *scopa_last_error(const scopa_ctx *ctx);
+
+/* device_id >= 0.  hip_stream: a hipStream_t to launch on (e.g. torch.cuda.current_stream().cuda_stream),
+ * or NULL to let the context create its own. */
+int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out);
+int32_t scopa_ctx_destroy(scopa_ctx *ctx);
+int32_t scopa_ctx_synchronize(scopa_ctx *ctx);
+
+/* ---- host-side single-state protocol (no context, no device) ------------------------------------------
+ * stands behind MiniScopaState / MiniScopaEnv: src/envs/openspiel_mini_scopa.py:17-115,
+ * src/envs/mini_scopa_game.py:117-194 */
+int32_t scopa_deal_py_seed(int64_t seed, uint8_t perm16[16]);              /* MiniDeck.__init__ :25-28        */
+int32_t scopa_state_init(const uint8_t perm16[16], scopa_state *out);      /* MiniScopaGame.reset :56-64      */
+int32_t scopa_state_step(scopa_state *s, int32_t action);                  /* MiniScopaEnv.step :140-167      */
+int32_t scopa_state_is_terminal(const scopa_state *s);                     /* 0/1                             */
+int32_t scopa_state_current_player(const scopa_state *s);                  /* 0/1, -4 at terminal             */
+int32_t scopa_state_legal(const scopa_state *s, int32_t player /* <0 = current */, int32_t out[4], int32_t *n);
+int32_t scopa_state_rewards_x2(const scopa_state *s, int32_t r2[2]);       /* evaluate_game :106-114, x2      */
+int32_t scopa_state_infoset_key(const scopa_state *s, int32_t player, uint64_t *key);
+int32_t scopa_key_to_string(uint64_t key, char *buf, int32_t cap);         /* information_state_string :86-95 */
+int32_t scopa_state_infoset_string(const scopa_state *s, int32_t player, char *buf, int32_t cap);
+
+/* ---- batched game step (HIP kernel) --------------------------------------------------------------------
+ * d_states[i] <- step(d_states[i], d_actions[i]); same semantics as scopa_state_step incl. the silent no-op. */
+int32_t scopa_step_batch(scopa_ctx *ctx, scopa_state *d_states, const uint8_t *d_actions, int64_t n);
+/* convenience for host buffers: H2D, kernel, D2H on the context's stream, synchronous */
+int32_t scopa_step_batch_host(scopa_ctx *ctx, scopa_state *h_states, const uint8_t *h_actions, int64_t n);
+
+/* ---- deal + game tree (built ON DEVICE by level-synchronous expansion with the step kernel) ------------
+ * stands behind game.new_initial_state() + the clone()/apply_action() recursion of every solver */
+int32_t scopa_set_deal(scopa_ctx *ctx, const uint8_t perm16[16]);          /* builds tree, zeroes tables      */
+int32_t scopa_tree_counts(scopa_ctx *ctx, int32_t *n_nodes, int32_t *n_decision, int32_t *n_infosets);
+/* Export in REFERENCE DFS ORDER (the order vanilla_cfr.py:79-85 visits nodes); any pointer may be NULL.
+ * h_states[n_nodes], h_infoset[n_nodes] (-1 at terminals; ids in first-visit order = dict insertion order),
+ * h_r2[n_nodes][2], h_infoset_key[n_infosets], h_infoset_nlegal[n_infosets], h_infoset_legal[n_infosets][4] */
+int32_t scopa_tree_export(scopa_ctx *ctx, scopa_state *h_states, int32_t *h_infoset, int8_t *h_r2,
+                          uint64_t *h_infoset_key, int8_t *h_infoset_nlegal, int8_t *h_infoset_legal);
+
+/* ---- tables: [n_infosets][4] float64, rows padded with 0; any pointer may be NULL ----------------------
+ * stands behind CFRTrainer.info_set_map / MCCFRTrainer.info_sets (InfoNode.regret_sum, .strategy_sum,
+ * .local_strategy): src/algorithms/vanilla_cfr.py:8-39,47-54, src/algorithms/mc_cfr.py:9-35 */
+int32_t scopa_tables_reset(scopa_ctx *ctx);
+int32_t scopa_tables_get(scopa_ctx *ctx, double *h_regret, double *h_strategy, double *h_local);
+int32_t scopa_tables_set(scopa_ctx *ctx, const double *h_regret, const double *h_strategy, const double *h_local);
+
+/* ---- vanilla CFR, exact sequential semantics (CFRTrainer._cfr_recursive / .train, vanilla_cfr.py:56-110)
+ * n_iters iterations of "for i in (0,1): traverse(root, i, 1.0, 1.0)"; h_root_values[n_iters][2] or NULL.
+ * Reproduces the reference bit-for-bit, incl. the mid-traversal local_strategy refresh (:97). */
+int32_t scopa_cfr_exact_iterate(scopa_ctx *ctx, int32_t n_iters, double *h_root_values);
+/* one traversal: CFRTrainer._cfr_recursive(new_initial_state(), player, 1.0, 1.0) -> value */
+int32_t scopa_cfr_exact_traverse(scopa_ctx *ctx, int32_t traverser, double *h_value);
+
+/* ---- MCCFR replay: MCCFRTrainer.iteration() (mc_cfr.py:37-92) driven by a host-supplied uniform stream
+ * (one float64 per decision visit in DFS order = what np.random.choice draws); bit-exact vs the reference. */
+int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_uniforms, int64_t n_uniforms,
+                           int64_t *consumed);
+
+/* ---- batched external-sampling MCCFR (the throughput path) ----------------------------------------------
+ * `batch` traversals per traverser per iteration against tables frozen for the iteration; random draws from
+ * Philox4x32-10 keyed by (seed; recursion-path code, global traversal id, iteration, traverser), so results do
+ * not depend on how traversals are split over launches or GPUs. */
+int32_t scopa_mccfr_seed(scopa_ctx *ctx, uint64_t seed);
+/* n_iters x { traverse [0,batch) ; apply } on this device */
+int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters);
+/* multi-GPU building blocks: accumulate the deltas of global traversal ids [b0, b0+nb) of `iteration` ... */
+int32_t scopa_mccfr_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb);
+/* ... expose the delta buffer ([n_infosets][5] float64: 4 regret deltas + traverser-visit count) for one
+ * sum-all-reduce (RCCL via torch.distributed) ... */
+int32_t scopa_mccfr_delta_buffer(scopa_ctx *ctx, void **d_delta, size_t *bytes);
+/* host copy of the delta buffer, h_delta[n_infosets][5] (tests, non-RCCL transports) and its inverse */
+int32_t scopa_mccfr_delta_get(scopa_ctx *ctx, double *h_delta);
+int32_t scopa_mccfr_delta_set(scopa_ctx *ctx, const double *h_delta);
+/* ... then regret += delta[:, :4]; strategy += count * sigma; delta <- 0; iteration counter += 1 */
+int32_t scopa_mccfr_apply(scopa_ctx *ctx);
+int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration);
+
+/* ---- counters / profiling -------------------------------------------------------------------------------
+ * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
+int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);
+/* when enabled, every launch of the dominant traversal kernel is bracketed by HIP events on the context's
+ * stream; scopa_prof_read synchronises and returns launches and the summed kernel milliseconds since enable */
+int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t on);
+int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SCOPA_H */

@@ -476,15 +476,16 @@ void og_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out
 double og_philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3) {
     uint32_t ctr[4] = {c0, c1, c2, c3}, key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)}, o[4];
     og_philox4x32_10(ctr, key, o);
-    /* 53-bit double in [0,1), the genrand_res53 construction numpy's random_sample uses */
     return ((double)(o[0] >> 5) * 67108864.0 + (double)(o[1] >> 6)) / 9007199254740992.0;
 }
 
 /* ===== batched MCCFR (frozen tables, path-keyed RNG) ================================ */
-/* A node of one traversal's recursion tree is named by its depth and by the branch taken
- * at each traverser node above it: digit 0 = the sampled child (mc_cfr.py:55-67),
- * digit i+1 = the re-expansion of legal action i (:72-78).  code = depth + 16*sum(digit_k * 8^k).
- * The uniform for that node is Philox(key=seed; ctr = (code, traversal id, iteration, traverser)). */
+/* A node of one traversal's recursion tree is named by the branches taken at the traverser nodes above
+ * it: digit 0 = the sampled child (mc_cfr.py:55-67), digit i+1 = the re-expansion of legal action i
+ * (:72-78); `ntl` = how many traverser nodes lie above.  An opponent node and the traverser node that
+ * follows it share (ntl, digits); one Philox block serves both:
+ *   block = Philox4x32-10(key = seed; ctr = (ntl + 16*sum(digit_k * 8^k), traversal id, iteration, traverser))
+ *   opponent node: u = u53(x0, x1)      traverser node: u = u53(x2, x3)                                   */
 typedef struct {
     const og_tree *t; const double *R; double *dR, *dS;
     uint64_t seed; uint32_t iter, b; int trav;
@@ -492,14 +493,22 @@ typedef struct {
     int32_t *tr_nodes; int8_t *tr_actions; int tr_n, tr_max;
 } bctx;
 
+static double u53(uint32_t a, uint32_t b) {
+    /* 53-bit double in [0,1), the genrand_res53 construction numpy's random_sample uses */
+    return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
+}
+
 static double mcb_rec(bctx *c, int node, uint32_t digits, int ntl, double reach_opp, double samp_trav) {
     const og_tree *t = c->t;
     if (t->term[node]) { c->tvis++; return (double)t->r2[node * 2 + c->trav] * 0.5; }
     c->dvis++;
-    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node], depth = t->depth[node];
+    int p = t->player[node], I = t->infoset[node], n = t->nlegal[node];
     double sigma[4];
     mc_strategy(c->R + I * 4, n, sigma);
-    double u = og_philox_uniform(c->seed, (uint32_t)depth + 16u * digits, c->b, c->iter, (uint32_t)c->trav);
+    uint32_t ctr[4] = {(uint32_t)ntl + 16u * digits, c->b, c->iter, (uint32_t)c->trav};
+    uint32_t key[2] = {(uint32_t)c->seed, (uint32_t)(c->seed >> 32)}, o[4];
+    og_philox4x32_10(ctr, key, o);
+    double u = p == c->trav ? u53(o[2], o[3]) : u53(o[0], o[1]);
     int a = np_choice(sigma, n, u);
     if (c->tr_nodes && c->tr_n < c->tr_max) { c->tr_nodes[c->tr_n] = node; c->tr_actions[c->tr_n] = (int8_t)a; }
     c->tr_n++;

@@ -1,0 +1,280 @@
+"""ctypes binding of libscopa_hip.so (the C ABI declared in include/scopa.h).
+
+The product path: every solver entry point goes through this library's HIP kernels.  There is no
+Python or CPU fallback -- if the library is missing or no GPU is present the call raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libscopa_hip.so")
+
+SCOPA_OK, SCOPA_EINVAL, SCOPA_ENODEV, SCOPA_EHIP, SCOPA_ESTATE, SCOPA_ENOMEM, SCOPA_ELIMIT = 0, -1, -2, -3, -4, -5, -6
+N_NODES, N_DECISION, N_TERMINAL = 2229, 1653, 576
+
+# every symbol include/scopa.h declares (tests check that the library exports all of them)
+SYMBOLS = [
+    "scopa_abi_version", "scopa_strerror", "scopa_last_error", "scopa_ctx_create", "scopa_ctx_destroy",
+    "scopa_ctx_synchronize", "scopa_deal_py_seed", "scopa_state_init", "scopa_state_step", "scopa_state_is_terminal",
+    "scopa_state_current_player", "scopa_state_legal", "scopa_state_rewards_x2", "scopa_state_infoset_key",
+    "scopa_key_to_string", "scopa_state_infoset_string", "scopa_step_batch", "scopa_step_batch_host", "scopa_set_deal",
+    "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
+    "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_mccfr_replay", "scopa_mccfr_seed",
+    "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
+    "scopa_mccfr_iteration_counter", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+]
+
+
+class ScopaError(RuntimeError):
+    def __init__(self, status, where, detail=""):
+        self.status = status
+        msg = f"{where}: status {status}"
+        try:
+            msg += f" ({lib().scopa_strerror(status).decode()})"
+        except Exception:
+            pass
+        if detail:
+            msg += f": {detail}"
+        super().__init__(msg)
+
+
+class State16(C.Structure):
+    """scopa_state, 16 bytes (include/scopa.h)."""
+    _fields_ = [("hand", C.c_uint16 * 2), ("table", C.c_uint32), ("nh", C.c_uint8 * 2), ("nt", C.c_uint8),
+                ("step", C.c_uint8), ("ncap", C.c_uint8 * 2), ("scopas", C.c_uint8 * 2)]
+
+
+STATE_DTYPE = np.dtype([("hand", "<u2", (2,)), ("table", "<u4"), ("nh", "u1", (2,)), ("nt", "u1"), ("step", "u1"),
+                        ("ncap", "u1", (2,)), ("scopas", "u1", (2,))])
+assert STATE_DTYPE.itemsize == 16 and C.sizeof(State16) == 16
+
+_lib = None
+
+
+def lib():
+    """Load the library (raises OSError loudly if it has not been built: python -m scopa_amd.build)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise OSError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or `python scopa_amd/build.py` "
+                      "(the MiniScopa solver path has no fallback)")
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, u32, u64 = C.c_void_p, C.c_int32, C.c_int64, C.c_uint32, C.c_uint64
+    sig = {
+        "scopa_abi_version": (i32, []),
+        "scopa_strerror": (C.c_char_p, [i32]),
+        "scopa_last_error": (C.c_char_p, [vp]),
+        "scopa_ctx_create": (i32, [i32, vp, C.POINTER(vp)]),
+        "scopa_ctx_destroy": (i32, [vp]),
+        "scopa_ctx_synchronize": (i32, [vp]),
+        "scopa_deal_py_seed": (i32, [i64, vp]),
+        "scopa_state_init": (i32, [vp, C.POINTER(State16)]),
+        "scopa_state_step": (i32, [C.POINTER(State16), i32]),
+        "scopa_state_is_terminal": (i32, [C.POINTER(State16)]),
+        "scopa_state_current_player": (i32, [C.POINTER(State16)]),
+        "scopa_state_legal": (i32, [C.POINTER(State16), i32, C.POINTER(i32 * 4), C.POINTER(i32)]),
+        "scopa_state_rewards_x2": (i32, [C.POINTER(State16), C.POINTER(i32 * 2)]),
+        "scopa_state_infoset_key": (i32, [C.POINTER(State16), i32, C.POINTER(u64)]),
+        "scopa_key_to_string": (i32, [u64, C.c_char_p, i32]),
+        "scopa_state_infoset_string": (i32, [C.POINTER(State16), i32, C.c_char_p, i32]),
+        "scopa_step_batch": (i32, [vp, vp, vp, i64]),
+        "scopa_step_batch_host": (i32, [vp, vp, vp, i64]),
+        "scopa_set_deal": (i32, [vp, vp]),
+        "scopa_tree_counts": (i32, [vp, C.POINTER(i32), C.POINTER(i32), C.POINTER(i32)]),
+        "scopa_tree_export": (i32, [vp, vp, vp, vp, vp, vp, vp]),
+        "scopa_tables_reset": (i32, [vp]),
+        "scopa_tables_get": (i32, [vp, vp, vp, vp]),
+        "scopa_tables_set": (i32, [vp, vp, vp, vp]),
+        "scopa_cfr_exact_iterate": (i32, [vp, i32, vp]),
+        "scopa_cfr_exact_traverse": (i32, [vp, i32, C.POINTER(C.c_double)]),
+        "scopa_mccfr_replay": (i32, [vp, i32, vp, i64, C.POINTER(i64)]),
+        "scopa_mccfr_seed": (i32, [vp, u64]),
+        "scopa_mccfr_iterate": (i32, [vp, u32, u32]),
+        "scopa_mccfr_traverse": (i32, [vp, u32, u32, u32]),
+        "scopa_mccfr_delta_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "scopa_mccfr_delta_get": (i32, [vp, vp]),
+        "scopa_mccfr_delta_set": (i32, [vp, vp]),
+        "scopa_mccfr_apply": (i32, [vp]),
+        "scopa_mccfr_iteration_counter": (i32, [vp, C.POINTER(u32)]),
+        "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "scopa_prof_enable": (i32, [vp, i32]),
+        "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    if L.scopa_abi_version() != 1:
+        raise OSError("libscopa_hip.so ABI version mismatch")
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def deal_py_seed(seed):
+    """16-card permutation of random.seed(seed); random.shuffle(deck) (MiniDeck, mini_scopa_game.py:25-28)."""
+    perm = np.zeros(16, np.uint8)
+    rc = lib().scopa_deal_py_seed(int(seed), _ptr(perm))
+    if rc:
+        raise ScopaError(rc, "scopa_deal_py_seed")
+    return perm
+
+
+def key_to_string(key):
+    buf = C.create_string_buffer(96)
+    rc = lib().scopa_key_to_string(int(key), buf, 96)
+    if rc < 0:
+        raise ScopaError(rc, "scopa_key_to_string")
+    return buf.value.decode()
+
+
+class Context:
+    """One scopa_ctx: a HIP device + stream + (after set_deal) one game tree and its tables."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        self._L = lib()
+        rc = self._L.scopa_ctx_create(int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if rc:
+            self._h = None
+            raise ScopaError(rc, "scopa_ctx_create", "a GPU is required: the solver path has no CPU fallback")
+        self.device = device
+        self.n_infosets = 0
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.scopa_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _ck(self, rc, where):
+        if rc:
+            raise ScopaError(rc, where, self._L.scopa_last_error(self._h).decode())
+
+    def synchronize(self):
+        self._ck(self._L.scopa_ctx_synchronize(self._h), "scopa_ctx_synchronize")
+
+    # ---- batched step ---------------------------------------------------------------------
+    def step_batch_host(self, states, actions):
+        """states: np array of STATE_DTYPE (modified in place), actions: uint8."""
+        assert states.dtype == STATE_DTYPE and states.flags.c_contiguous
+        actions = np.ascontiguousarray(actions, np.uint8)
+        assert actions.size == states.size
+        self._ck(self._L.scopa_step_batch_host(self._h, _ptr(states), _ptr(actions), states.size), "scopa_step_batch_host")
+        return states
+
+    def step_batch(self, d_states_ptr, d_actions_ptr, n):
+        self._ck(self._L.scopa_step_batch(self._h, C.c_void_p(d_states_ptr), C.c_void_p(d_actions_ptr), int(n)), "scopa_step_batch")
+
+    # ---- deal / tree ------------------------------------------------------------------------
+    def set_deal(self, perm16):
+        perm = np.ascontiguousarray(perm16, np.uint8)
+        assert perm.size == 16
+        self._ck(self._L.scopa_set_deal(self._h, _ptr(perm)), "scopa_set_deal")
+        a, b, c = C.c_int32(), C.c_int32(), C.c_int32()
+        self._ck(self._L.scopa_tree_counts(self._h, C.byref(a), C.byref(b), C.byref(c)), "scopa_tree_counts")
+        self.n_infosets = c.value
+        self.perm = perm
+        return self.n_infosets
+
+    def tree_export(self):
+        I = self.n_infosets
+        out = dict(states=np.zeros(N_NODES, STATE_DTYPE), infoset=np.zeros(N_NODES, np.int32), r2=np.zeros((N_NODES, 2), np.int8),
+                   infoset_key=np.zeros(I, np.uint64), infoset_nlegal=np.zeros(I, np.int8), infoset_legal=np.zeros((I, 4), np.int8))
+        self._ck(self._L.scopa_tree_export(self._h, _ptr(out["states"]), _ptr(out["infoset"]), _ptr(out["r2"]),
+                                           _ptr(out["infoset_key"]), _ptr(out["infoset_nlegal"]), _ptr(out["infoset_legal"])),
+                 "scopa_tree_export")
+        return out
+
+    # ---- tables ------------------------------------------------------------------------------
+    def tables_reset(self):
+        self._ck(self._L.scopa_tables_reset(self._h), "scopa_tables_reset")
+
+    def tables_get(self, regret=True, strategy=True, local=True):
+        I = self.n_infosets
+        R = np.zeros((I, 4)) if regret else None
+        S = np.zeros((I, 4)) if strategy else None
+        Lc = np.zeros((I, 4)) if local else None
+        self._ck(self._L.scopa_tables_get(self._h, _ptr(R), _ptr(S), _ptr(Lc)), "scopa_tables_get")
+        return R, S, Lc
+
+    def tables_set(self, regret=None, strategy=None, local=None):
+        arrs = []
+        for a in (regret, strategy, local):
+            if a is not None:
+                a = np.ascontiguousarray(a, np.float64)
+                assert a.shape == (self.n_infosets, 4)
+            arrs.append(a)
+        self._ck(self._L.scopa_tables_set(self._h, _ptr(arrs[0]), _ptr(arrs[1]), _ptr(arrs[2])), "scopa_tables_set")
+
+    # ---- solvers ------------------------------------------------------------------------------
+    def cfr_exact_iterate(self, n_iters):
+        rv = np.zeros((max(int(n_iters), 0), 2))
+        self._ck(self._L.scopa_cfr_exact_iterate(self._h, int(n_iters), _ptr(rv)), "scopa_cfr_exact_iterate")
+        return rv
+
+    def cfr_exact_traverse(self, traverser):
+        v = C.c_double()
+        self._ck(self._L.scopa_cfr_exact_traverse(self._h, int(traverser), C.byref(v)), "scopa_cfr_exact_traverse")
+        return v.value
+
+    def mccfr_replay(self, n_iters, uniforms):
+        u = np.ascontiguousarray(uniforms, np.float64)
+        used = C.c_int64()
+        self._ck(self._L.scopa_mccfr_replay(self._h, int(n_iters), _ptr(u), u.size, C.byref(used)), "scopa_mccfr_replay")
+        return used.value
+
+    def mccfr_seed(self, seed):
+        self._ck(self._L.scopa_mccfr_seed(self._h, int(seed)), "scopa_mccfr_seed")
+
+    def mccfr_iterate(self, batch, n_iters):
+        self._ck(self._L.scopa_mccfr_iterate(self._h, int(batch), int(n_iters)), "scopa_mccfr_iterate")
+
+    def mccfr_traverse(self, iteration, b0, nb):
+        self._ck(self._L.scopa_mccfr_traverse(self._h, int(iteration), int(b0), int(nb)), "scopa_mccfr_traverse")
+
+    def mccfr_delta_buffer(self):
+        p, n = C.c_void_p(), C.c_size_t()
+        self._ck(self._L.scopa_mccfr_delta_buffer(self._h, C.byref(p), C.byref(n)), "scopa_mccfr_delta_buffer")
+        return p.value, n.value
+
+    def mccfr_delta_get(self):
+        d = np.zeros((self.n_infosets, 5))
+        self._ck(self._L.scopa_mccfr_delta_get(self._h, _ptr(d)), "scopa_mccfr_delta_get")
+        return d
+
+    def mccfr_delta_set(self, d):
+        d = np.ascontiguousarray(d, np.float64)
+        assert d.shape == (self.n_infosets, 5)
+        self._ck(self._L.scopa_mccfr_delta_set(self._h, _ptr(d)), "scopa_mccfr_delta_set")
+
+    def mccfr_apply(self):
+        self._ck(self._L.scopa_mccfr_apply(self._h), "scopa_mccfr_apply")
+
+    def mccfr_iteration(self):
+        v = C.c_uint32()
+        self._ck(self._L.scopa_mccfr_iteration_counter(self._h, C.byref(v)), "scopa_mccfr_iteration_counter")
+        return v.value
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self._ck(self._L.scopa_counters(self._h, C.byref(a), C.byref(b)), "scopa_counters")
+        return a.value, b.value
+
+    def prof_enable(self, on=True):
+        self._ck(self._L.scopa_prof_enable(self._h, 1 if on else 0), "scopa_prof_enable")
+
+    def prof_read(self):
+        n, ms = C.c_int64(), C.c_double()
+        self._ck(self._L.scopa_prof_read(self._h, C.byref(n), C.byref(ms)), "scopa_prof_read")
+        return n.value, ms.value

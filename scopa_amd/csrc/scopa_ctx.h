@@ -1,0 +1,87 @@
+// scopa_ctx.h -- context object behind the C ABI (include/scopa.h): one HIP device, one stream, one deal.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include <vector>
+
+#include "../../include/scopa.h"
+#include "scopa_rules.h"
+
+// Device-resident data of one context.
+//
+//  tree (built on device by k_tree_build, BFS/level order; the tree's shape is deal-independent so children
+//  are index arithmetic and only two small arrays are kept):
+//    d_states   [2229]  scopa_state per node            (35.7 KB)
+//    d_infoset  [1653]  uint16 dense infoset id per decision node; ids in reference DFS first-visit order
+//    d_payoff   [576]   int8 rewards_x2 of player 0 at each terminal (player 1 = negation)
+//    d_key      [1653]  uint64 infoset key per infoset id
+//  tables, row-padded [kDecision][4] float64 (only the first n_infosets rows are live):
+//    d_regret, d_strat, d_local
+//  batched MCCFR:
+//    d_delta    [kDecision][5] float64: 4 regret deltas + traverser-visit count (the all-reduce payload)
+struct scopa_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    char err[512] = {0};
+
+    bool has_deal = false;
+    uint8_t perm[16] = {0};
+    int n_infosets = 0;
+
+    scopa_state *d_states = nullptr;
+    uint16_t *d_infoset = nullptr;
+    int8_t *d_payoff = nullptr;
+    uint64_t *d_key = nullptr;
+    int32_t *d_meta = nullptr;  // [0] = n_infosets
+
+    double *d_regret = nullptr, *d_strat = nullptr, *d_local = nullptr;
+    double *d_delta = nullptr;
+    double *d_scratch = nullptr;  // root values / uniforms staging
+    size_t scratch_bytes = 0;
+
+    unsigned long long *d_counters = nullptr;  // [0] decision visits, [1] terminal visits, [2] aux
+
+    uint64_t seed = 0x5C09A;
+    uint32_t iteration = 0;
+
+    // profiling of the dominant kernel
+    bool prof_on = false;
+    std::vector<hipEvent_t> ev_pool;
+    size_t ev_used = 0;
+    int64_t prof_launches = 0;
+    double prof_ms = 0.0;
+
+    int lds_limit = 160 * 1024;
+    int n_cus = 256;
+};
+
+namespace scopa {
+
+inline int32_t fail(scopa_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess) {
+    if (ctx) {
+        if (e != hipSuccess) snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e));
+        else snprintf(ctx->err, sizeof ctx->err, "%s", what);
+    }
+    return code;
+}
+
+#define SC_HIP(ctx, call)                                                         \
+    do {                                                                          \
+        hipError_t e__ = (call);                                                  \
+        if (e__ != hipSuccess) return scopa::fail((ctx), SCOPA_EHIP, #call, e__); \
+    } while (0)
+
+#define SC_REQUIRE(ctx, cond, code, msg)                        \
+    do {                                                        \
+        if (!(cond)) return scopa::fail((ctx), (code), (msg)); \
+    } while (0)
+
+int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
+// event pair bracketing a launch of the dominant kernel when profiling is on
+void prof_begin(scopa_ctx *ctx);
+void prof_end(scopa_ctx *ctx);
+
+}  // namespace scopa

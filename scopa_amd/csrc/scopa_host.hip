@@ -1,0 +1,320 @@
+// scopa_host.hip -- context lifetime, host-side single-state glue, table I/O, counters, profiling.
+#include <string.h>
+
+#include <new>
+
+#include "scopa_ctx.h"
+
+using namespace scopa;
+
+namespace scopa {
+
+int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes) {
+    if (bytes <= ctx->scratch_bytes) return SCOPA_OK;
+    if (ctx->d_scratch) SC_HIP(ctx, hipFree(ctx->d_scratch));
+    ctx->d_scratch = nullptr;
+    ctx->scratch_bytes = 0;
+    SC_HIP(ctx, hipMalloc(&ctx->d_scratch, bytes));
+    ctx->scratch_bytes = bytes;
+    return SCOPA_OK;
+}
+
+void prof_begin(scopa_ctx *ctx) {
+    if (!ctx->prof_on) return;
+    if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
+        // drain: fold finished pairs into the running sum, then reuse the pool
+        if (ctx->ev_used) {
+            (void)hipEventSynchronize(ctx->ev_pool[ctx->ev_used - 1]);
+            for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+                float ms = 0.f;
+                if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess) ctx->prof_ms += ms;
+            }
+            ctx->ev_used = 0;
+        }
+        while (ctx->ev_pool.size() < 4096) {
+            hipEvent_t e;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            ctx->ev_pool.push_back(e);
+        }
+    }
+    if (ctx->ev_used + 2 <= ctx->ev_pool.size()) (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], ctx->stream);
+}
+
+void prof_end(scopa_ctx *ctx) {
+    if (!ctx->prof_on) return;
+    if (ctx->ev_used + 2 <= ctx->ev_pool.size()) {
+        (void)hipEventRecord(ctx->ev_pool[ctx->ev_used + 1], ctx->stream);
+        ctx->ev_used += 2;
+        ctx->prof_launches++;
+    }
+}
+
+}  // namespace scopa
+
+extern "C" {
+
+int32_t scopa_abi_version(void) { return SCOPA_ABI_VERSION; }
+
+const char *scopa_strerror(int32_t status) {
+    switch (status) {
+        case SCOPA_OK: return "ok";
+        case SCOPA_EINVAL: return "invalid argument";
+        case SCOPA_ENODEV: return "no usable HIP device (the solver path has no CPU fallback)";
+        case SCOPA_EHIP: return "HIP runtime error";
+        case SCOPA_ESTATE: return "call order violated";
+        case SCOPA_ENOMEM: return "out of memory";
+        case SCOPA_ELIMIT: return "problem exceeds a compiled-in capacity";
+        default: return "unknown status";
+    }
+}
+
+const char *scopa_last_error(const scopa_ctx *ctx) { return ctx ? ctx->err : "null context"; }
+
+int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
+    if (!out || device_id < 0) return SCOPA_EINVAL;
+    *out = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count <= 0) return SCOPA_ENODEV;
+    if (device_id >= count) return SCOPA_ENODEV;
+    scopa_ctx *ctx = new (std::nothrow) scopa_ctx();
+    if (!ctx) return SCOPA_ENOMEM;
+    ctx->device = device_id;
+    hipError_t e = hipSetDevice(device_id);
+    if (e != hipSuccess) { delete ctx; return SCOPA_ENODEV; }
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device_id) == hipSuccess) {
+        ctx->n_cus = prop.multiProcessorCount;
+        ctx->lds_limit = (int)prop.sharedMemPerBlock;
+    }
+    if (hip_stream) ctx->stream = (hipStream_t)hip_stream;
+    else {
+        e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete ctx; return SCOPA_EHIP; }
+        ctx->own_stream = true;
+    }
+    const size_t rows = (size_t)kDecision;
+    bool ok = hipMalloc(&ctx->d_states, sizeof(scopa_state) * kNodes) == hipSuccess &&
+              hipMalloc(&ctx->d_infoset, sizeof(uint16_t) * kDecision) == hipSuccess &&
+              hipMalloc(&ctx->d_payoff, kTerminal) == hipSuccess &&
+              hipMalloc(&ctx->d_key, sizeof(uint64_t) * kDecision) == hipSuccess &&
+              hipMalloc(&ctx->d_meta, sizeof(int32_t) * 8) == hipSuccess &&
+              hipMalloc(&ctx->d_regret, rows * 4 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->d_strat, rows * 4 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->d_local, rows * 4 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->d_delta, rows * 5 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream) == hipSuccess &&
+                 hipMemsetAsync(ctx->d_delta, 0, rows * 5 * sizeof(double), ctx->stream) == hipSuccess;
+    if (!ok) { scopa_ctx_destroy(ctx); return SCOPA_ENOMEM; }
+    *out = ctx;
+    return SCOPA_OK;
+}
+
+int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
+    if (!ctx) return SCOPA_EINVAL;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
+    void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
+                    ctx->d_local, ctx->d_delta, ctx->d_scratch, ctx->d_counters};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return SCOPA_OK;
+}
+
+int32_t scopa_ctx_synchronize(scopa_ctx *ctx) {
+    if (!ctx) return SCOPA_EINVAL;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+// ---- CPython random.seed(int) + random.shuffle (MiniDeck.__init__, mini_scopa_game.py:25-28) ----------------
+namespace {
+struct Mt19937 {
+    uint32_t mt[624];
+    int at = 624;
+    void seed_u32(uint32_t s) {
+        mt[0] = s;
+        for (int i = 1; i < 624; i++) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + (uint32_t)i;
+        at = 624;
+    }
+    void seed_array(const uint32_t *key, int n) {  // init_by_array, as CPython's random_seed() calls it
+        seed_u32(19650218u);
+        int i = 1, j = 0;
+        for (int k = n > 624 ? n : 624; k > 0; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+            if (++j >= n) j = 0;
+        }
+        for (int k = 623; k > 0; k--) {
+            mt[i] = (mt[i] ^ ((mt[i - 1] ^ (mt[i - 1] >> 30)) * 1566083941u)) - (uint32_t)i;
+            if (++i >= 624) { mt[0] = mt[623]; i = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    void refill() {
+        for (int k = 0; k < 624; k++) {
+            const uint32_t y = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y >> 1) ^ ((y & 1u) ? 0x9908b0dfu : 0u);
+        }
+        at = 0;
+    }
+    uint32_t next() {
+        if (at >= 624) refill();
+        uint32_t y = mt[at++];
+        y ^= y >> 11;
+        y ^= (y << 7) & 0x9d2c5680u;
+        y ^= (y << 15) & 0xefc60000u;
+        y ^= y >> 18;
+        return y;
+    }
+    uint32_t below(uint32_t n) {  // Random._randbelow_with_getrandbits
+        int bits = 32 - __builtin_clz(n);
+        uint32_t r;
+        do r = next() >> (32 - bits); while (r >= n);
+        return r;
+    }
+};
+}  // namespace
+
+int32_t scopa_deal_py_seed(int64_t seed, uint8_t perm16[16]) {
+    if (!perm16) return SCOPA_EINVAL;
+    const uint64_t a = seed < 0 ? (uint64_t)0 - (uint64_t)seed : (uint64_t)seed;  // random.seed(int) takes abs()
+    const uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+    Mt19937 g;
+    g.seed_array(key, key[1] ? 2 : 1);
+    for (int i = 0; i < 16; i++) perm16[i] = (uint8_t)i;  // deck order: suit-major, rank_idx minor = card id
+    for (uint32_t i = 15; i >= 1; i--) {                  // random.shuffle
+        const uint32_t j = g.below(i + 1);
+        const uint8_t t = perm16[i]; perm16[i] = perm16[j]; perm16[j] = t;
+    }
+    return SCOPA_OK;
+}
+
+// ---- host-side single-state protocol ---------------------------------------------------------------------------
+static bool perm_ok(const uint8_t *p) {
+    uint32_t seen = 0;
+    for (int i = 0; i < 16; i++) { if (p[i] > 15) return false; seen |= 1u << p[i]; }
+    return seen == 0xFFFFu;
+}
+
+int32_t scopa_state_init(const uint8_t perm16[16], scopa_state *out) {
+    if (!perm16 || !out || !perm_ok(perm16)) return SCOPA_EINVAL;
+    state_init(*out, perm16);
+    return SCOPA_OK;
+}
+
+int32_t scopa_state_step(scopa_state *s, int32_t action) {
+    if (!s || action < 0 || action > 15) return SCOPA_EINVAL;
+    step(*s, action);
+    return SCOPA_OK;
+}
+
+int32_t scopa_state_is_terminal(const scopa_state *s) { return s ? (is_terminal(*s) ? 1 : 0) : SCOPA_EINVAL; }
+
+int32_t scopa_state_current_player(const scopa_state *s) { return s ? current_player(*s) : SCOPA_EINVAL; }
+
+int32_t scopa_state_legal(const scopa_state *s, int32_t player, int32_t out[4], int32_t *n) {
+    if (!s || !out || !n || player > 1) return SCOPA_EINVAL;
+    int tmp[4];
+    *n = legal(*s, player, tmp);
+    for (int i = 0; i < *n; i++) out[i] = tmp[i];
+    return SCOPA_OK;
+}
+
+int32_t scopa_state_rewards_x2(const scopa_state *s, int32_t r2[2]) {
+    if (!s || !r2) return SCOPA_EINVAL;
+    int a, b;
+    rewards_x2(*s, a, b);
+    r2[0] = a; r2[1] = b;
+    return SCOPA_OK;
+}
+
+int32_t scopa_state_infoset_key(const scopa_state *s, int32_t player, uint64_t *key) {
+    if (!s || !key || player > 1) return SCOPA_EINVAL;
+    if (player < 0) player = s->step & 1;
+    *key = infoset_key(*s, player);
+    return SCOPA_OK;
+}
+
+int32_t scopa_key_to_string(uint64_t key, char *buf, int32_t cap) {
+    // information_state_string, openspiel_mini_scopa.py:86-95:  P{p}:H[9f-6p]_T[7b]
+    if (!buf || cap < 64) return SCOPA_EINVAL;
+    static const char suit[4] = {'c', 'f', 'p', 'b'};
+    const int player = (int)(key & 1), nh = (int)((key >> 1) & 7), nt = (int)((key >> 20) & 15);
+    const uint32_t hand = (uint32_t)((key >> 4) & 0xFFFF), table = (uint32_t)(key >> 24);
+    char *w = buf;
+    w += sprintf(w, "P%d:H[", player);
+    for (int i = 0; i < nh; i++) w += sprintf(w, "%s%d%c", i ? "-" : "", card_rank(nib(hand, i)), suit[nib(hand, i) >> 2]);
+    w += sprintf(w, "]_T[");
+    for (int i = 0; i < nt; i++) w += sprintf(w, "%s%d%c", i ? "-" : "", card_rank(nib(table, i)), suit[nib(table, i) >> 2]);
+    w += sprintf(w, "]");
+    return (int32_t)(w - buf);
+}
+
+int32_t scopa_state_infoset_string(const scopa_state *s, int32_t player, char *buf, int32_t cap) {
+    if (!s || !buf || cap < 64 || player > 1) return SCOPA_EINVAL;
+    if (player < 0) player = current_player(*s);
+    if (is_terminal(*s) || player < 0) return (int32_t)sprintf(buf, "TERMINAL");
+    return scopa_key_to_string(infoset_key(*s, player), buf, cap);
+}
+
+// ---- tables ----------------------------------------------------------------------------------------------------
+int32_t scopa_tables_get(scopa_ctx *ctx, double *h_regret, double *h_strategy, double *h_local) {
+    if (!ctx) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_tables_get: no deal set");
+    const size_t bytes = (size_t)ctx->n_infosets * 4 * sizeof(double);
+    if (h_regret) SC_HIP(ctx, hipMemcpyAsync(h_regret, ctx->d_regret, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_strategy) SC_HIP(ctx, hipMemcpyAsync(h_strategy, ctx->d_strat, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_local) SC_HIP(ctx, hipMemcpyAsync(h_local, ctx->d_local, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_tables_set(scopa_ctx *ctx, const double *h_regret, const double *h_strategy, const double *h_local) {
+    if (!ctx) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_tables_set: no deal set");
+    const size_t bytes = (size_t)ctx->n_infosets * 4 * sizeof(double);
+    if (h_regret) SC_HIP(ctx, hipMemcpyAsync(ctx->d_regret, h_regret, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (h_strategy) SC_HIP(ctx, hipMemcpyAsync(ctx->d_strat, h_strategy, bytes, hipMemcpyHostToDevice, ctx->stream));
+    if (h_local) SC_HIP(ctx, hipMemcpyAsync(ctx->d_local, h_local, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+// ---- counters / profiling --------------------------------------------------------------------------------------
+int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits) {
+    if (!ctx) return SCOPA_EINVAL;
+    unsigned long long h[2] = {0, 0};
+    SC_HIP(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (decision_visits) *decision_visits = h[0];
+    if (terminal_visits) *terminal_visits = h[1];
+    return SCOPA_OK;
+}
+
+int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t on) {
+    if (!ctx) return SCOPA_EINVAL;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->prof_on = on != 0;
+    ctx->ev_used = 0;
+    ctx->prof_launches = 0;
+    ctx->prof_ms = 0.0;
+    return SCOPA_OK;
+}
+
+int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms) {
+    if (!ctx) return SCOPA_EINVAL;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i + 1 < ctx->ev_used; i += 2) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, ctx->ev_pool[i], ctx->ev_pool[i + 1]) == hipSuccess) ctx->prof_ms += ms;
+    }
+    ctx->ev_used = 0;
+    if (launches) *launches = ctx->prof_launches;
+    if (kernel_ms) *kernel_ms = ctx->prof_ms;
+    return SCOPA_OK;
+}
+
+}  // extern "C"

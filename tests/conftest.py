@@ -1,0 +1,75 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """The CPU oracle (oracle/scopa_oracle.c through ctypes).  Test infrastructure only."""
+    import oracle as O
+    O.build()
+    return O
+
+
+@pytest.fixture(scope="session")
+def golden():
+    class G:
+        dir = GOLDEN
+
+        @staticmethod
+        def npz(name):
+            return np.load(os.path.join(GOLDEN, name), allow_pickle=False)
+
+        @staticmethod
+        def json(name):
+            with open(os.path.join(GOLDEN, name)) as f:
+                return json.load(f)
+    return G
+
+
+@pytest.fixture(scope="session")
+def sl():
+    """The product's ctypes binding; building the library first if the snapshot lacks it."""
+    from scopa_amd import build
+    build.build_lib()
+    from scopa_amd import _lib
+    _lib.lib()
+    return _lib
+
+
+@pytest.fixture()
+def ctx(sl):
+    """A HIP context on device 0.  Skips on a box without a GPU; fails loudly on any other error."""
+    try:
+        c = sl.Context(0)
+    except sl.ScopaError as e:
+        if e.status == sl.SCOPA_ENODEV:
+            pytest.skip("no GPU on this box")
+        raise
+    yield c
+    c.close()
+
+
+def unpack_state(s):
+    """numpy STATE_DTYPE record / ctypes State16 -> dict of python lists (the oracle's snapshot format)."""
+    hand = [int(s["hand"][0]), int(s["hand"][1])] if not hasattr(s, "_fields_") else [s.hand[0], s.hand[1]]
+    g = (lambda k: s[k]) if not hasattr(s, "_fields_") else (lambda k: getattr(s, k))
+    nh = [int(g("nh")[0]), int(g("nh")[1])]
+    table, nt = int(g("table")), int(g("nt"))
+    return dict(hands=[[(hand[p] >> (4 * i)) & 15 for i in range(nh[p])] for p in range(2)],
+                table=[(table >> (4 * i)) & 15 for i in range(nt)],
+                ncap=[int(g("ncap")[0]), int(g("ncap")[1])], scopas=[int(g("scopas")[0]), int(g("scopas")[1])],
+                step=int(g("step")))

@@ -1,0 +1,199 @@
+"""GPU parity: the HIP path (through the C ABI) against the oracle and the committed golden vectors.
+
+Integer game state, infoset ids and visit counters must be bit-exact; the exact-semantics solvers must reproduce
+the reference's float64 tables bit-for-bit; the batched (frozen-table) MCCFR matches the oracle's definition to
+1e-12 relative (float64 atomic sums re-associate) with EXACT integer visit counts."""
+import numpy as np
+import pytest
+
+from conftest import unpack_state
+
+pytestmark = pytest.mark.gpu
+
+
+def _random_states(sl, oracle, n, rng):
+    """n states reached by random play (20 % illegal actions) on random deals, and the next action to apply."""
+    states = np.zeros(n, sl.STATE_DTYPE)
+    actions = np.zeros(n, np.uint8)
+    expect = []
+    for i in range(n):
+        perm = rng.permutation(16).astype(np.uint8)
+        o = oracle.State(perm=perm)
+        for _ in range(rng.randint(0, 9)):
+            legal = o.legal()
+            if not legal:
+                break
+            o.step(int(legal[rng.randint(len(legal))]) if rng.rand() < 0.8 else int(rng.randint(16)))
+        sn = o.snapshot()
+        for p in range(2):
+            states[i]["hand"][p] = sum(c << (4 * k) for k, c in enumerate(sn["hands"][p]))
+            states[i]["nh"][p] = len(sn["hands"][p])
+            states[i]["ncap"][p] = sn["ncap"][p]
+            states[i]["scopas"][p] = sn["scopas"][p]
+        states[i]["table"] = sum(c << (4 * k) for k, c in enumerate(sn["table"]))
+        states[i]["nt"] = len(sn["table"])
+        states[i]["step"] = sn["step"]
+        legal = o.legal()
+        a = int(legal[rng.randint(len(legal))]) if legal and rng.rand() < 0.8 else int(rng.randint(16))
+        actions[i] = a
+        o.step(a)
+        expect.append(o.snapshot())
+    return states, actions, expect
+
+
+def test_step_batch_bit_exact(ctx, sl, oracle):
+    rng = np.random.RandomState(11)
+    states, actions, expect = _random_states(sl, oracle, 4096, rng)
+    ctx.step_batch_host(states, actions)
+    for i in range(states.size):
+        assert unpack_state(states[i]) == expect[i], i
+
+
+def test_step_batch_edge_cases(ctx, sl):
+    ctx.step_batch_host(np.zeros(0, sl.STATE_DTYPE), np.zeros(0, np.uint8))  # empty batch is a no-op
+    s = np.zeros(1, sl.STATE_DTYPE)
+    s[0]["step"] = 8  # terminal: a dead step changes nothing
+    before = s.copy()
+    ctx.step_batch_host(s, np.array([3], np.uint8))
+    assert s.tobytes() == before.tobytes()
+
+
+@pytest.mark.parametrize("seed", [42, 0, 1, 7, 123])
+def test_tree_build_matches_reference(ctx, sl, golden, seed):
+    g = golden.npz(f"tree_seed{seed}.npz")
+    n_inf = ctx.set_deal(sl.deal_py_seed(seed))
+    assert n_inf == len(g["infoset_strings"])
+    t = ctx.tree_export()
+    assert np.array_equal(t["infoset"], g["infoset"])
+    assert np.array_equal(t["r2"], g["r2"])
+    assert [sl.key_to_string(k) for k in t["infoset_key"]] == list(g["infoset_strings"])
+    for i in range(0, 2229, 7):
+        sn = unpack_state(t["states"][i])
+        nh = g["nh"][i]
+        assert sn["hands"] == [list(g["hands"][i, p, :nh[p]]) for p in range(2)]
+        assert sn["table"] == list(g["table"][i, :g["nt"][i]])
+        assert sn["ncap"] == list(g["ncap"][i]) and sn["scopas"] == list(g["scopas"][i]) and sn["step"] == g["step"][i]
+
+
+def test_tree_build_random_deals_vs_oracle(ctx, sl, oracle):
+    rng = np.random.RandomState(3)
+    for _ in range(6):
+        perm = rng.permutation(16).astype(np.uint8)
+        o = oracle.Tree(perm=perm)
+        assert ctx.set_deal(perm) == o.n_infosets
+        t = ctx.tree_export()
+        assert np.array_equal(t["infoset"], o.infoset.astype(np.int32))
+        assert np.array_equal(t["r2"], o.r2)
+        assert [sl.key_to_string(k) for k in t["infoset_key"]] == o.infoset_strings
+        assert np.array_equal(t["infoset_legal"], o.infoset_legal)
+
+
+def test_vanilla_cfr_exact_bit_exact_vs_reference(ctx, sl, golden):
+    g = golden.npz("vanilla_cfr.npz")
+    ctx.set_deal(sl.deal_py_seed(42))
+    done, rvs = 0, []
+    for cp in [int(c) for c in g["checkpoints"]]:
+        rvs.append(ctx.cfr_exact_iterate(cp - done))
+        done = cp
+        R, S, L = ctx.tables_get()
+        assert np.array_equal(R, g[f"it{cp}_regret"]), cp
+        assert np.array_equal(S, g[f"it{cp}_strategy"]), cp
+        assert np.array_equal(L, g[f"it{cp}_local"]), cp
+    assert np.array_equal(np.concatenate(rvs), g["root_values"])
+    assert ctx.counters() == (3306 * done, 1152 * done)
+
+
+def test_vanilla_cfr_single_traversals(ctx, sl, golden):
+    g = golden.npz("vanilla_cfr.npz")
+    ctx.set_deal(sl.deal_py_seed(42))
+    assert ctx.cfr_exact_traverse(0) == g["root_values"][0, 0]
+    assert ctx.cfr_exact_traverse(1) == g["root_values"][0, 1]
+    R, _, _ = ctx.tables_get()
+    assert np.array_equal(R, g["it1_regret"])
+
+
+@pytest.mark.parametrize("seed,iters", [(0, 1), (0, 10), (1, 200), (2, 200)])
+def test_mccfr_replay_bit_exact_vs_reference(ctx, sl, golden, seed, iters):
+    m = golden.npz("mccfr.npz")
+    tag = f"s{seed}_it{iters}"
+    ctx.set_deal(sl.deal_py_seed(42))
+    u = np.random.RandomState(seed).random_sample(463 * iters)
+    assert ctx.mccfr_replay(iters, u) == 463 * iters
+    R, S, _ = ctx.tables_get()
+    keys = [sl.key_to_string(k) for k in ctx.tree_export()["infoset_key"]]
+    idx = [keys.index(k.split("|", 1)[1]) for k in m[tag + "_keys"]]
+    assert np.array_equal(R[idx], m[tag + "_regret"]) and np.array_equal(S[idx], m[tag + "_strategy"])
+    assert ctx.counters() == (463 * iters, 240 * iters)
+
+
+@pytest.mark.parametrize("batch", [1, 7, 64, 1000])
+def test_mccfr_batched_delta_vs_oracle(ctx, sl, oracle, batch):
+    """One iteration's deltas from a non-trivial frozen table: regret deltas to 1e-12, visit counts EXACT."""
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    R, S, L = t.tables()
+    t.cfr_exact(R, S, L, 3)  # a table with mixed-sign regrets
+    ctx.tables_set(regret=R)
+    ctx.mccfr_seed(0xABCDEF12345)
+    ctx.mccfr_traverse(5, 10, batch)
+    d = ctx.mccfr_delta_get()
+    dR, dS, dv, tv = t.mccfr_batched_delta(R, 0xABCDEF12345, 5, 10, batch)
+    assert np.array_equal(d[:, 4], np.rint(dS.sum(1)))          # traverser-visit counts per infoset: exact
+    assert d[:, 4].sum() == 172 * batch                          # 86 + 86 traverser visits per traversal pair
+    np.testing.assert_allclose(d[:, :4], dR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(dR).max()))
+    assert ctx.counters() == (dv, tv) == (463 * batch, 240 * batch)
+
+
+def test_mccfr_batched_iterations_vs_oracle(ctx, sl, oracle):
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.mccfr_seed(99)
+    ctx.mccfr_iterate(256, 6)
+    R, S, _ = ctx.tables_get()
+    Ro, So, _ = t.tables()
+    t.mccfr_batched(Ro, So, 99, 0, 6, 256)
+    np.testing.assert_allclose(R, Ro, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(S, So, rtol=1e-10, atol=1e-10)
+    assert ctx.mccfr_iteration() == 6
+    assert ctx.counters()[0] == 463 * 256 * 6
+
+
+def test_mccfr_batched_split_invariance(ctx, sl):
+    """Traversal ids split over several launches (as over several GPUs) give the same deltas: the RNG is keyed by
+    the global traversal id, not by launch geometry."""
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.mccfr_seed(5)
+    ctx.mccfr_traverse(0, 0, 600)
+    whole = ctx.mccfr_delta_get()
+    ctx.mccfr_delta_set(np.zeros_like(whole))
+    for b0, nb in ((0, 100), (100, 371), (471, 129)):
+        ctx.mccfr_traverse(0, b0, nb)
+    parts = ctx.mccfr_delta_get()
+    assert np.array_equal(parts[:, 4], whole[:, 4])
+    np.testing.assert_allclose(parts[:, :4], whole[:, :4], rtol=1e-12, atol=1e-12)
+
+
+def test_mccfr_full_size_properties(ctx, sl):
+    """BASELINE configs[1] size (4096 traversals per traverser): size-independent invariants."""
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.mccfr_seed(1)
+    ctx.mccfr_traverse(0, 0, 4096)
+    d = ctx.mccfr_delta_get()
+    assert d[:, 4].sum() == 172 * 4096 and d[0, 4] == 4096      # the root infoset is visited once per traversal
+    assert ctx.counters() == (463 * 4096, 240 * 4096)
+    ctx.mccfr_apply()
+    R, S, _ = ctx.tables_get()
+    n = ctx.tree_export()["infoset_nlegal"]
+    rows = S.sum(1)
+    np.testing.assert_allclose(rows, d[:, 4], rtol=1e-12)        # each visit adds a probability vector
+    assert all((S[i, n[i]:] == 0).all() and (R[i, n[i]:] == 0).all() for i in range(len(n)))
+    assert not ctx.mccfr_delta_get().any()                       # apply clears the delta buffer
+
+
+def test_profiling_counts_launches(ctx, sl):
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.prof_enable(True)
+    ctx.mccfr_iterate(512, 5)
+    n, ms = ctx.prof_read()
+    assert n == 5 and ms > 0
+    ctx.prof_enable(False)

@@ -1,0 +1,122 @@
+"""The oracle against the fixtures produced by RUNNING the reference (oracle/gen_golden.py).
+
+These pin the oracle before anything is compared with it (bit-exact for integer state and for the
+float64 tables: the reference is bit-deterministic)."""
+import numpy as np
+import pytest
+
+
+def test_philox_known_answers(oracle):
+    # Random123 kat_vectors, philox4x32-10
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8]),
+           ([0xffffffff] * 4, [0xffffffff] * 2, [0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd]),
+           ([0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344], [0xa4093822, 0x299f31d0],
+            [0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1])]
+    for ctr, key, out in kat:
+        assert list(oracle.philox4x32_10(ctr, key)) == out
+
+
+def test_deals_cpython_shuffle(oracle, golden):
+    deals = golden.json("deals.json")
+    assert len(deals) >= 70
+    for seed, perm in deals.items():
+        assert list(oracle.deal_py_seed(int(seed))) == perm, seed
+    # SURVEY §4 KAT: seed 42 -> P0 9f 6p 5f 7f = actions [7, 9, 5, 6]; P1 7b 8p 3b 3p = [14, 10, 12, 8]
+    assert deals["42"][:8] == [7, 9, 5, 6, 14, 10, 12, 8]
+
+
+@pytest.mark.parametrize("seed", [42, 0, 1, 7, 123])
+def test_tree_matches_reference(oracle, golden, seed):
+    g = golden.npz(f"tree_seed{seed}.npz")
+    t = oracle.Tree(seed=seed)
+    assert (t.n_nodes, t.n_decision) == (2229, 1653)
+    assert t.n_infosets == len(g["infoset_strings"])
+    for mine, ref in ((t.term, "term"), (t.player, "player"), (t.nlegal, "nl"), (t.legal, "legal"), (t.infoset, "infoset"),
+                      (t.r2, "r2"), (t.depth, "depth")):
+        assert np.array_equal(mine, g[ref]), ref
+    assert t.infoset_strings == list(g["infoset_strings"])
+    st = t.states()
+    for k in ("hands", "nh", "table", "nt", "ncap", "scopas", "step"):
+        assert np.array_equal(st[k], g[k]), k
+
+
+def test_tree_census_seed42(oracle):
+    t = oracle.Tree(seed=42)
+    dec = t.term == 0
+    assert [int(((t.depth == d) & dec).sum()) for d in range(8)] == [1, 4, 16, 48, 144, 288, 576, 576]
+    assert int(t.term.sum()) == 576 and t.n_infosets == 738
+    assert t.infoset_strings[0] == "P0:H[9f-6p-5f-7f]_T[]"
+    assert "P1:H[7b-8p-3b-3p]_T[9f]" in t.infoset_strings
+
+
+def test_playouts_with_illegal_actions(oracle, golden):
+    for c in golden.json("playouts.json"):
+        s = oracle.State(seed=c["seed"])
+        for a, tr in zip(c["actions"], c["trail"]):
+            s.step(a)
+            sn = s.snapshot()
+            for k in ("hands", "table", "ncap", "scopas", "step"):
+                assert sn[k] == tr[k], (c["seed"], c["actions"], k)
+            assert s.is_terminal() == tr["term"] and s.current_player() == tr["cur"]
+            assert s.infoset_string(0) == tr["info0"] and s.infoset_string(1) == tr["info1"]
+        assert s.rewards() == c["rewards"]
+
+
+def test_vanilla_cfr_bit_exact(oracle, golden):
+    g = golden.npz("vanilla_cfr.npz")
+    t = oracle.Tree(seed=42)
+    assert t.infoset_strings == list(g["keys"])
+    assert np.array_equal(t.infoset_legal, g["legal"])
+    R, S, L = t.tables()
+    done, rvs = 0, []
+    for cp in [int(c) for c in g["checkpoints"] if c <= 50]:
+        rvs.append(t.cfr_exact(R, S, L, cp - done))
+        done = cp
+        assert np.array_equal(R, g[f"it{cp}_regret"]), cp
+        assert np.array_equal(S, g[f"it{cp}_strategy"]), cp
+        assert np.array_equal(L, g[f"it{cp}_local"]), cp
+    assert np.array_equal(np.concatenate(rvs), g["root_values"][:done])
+    # SURVEY §4 KAT, iteration 1
+    assert g["root_values"][0, 0] == -0.8020833333333334 and g["root_values"][0, 1] == -1.4271996068277712
+
+
+@pytest.mark.parametrize("seed,iters", [(0, 1), (0, 10), (1, 10), (2, 10), (1, 200), (2, 200)])
+def test_mccfr_replay_bit_exact(oracle, golden, seed, iters):
+    m = golden.npz("mccfr.npz")
+    tag = f"s{seed}_it{iters}"
+    t = oracle.Tree(seed=42)
+    rs = np.random.RandomState(seed)
+    u = rs.random_sample(463 * iters)
+    R, S, _ = t.tables()
+    assert t.mccfr_replay(R, S, iters, u) == 463 * iters
+    assert rs.random_sample() == m[tag + "_next_u"][0]  # the reference consumed exactly 463 draws per iteration
+    idx = [t.infoset_strings.index(k.split("|", 1)[1]) for k in m[tag + "_keys"]]
+    assert np.array_equal(R[idx], m[tag + "_regret"]) and np.array_equal(S[idx], m[tag + "_strategy"])
+    rest = np.ones(t.n_infosets, bool)
+    rest[idx] = False
+    assert not R[rest].any() and not S[rest].any()
+
+
+def test_uniform_value_and_exploitability_invariants(oracle, golden):
+    t = oracle.Tree(seed=42)
+    uni = t.average_policy(np.zeros((t.n_infosets, 4)))
+    assert abs(t.policy_value(uni) - golden.json("evaluate.json")["uniform_ev_p0"]) < 1e-12
+    e, br = t.exploitability(uni)
+    assert e > 0 and br[0] >= t.policy_value(uni) - 1e-12 and br[1] >= -t.policy_value(uni) - 1e-12
+    # exploitability (build-defined, parity unpinned vs OpenSpiel) falls as CFR trains
+    R, S, L = t.tables()
+    t.cfr_exact(R, S, L, 30)
+    e30, _ = t.exploitability(t.average_policy(S))
+    assert 0 <= e30 < e
+
+
+def test_batched_mccfr_shape_and_split_invariance(oracle):
+    t = oracle.Tree(seed=42)
+    R = np.zeros((t.n_infosets, 4))
+    dR, dS, dv, tv = t.mccfr_batched_delta(R, 7, 0, 0, 8)
+    assert (dv, tv) == (463 * 8, 240 * 8)
+    # splitting the traversal ids across "ranks" gives the same deltas (sums re-associate: tolerance)
+    a = t.mccfr_batched_delta(R, 7, 0, 0, 3)
+    b = t.mccfr_batched_delta(R, 7, 0, 3, 5)
+    assert np.allclose(a[0] + b[0], dR, rtol=0, atol=1e-12) and np.allclose(a[1] + b[1], dS, rtol=0, atol=1e-12)
+    assert np.array_equal(np.rint((a[1] + b[1]).sum(1)), np.rint(dS.sum(1)))
