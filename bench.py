@@ -1,0 +1,156 @@
+#!/usr/bin/env python3
+"""bench.py -- MiniScopa infoset-traversals/sec (BASELINE.json metric) on N MI355X of one node.
+
+A "step" is one batched external-sampling MCCFR iteration: `batch` traversals per traverser per GPU against the
+iteration's frozen tables (k_mccfr_traverse), [N>1: one sum-all-reduce of the [738][5] float64 delta over RCCL],
+apply.  N=1 workload = BASELINE configs[1] ("External-sampling MCCFR, 4096 parallel traversals, 1 MI355X").
+An infoset-traversal = one decision-node visit: 463 per traversal pair, counted exactly by the kernel.
+
+    python bench.py --gpus 1 --steps 2000 --warmup 100
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+VISITS_PER_PAIR = 463          # 291 + 172 decision visits per (traverser 0, traverser 1) traversal pair
+ALG_BYTES_PER_VISIT = 111.6    # 32 B state + 32 B regret row + 0.3715 * 128 B table RMW
+HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+REF_PY_VISITS_PER_S = 9300.0   # reference Python MCCFR, 1 Xeon core, survey container
+
+
+def cpu_baseline(batch, target_s=12.0):
+    """The oracle's batched MCCFR (same workload, same RNG keying) on ONE host core, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import numpy as np
+    import oracle as O
+    t = O.Tree(seed=42)
+    R, S, _ = t.tables()
+    sample_batch = min(batch, 1024)
+    visits, iters, t0 = 0, 0, time.perf_counter()
+    while True:
+        visits += t.mccfr_batched(R, S, 0x5C09A, iters, 1, sample_batch)
+        iters += 1
+        dt = time.perf_counter() - t0
+        if dt >= target_s or iters >= 10000:
+            break
+    return {"value": visits / dt, "unit": "infoset-traversals/s", "cores": 1, "kind": "port",
+            "sample": f"{iters} iterations x {sample_batch} traversals/traverser of the same MCCFR workload "
+                      f"(oracle/scopa_oracle.c og_mccfr_batched, {visits} visits in {dt:.1f} s)",
+            "reference_python_visits_per_s": REF_PY_VISITS_PER_S,
+            "reference_python_note": "rug-marl-group2/scopa MCCFRTrainer on 1 Xeon core, measured in the survey container (BASELINE.md); the reference cannot run on the GPU box"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2000)
+    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
+    ap.add_argument("--prof-stride", type=int, default=8, help="bracket every n-th traversal launch with HIP events")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from scopa_amd import _lib
+    from scopa_amd.distributed import ShardedMCCFR, make_gpu_engine
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the solver path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+
+    perm = _lib.deal_py_seed(42)
+    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=world)
+    batch_total = args.batch * world
+    drv = ShardedMCCFR(ctx, rank, world, all_reduce)
+
+    def run(k):
+        if world == 1:
+            ctx.mccfr_iterate(args.batch, k)  # in-library launch loop: traverse + apply per iteration
+        else:
+            drv.run(batch_total, k)
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    run(args.warmup)
+    fence()
+    d0, _ = ctx.counters()
+    ctx.prof_enable(args.prof_stride)
+    fence()
+    t0 = time.perf_counter()
+    run(args.steps)
+    fence()
+    elapsed = time.perf_counter() - t0
+    launches, kernel_ms = ctx.prof_read()
+    ctx.prof_enable(0)
+    d1, _ = ctx.counters()
+
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        cnt = torch.tensor([d1 - d0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
+        visits = int(cnt.item())
+    else:
+        visits = d1 - d0
+    expected = VISITS_PER_PAIR * batch_total * args.steps
+    assert visits == expected, f"kernel visit counter {visits} != {expected}"
+
+    if rank == 0:
+        kern_us = 1e3 * kernel_ms / max(launches, 1)
+        visits_per_launch = VISITS_PER_PAIR * args.batch  # this rank's slice
+        achieved = visits_per_launch * ALG_BYTES_PER_VISIT / (kern_us * 1e-6) / 1e9 if launches else None
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
+        if os.path.exists(tpath):
+            try:
+                traffic = json.load(open(tpath)).get("bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "MiniScopa infoset-traversals/sec", "value": visits / elapsed, "unit": "infoset-traversals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE configs[1]: external-sampling MCCFR on MiniScopa (seed-42 deal, 738 infosets), "
+                                   f"{args.batch} parallel traversals per traverser per GPU per iteration, tables frozen per iteration",
+                       "batch_per_gpu": args.batch, "global_batch": batch_total, "iterations": args.steps,
+                       "parallelism": f"dp{world}" + (" + 1 RCCL all-reduce of 29520 B per iteration" if world > 1 else ""),
+                       "rng": "Philox4x32-10 keyed by (seed, path code, global traversal id, iteration, traverser)"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
+                         "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
+                         "algorithmic_bytes_per_launch": visits_per_launch * ALG_BYTES_PER_VISIT,
+                         "note": "algorithmic bytes = 111.6 B/visit x 463 x batch visits per launch (SURVEY 8d); the working set "
+                                 "(tables, tree) is LDS-resident by design, so HBM traffic is far below the algorithmic bytes"},
+            "decision_visits": visits,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args.batch)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

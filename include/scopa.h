@@ -134,6 +134,10 @@ int32_t scopa_mccfr_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, ui
 /* ... expose the delta buffer ([n_infosets][5] float64: 4 regret deltas + traverser-visit count) for one
  * sum-all-reduce (RCCL via torch.distributed) ... */
 int32_t scopa_mccfr_delta_buffer(scopa_ctx *ctx, void **d_delta, size_t *bytes);
+/* ... or bind a CALLER-OWNED device buffer of at least n_infosets*5 float64 (e.g. a torch tensor handed to
+ * torch.distributed.all_reduce) as the delta buffer; it is zeroed here.  d_buf = NULL returns to the internal one.
+ * The binding lasts until the next scopa_set_deal / scopa_mccfr_bind_delta. */
+int32_t scopa_mccfr_bind_delta(scopa_ctx *ctx, void *d_buf, size_t bytes);
 /* host copy of the delta buffer, h_delta[n_infosets][5] (tests, non-RCCL transports) and its inverse */
 int32_t scopa_mccfr_delta_get(scopa_ctx *ctx, double *h_delta);
 int32_t scopa_mccfr_delta_set(scopa_ctx *ctx, const double *h_delta);
@@ -144,9 +148,10 @@ int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration);
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);
-/* when enabled, every launch of the dominant traversal kernel is bracketed by HIP events on the context's
- * stream; scopa_prof_read synchronises and returns launches and the summed kernel milliseconds since enable */
-int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t on);
+/* stride > 0: every stride-th launch of the dominant traversal kernel is bracketed by HIP events on the context's
+ * stream (stride 1 = every launch); 0 = off.  scopa_prof_read synchronises and returns the number of bracketed
+ * launches and their summed kernel milliseconds since enable. */
+int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride);
 int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
 
 #ifdef __cplusplus

@@ -22,7 +22,7 @@ SYMBOLS = [
     "scopa_key_to_string", "scopa_state_infoset_string", "scopa_step_batch", "scopa_step_batch_host", "scopa_set_deal",
     "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
     "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_mccfr_replay", "scopa_mccfr_seed",
-    "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
+    "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
@@ -95,6 +95,7 @@ def lib():
         "scopa_mccfr_iterate": (i32, [vp, u32, u32]),
         "scopa_mccfr_traverse": (i32, [vp, u32, u32, u32]),
         "scopa_mccfr_delta_buffer": (i32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
+        "scopa_mccfr_bind_delta": (i32, [vp, vp, C.c_size_t]),
         "scopa_mccfr_delta_get": (i32, [vp, vp]),
         "scopa_mccfr_delta_set": (i32, [vp, vp]),
         "scopa_mccfr_apply": (i32, [vp]),
@@ -248,6 +249,10 @@ class Context:
         self._ck(self._L.scopa_mccfr_delta_buffer(self._h, C.byref(p), C.byref(n)), "scopa_mccfr_delta_buffer")
         return p.value, n.value
 
+    def mccfr_bind_delta(self, d_ptr, nbytes):
+        """Use a caller-owned device buffer (e.g. torch tensor .data_ptr()) as the all-reduce payload."""
+        self._ck(self._L.scopa_mccfr_bind_delta(self._h, C.c_void_p(d_ptr) if d_ptr else None, int(nbytes)), "scopa_mccfr_bind_delta")
+
     def mccfr_delta_get(self):
         d = np.zeros((self.n_infosets, 5))
         self._ck(self._L.scopa_mccfr_delta_get(self._h, _ptr(d)), "scopa_mccfr_delta_get")
@@ -271,8 +276,9 @@ class Context:
         self._ck(self._L.scopa_counters(self._h, C.byref(a), C.byref(b)), "scopa_counters")
         return a.value, b.value
 
-    def prof_enable(self, on=True):
-        self._ck(self._L.scopa_prof_enable(self._h, 1 if on else 0), "scopa_prof_enable")
+    def prof_enable(self, stride=1):
+        """stride: bracket every stride-th traversal launch with HIP events (True = 1, False/0 = off)."""
+        self._ck(self._L.scopa_prof_enable(self._h, int(stride)), "scopa_prof_enable")
 
     def prof_read(self):
         n, ms = C.c_int64(), C.c_double()

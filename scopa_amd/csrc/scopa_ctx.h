@@ -21,6 +21,7 @@
 //    d_regret, d_strat, d_local
 //  batched MCCFR:
 //    d_delta    [kDecision][5] float64: 4 regret deltas + traverser-visit count (the all-reduce payload)
+//    d_slabs    [n_cus][n_infosets][5] float64: per-workgroup partial deltas, summed in fixed order into d_delta
 struct scopa_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -38,8 +39,11 @@ struct scopa_ctx {
     int32_t *d_meta = nullptr;  // [0] = n_infosets
 
     double *d_regret = nullptr, *d_strat = nullptr, *d_local = nullptr;
-    double *d_delta = nullptr;
+    double *d_delta = nullptr;        // buffer in use (internal or caller-bound)
+    double *d_delta_own = nullptr;    // the internal one
     double *d_scratch = nullptr;  // root values / uniforms staging
+    double *d_slabs = nullptr;    // [workgroups][n_infosets][5] per-workgroup partial deltas of one traversal launch
+    size_t slab_bytes = 0;
     size_t scratch_bytes = 0;
 
     unsigned long long *d_counters = nullptr;  // [0] decision visits, [1] terminal visits, [2] aux
@@ -49,6 +53,9 @@ struct scopa_ctx {
 
     // profiling of the dominant kernel
     bool prof_on = false;
+    int prof_stride = 1;
+    long long prof_tick = 0;
+    bool prof_open = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     int64_t prof_launches = 0;

@@ -20,7 +20,9 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes) {
 }
 
 void prof_begin(scopa_ctx *ctx) {
+    ctx->prof_open = false;
     if (!ctx->prof_on) return;
+    if ((ctx->prof_tick++ % ctx->prof_stride) != 0) return;
     if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
         // drain: fold finished pairs into the running sum, then reuse the pool
         if (ctx->ev_used) {
@@ -37,11 +39,15 @@ void prof_begin(scopa_ctx *ctx) {
             ctx->ev_pool.push_back(e);
         }
     }
-    if (ctx->ev_used + 2 <= ctx->ev_pool.size()) (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], ctx->stream);
+    if (ctx->ev_used + 2 <= ctx->ev_pool.size()) {
+        (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], ctx->stream);
+        ctx->prof_open = true;
+    }
 }
 
 void prof_end(scopa_ctx *ctx) {
-    if (!ctx->prof_on) return;
+    if (!ctx->prof_on || !ctx->prof_open) return;
+    ctx->prof_open = false;
     if (ctx->ev_used + 2 <= ctx->ev_pool.size()) {
         (void)hipEventRecord(ctx->ev_pool[ctx->ev_used + 1], ctx->stream);
         ctx->ev_used += 2;
@@ -101,9 +107,10 @@ int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
               hipMalloc(&ctx->d_regret, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_strat, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_local, rows * 4 * sizeof(double)) == hipSuccess &&
-              hipMalloc(&ctx->d_delta, rows * 5 * sizeof(double)) == hipSuccess &&
-              hipMalloc(&ctx->d_counters, 8 * sizeof(unsigned long long)) == hipSuccess;
-    if (ok) ok = hipMemsetAsync(ctx->d_counters, 0, 8 * sizeof(unsigned long long), ctx->stream) == hipSuccess &&
+              hipMalloc(&ctx->d_delta_own, rows * 5 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->d_counters, (8 + 2 * 1024) * sizeof(unsigned long long)) == hipSuccess;  // [0..7] totals, then per-workgroup pairs
+    ctx->d_delta = ctx->d_delta_own;
+    if (ok) ok = hipMemsetAsync(ctx->d_counters, 0, (8 + 2 * 1024) * sizeof(unsigned long long), ctx->stream) == hipSuccess &&
                  hipMemsetAsync(ctx->d_delta, 0, rows * 5 * sizeof(double), ctx->stream) == hipSuccess;
     if (!ok) { scopa_ctx_destroy(ctx); return SCOPA_ENOMEM; }
     *out = ctx;
@@ -116,7 +123,7 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
-                    ctx->d_local, ctx->d_delta, ctx->d_scratch, ctx->d_counters};
+                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -294,10 +301,13 @@ int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *term
     return SCOPA_OK;
 }
 
-int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t on) {
-    if (!ctx) return SCOPA_EINVAL;
+int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride) {
+    if (!ctx || stride < 0) return SCOPA_EINVAL;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    ctx->prof_on = on != 0;
+    ctx->prof_on = stride != 0;
+    ctx->prof_stride = stride > 0 ? stride : 1;
+    ctx->prof_tick = 0;
+    ctx->prof_open = false;
     ctx->ev_used = 0;
     ctx->prof_launches = 0;
     ctx->prof_ms = 0.0;

@@ -14,8 +14,10 @@
 // produced once per task in a dense pass (86 / 26 Philox blocks) and staged in LDS.  Everything the walk touches
 // -- sigma and normalised-cdf rows of the frozen regret table, the node -> infoset map, leaf payoffs -- is LDS
 // resident (~93 KB for 738 infosets; one persistent 1024-thread workgroup per CU).  Regret deltas are reduced with
-// LDS float64 atomics per workgroup and flushed once with global float64 atomics; strategy sums are accumulated as
-// integer visit counts (sigma is frozen, so strategy_sum += count * sigma).
+// LDS float64 atomics per workgroup; each workgroup then writes its partial table as one coalesced SLAB in HBM
+// (plain stores) and k_mccfr_reduce sums the slabs in a fixed order.  (v1 flushed with global float64 atomics:
+// 256 workgroups hammering the same 29.5 KB cost ~105 us per launch, 6x the traversal itself -- measured.)
+// Strategy sums are accumulated as integer visit counts (sigma is frozen, so strategy_sum += count * sigma).
 #include "scopa_ctx.h"
 #include "scopa_philox.h"
 
@@ -55,10 +57,11 @@ __device__ __forceinline__ int slot_of(int ntl, uint32_t dig) {
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
-                 const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret, double *__restrict__ g_delta,
+                 const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret, double *__restrict__ g_slabs,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
-                 unsigned long long *__restrict__ g_counters) {
+                 unsigned long long *__restrict__ g_wg_counts) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned int s_vis[2];
     const int I = n_infosets;
     double *s_sigma = reinterpret_cast<double *>(smem);          // [I][4]
     double *s_cdf = s_sigma + (size_t)I * 4;                     // [I][4]
@@ -71,6 +74,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);   // [576]
 
     const int tid = threadIdx.x;
+    if (tid < 2) s_vis[tid] = 0u;
     // ---- prologue: freeze this iteration's strategy in LDS ----------------------------------------------------------
     for (int r = tid; r < I; r += blockDim.x) {
         const int n = (int)((g_key[r] >> 1) & 7);
@@ -173,23 +177,65 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         __syncthreads();
     }
 
-    // ---- epilogue: flush this workgroup's deltas -----------------------------------------------------------------------
-    for (int i = tid; i < I * 4; i += blockDim.x) {
-        const double v = s_dR[i];
-        if (v != 0.0) atomicAdd(&g_delta[(i >> 2) * 5 + (i & 3)], v);
+    // ---- epilogue: this workgroup's partial delta table -> its slab, [n_infosets][5] like the delta buffer ----------
+    {
+        double *slab = g_slabs + (size_t)blockIdx.x * ((size_t)I * 5);
+        for (int c = tid; c < I * 5; c += blockDim.x) {
+            const int r = c / 5, k = c - r * 5;
+            slab[c] = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
+        }
     }
-    for (int r = tid; r < I; r += blockDim.x) {
-        const unsigned int c = s_cnt[r];
-        if (c) atomicAdd(&g_delta[r * 5 + 4], (double)c);
-    }
-    // exact visit counters: wave reduce, one atomic per wavefront
+    // exact visit counters: wave reduce -> LDS -> ONE plain store per workgroup, summed by k_mccfr_reduce.  (v1 issued
+    // one global atomicAdd per wavefront: 8192 same-address atomics at ~12 ns each = the ~100 us fixed cost measured.)
     for (int off = 32; off > 0; off >>= 1) {
         my_dvis += __shfl_down(my_dvis, off);
         my_tvis += __shfl_down(my_tvis, off);
     }
-    if ((tid & 63) == 0 && (my_dvis | my_tvis)) {
-        atomicAdd(&g_counters[0], (unsigned long long)my_dvis);
-        atomicAdd(&g_counters[1], (unsigned long long)my_tvis);
+    if ((tid & 63) == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
+    __syncthreads();
+    if (tid < 2) g_wg_counts[blockIdx.x * 2 + tid] = s_vis[tid];
+}
+
+// delta[c] += sum over slabs, in slab order (deterministic).  A workgroup owns 16 consecutive cells; thread
+// (chunk = tid / 16, cell = tid % 16) adds slabs chunk, chunk+16, ... so that 16 lanes read 128 contiguous bytes of
+// one slab; the 16 partial sums per cell are then combined in chunk order through LDS.
+__global__ void __launch_bounds__(256)
+k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_cells,
+               const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters) {
+    __shared__ double part[16][17];
+    __shared__ unsigned long long s_tot[2];
+    if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch: one lane per workgroup record, LDS reduce
+        if (threadIdx.x < 2) s_tot[threadIdx.x] = 0ull;
+        __syncthreads();
+        unsigned long long d = 0ull, t = 0ull;
+        for (int w = threadIdx.x; w < n_slabs; w += blockDim.x) { d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1]; }
+        if (d | t) { atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t); }
+        __syncthreads();
+        if (threadIdx.x < 2) g_counters[threadIdx.x] += s_tot[threadIdx.x];
+    }
+    const int cell_l = threadIdx.x & 15, chunk = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cell_l;
+    double acc = 0.0;
+    if (c < n_cells) {
+        // all loads of a batch are issued before the first add (16 independent requests in flight per lane; the
+        // dependent load->add form of v1 took 35 us for 7.5 MB), then summed in slab order
+        for (int base = chunk; base < n_slabs; base += 256) {
+            double v[16];
+#pragma unroll
+            for (int j = 0; j < 16; j++) {
+                const int sl = base + 16 * j;
+                v[j] = sl < n_slabs ? __builtin_nontemporal_load(&g_slabs[(size_t)sl * n_cells + c]) : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < 16; j++) acc += v[j];
+        }
+    }
+    part[chunk][cell_l] = acc;
+    __syncthreads();
+    if (chunk == 0 && c < n_cells) {
+        double t = part[0][cell_l];
+        for (int k = 1; k < 16; k++) t += part[k][cell_l];
+        g_delta[c] += t;
     }
 }
 
@@ -313,20 +359,33 @@ static size_t traverse_lds_bytes(int n_infosets, int threads) {
 static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
     const int threads = 1024;
     const size_t lds = traverse_lds_bytes(ctx->n_infosets, threads);
-    SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
+    SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_traverse),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 64));  // 8 B of static LDS (s_vis)
         attr_set = true;
     }
     const uint32_t n_groups = (nb * 2u + (threads / kTaskLanes) - 1) / (threads / kTaskLanes);
     const uint32_t grid = n_groups < (uint32_t)ctx->n_cus ? n_groups : (uint32_t)ctx->n_cus;
+    const int n_cells = ctx->n_infosets * 5;
+    const size_t slab_bytes = (size_t)grid * n_cells * sizeof(double);
+    if (slab_bytes > ctx->slab_bytes) {
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (ctx->d_slabs) SC_HIP(ctx, hipFree(ctx->d_slabs));
+        ctx->d_slabs = nullptr; ctx->slab_bytes = 0;
+        const size_t want = (size_t)ctx->n_cus * kDecision * 5 * sizeof(double);  // worst case, allocated once (16.9 MB)
+        SC_HIP(ctx, hipMalloc(&ctx->d_slabs, want > slab_bytes ? want : slab_bytes));
+        ctx->slab_bytes = want > slab_bytes ? want : slab_bytes;
+    }
     prof_begin(ctx);
     hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
-                       ctx->d_key, ctx->d_regret, ctx->d_delta, ctx->n_infosets, (uint32_t)ctx->seed,
-                       (uint32_t)(ctx->seed >> 32), iteration, b0, nb, ctx->d_counters);
+                       ctx->d_key, ctx->d_regret, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed,
+                       (uint32_t)(ctx->seed >> 32), iteration, b0, nb, ctx->d_counters + 8);
     prof_end(ctx);
+    SC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_mccfr_reduce, dim3((n_cells + 15) / 16), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+                       ctx->d_delta, n_cells, ctx->d_counters + 8, ctx->d_counters);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -353,6 +412,22 @@ int32_t scopa_mccfr_delta_buffer(scopa_ctx *ctx, void **d_delta, size_t *bytes) 
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_delta_buffer: no deal set");
     *d_delta = ctx->d_delta;
     *bytes = (size_t)ctx->n_infosets * 5 * sizeof(double);
+    return SCOPA_OK;
+}
+
+int32_t scopa_mccfr_bind_delta(scopa_ctx *ctx, void *d_buf, size_t bytes) {
+    if (!ctx) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_bind_delta: no deal set");
+    const size_t need = (size_t)ctx->n_infosets * 5 * sizeof(double);
+    if (d_buf) {
+        SC_REQUIRE(ctx, bytes >= need, SCOPA_EINVAL, "scopa_mccfr_bind_delta: buffer smaller than n_infosets*5 float64");
+        SC_REQUIRE(ctx, ((uintptr_t)d_buf & 15) == 0, SCOPA_EINVAL, "scopa_mccfr_bind_delta: buffer must be 16-byte aligned");
+        ctx->d_delta = static_cast<double *>(d_buf);
+    } else {
+        ctx->d_delta = ctx->d_delta_own;
+    }
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    SC_HIP(ctx, hipMemsetAsync(ctx->d_delta, 0, need, ctx->stream));
     return SCOPA_OK;
 }
 

@@ -171,7 +171,7 @@ int32_t scopa_tables_reset(scopa_ctx *ctx) {
     hipLaunchKernelGGL(k_tables_reset, dim3(8), dim3(1024), 0, ctx->stream, ctx->d_regret, ctx->d_strat, ctx->d_local,
                        ctx->d_key, ctx->d_meta);
     SC_HIP(ctx, hipGetLastError());
-    SC_HIP(ctx, hipMemsetAsync(ctx->d_delta, 0, (size_t)kDecision * 5 * sizeof(double), ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(ctx->d_delta, 0, (size_t)(ctx->d_delta == ctx->d_delta_own ? kDecision : ctx->n_infosets) * 5 * sizeof(double), ctx->stream));
     ctx->iteration = 0;
     return SCOPA_OK;
 }
@@ -194,6 +194,7 @@ int32_t scopa_set_deal(scopa_ctx *ctx, const uint8_t perm16[16]) {
     SC_REQUIRE(ctx, n_inf > 0 && n_inf <= kDecision, SCOPA_EHIP, "scopa_set_deal: tree build produced a bad infoset count");
     ctx->n_infosets = n_inf;
     ctx->has_deal = true;
+    ctx->d_delta = ctx->d_delta_own;  // a new deal drops any caller-bound delta buffer
     return scopa_tables_reset(ctx);
 }
 
