@@ -110,12 +110,22 @@ int32_t scopa_tables_reset(scopa_ctx *ctx);
 int32_t scopa_tables_get(scopa_ctx *ctx, double *h_regret, double *h_strategy, double *h_local);
 int32_t scopa_tables_set(scopa_ctx *ctx, const double *h_regret, const double *h_strategy, const double *h_local);
 
+/* First-visit order of every infoset, h_seq[n_infosets]: 0 = never visited by any solver since the last reset,
+ * otherwise a strictly increasing sequence number (sequential solvers) or 0x40000000 + id (first seen by a batched
+ * launch).  Mirrors which keys the reference's dicts hold, and in which insertion order
+ * (CFRTrainer._get_or_create_node vanilla_cfr.py:51-54, MCCFRTrainer._get_node mc_cfr.py:32-35). */
+int32_t scopa_visited_get(scopa_ctx *ctx, uint32_t *h_seq);
+
 /* ---- vanilla CFR, exact sequential semantics (CFRTrainer._cfr_recursive / .train, vanilla_cfr.py:56-110)
  * n_iters iterations of "for i in (0,1): traverse(root, i, 1.0, 1.0)"; h_root_values[n_iters][2] or NULL.
  * Reproduces the reference bit-for-bit, incl. the mid-traversal local_strategy refresh (:97). */
 int32_t scopa_cfr_exact_iterate(scopa_ctx *ctx, int32_t n_iters, double *h_root_values);
 /* one traversal: CFRTrainer._cfr_recursive(new_initial_state(), player, 1.0, 1.0) -> value */
 int32_t scopa_cfr_exact_traverse(scopa_ctx *ctx, int32_t traverser, double *h_value);
+/* CFRTrainer._cfr_recursive(state, player, reach_p0, reach_p1) for any state of the tree: the state reached from the
+ * root by legal-action INDICES path[0..depth) (index into legal_actions(), i.e. hand position) */
+int32_t scopa_cfr_exact_traverse_from(scopa_ctx *ctx, int32_t traverser, int32_t depth, const int32_t *path,
+                                      double reach_p0, double reach_p1, double *h_value);
 
 /* ---- MCCFR replay: MCCFRTrainer.iteration() (mc_cfr.py:37-92) driven by a host-supplied uniform stream
  * (one float64 per decision visit in DFS order = what np.random.choice draws); bit-exact vs the reference. */
@@ -144,6 +154,12 @@ int32_t scopa_mccfr_delta_set(scopa_ctx *ctx, const double *h_delta);
 /* ... then regret += delta[:, :4]; strategy += count * sigma; delta <- 0; iteration counter += 1 */
 int32_t scopa_mccfr_apply(scopa_ctx *ctx);
 int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration);
+
+/* ---- policy value / exploitability (build-defined; the reference only calls OpenSpiel's, vanilla_cfr.py:112-118) --
+ * h_policy[n_infosets][4] or NULL = the average policy of the strategy table (InfoNode.policy, vanilla_cfr.py:32-39).
+ * h_out4 = {exploitability = (BR0+BR1)/2, BR0, BR1, value of the policy for player 0}; h_policy_out (optional)
+ * receives the policy that was evaluated. */
+int32_t scopa_exploitability(scopa_ctx *ctx, const double *h_policy, double *h_out4, double *h_policy_out);
 
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */

@@ -40,6 +40,7 @@ def lib():
         L.og_policy_value.restype = C.c_double
         L.og_exploitability.restype = C.c_double
         L.og_mccfr_replay.restype = C.c_int64
+        L.og_cfr_exact_from.restype = C.c_double
         L.og_deal_py_seed.argtypes = [C.c_int64, C.c_void_p]
         _lib = L
     return _lib
@@ -172,6 +173,10 @@ class Tree:
         rv = np.zeros((n_iters, 2))
         lib().og_cfr_exact(self.h, _p(R), _p(S), _p(Lc), int(n_iters), _p(rv))
         return rv
+
+    def cfr_exact_from(self, R, S, Lc, path, trav, r0, r1):
+        pa = np.ascontiguousarray(path, np.int32)
+        return lib().og_cfr_exact_from(self.h, _p(R), _p(S), _p(Lc), _p(pa), int(pa.size), int(trav), C.c_double(r0), C.c_double(r1))
 
     def cfr_sync(self, R, S, n_iters):
         lib().og_cfr_sync(self.h, _p(R), _p(S), int(n_iters))

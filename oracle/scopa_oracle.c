@@ -395,6 +395,14 @@ void og_cfr_exact(const og_tree *t, double *regret, double *strat, double *local
         }
 }
 
+double og_cfr_exact_from(const og_tree *t, double *regret, double *strat, double *local, const int *path, int depth,
+                         int trav, double r0, double r1) {
+    /* CFRTrainer._cfr_recursive(state, trav, r0, r1) for the state reached by legal-action indices path[0..depth) */
+    int node = 0;
+    for (int d = 0; d < depth; d++) node = t->child[node * 4 + path[d]];
+    return cfr_rec(t, regret, strat, local, node, trav, r0, r1);
+}
+
 /* ===== MCCFR replay (reference semantics, host-supplied uniforms) ================== */
 static int np_choice(const double *p, int n, double u) {
     /* np.random.choice(a, p=p): cdf = p.cumsum(); cdf /= cdf[-1]; cdf.searchsorted(u, 'right') */

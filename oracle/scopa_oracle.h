@@ -87,6 +87,8 @@ int og_tree_infoset_meta(const og_tree *t, int8_t *nlegal, int8_t *legal /*[I][4
  * refresh (:97).  `local` must be initialised by og_tables_init. root_values: [n_iters][2] or NULL */
 void og_tables_init(const og_tree *t, double *regret, double *strat, double *local);
 void og_cfr_exact(const og_tree *t, double *regret, double *strat, double *local, int n_iters, double *root_values);
+double og_cfr_exact_from(const og_tree *t, double *regret, double *strat, double *local, const int *path, int depth,
+                         int trav, double r0, double r1);
 /* mc_cfr.py:37-92 replayed from a host-supplied uniform stream (one double per decision
  * visit, DFS order; np.random.choice == searchsorted(cumsum(p)/sum, u, 'right')).
  * Returns the number of uniforms consumed. */

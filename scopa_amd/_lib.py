@@ -21,9 +21,9 @@ SYMBOLS = [
     "scopa_state_current_player", "scopa_state_legal", "scopa_state_rewards_x2", "scopa_state_infoset_key",
     "scopa_key_to_string", "scopa_state_infoset_string", "scopa_step_batch", "scopa_step_batch_host", "scopa_set_deal",
     "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
-    "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_mccfr_replay", "scopa_mccfr_seed",
+    "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
-    "scopa_mccfr_iteration_counter", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_mccfr_iteration_counter", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
         "scopa_tables_set": (i32, [vp, vp, vp, vp]),
         "scopa_cfr_exact_iterate": (i32, [vp, i32, vp]),
         "scopa_cfr_exact_traverse": (i32, [vp, i32, C.POINTER(C.c_double)]),
+        "scopa_cfr_exact_traverse_from": (i32, [vp, i32, i32, vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),
+        "scopa_visited_get": (i32, [vp, vp]),
         "scopa_mccfr_replay": (i32, [vp, i32, vp, i64, C.POINTER(i64)]),
         "scopa_mccfr_seed": (i32, [vp, u64]),
         "scopa_mccfr_iterate": (i32, [vp, u32, u32]),
@@ -100,6 +102,7 @@ def lib():
         "scopa_mccfr_delta_set": (i32, [vp, vp]),
         "scopa_mccfr_apply": (i32, [vp]),
         "scopa_mccfr_iteration_counter": (i32, [vp, C.POINTER(u32)]),
+        "scopa_exploitability": (i32, [vp, vp, vp, vp]),
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
@@ -229,6 +232,18 @@ class Context:
         self._ck(self._L.scopa_cfr_exact_traverse(self._h, int(traverser), C.byref(v)), "scopa_cfr_exact_traverse")
         return v.value
 
+    def cfr_exact_traverse_from(self, traverser, path, reach_p0=1.0, reach_p1=1.0):
+        pa = np.ascontiguousarray(path, np.int32)
+        v = C.c_double()
+        self._ck(self._L.scopa_cfr_exact_traverse_from(self._h, int(traverser), pa.size, _ptr(pa), float(reach_p0), float(reach_p1),
+                                                       C.byref(v)), "scopa_cfr_exact_traverse_from")
+        return v.value
+
+    def visited_get(self):
+        seq = np.zeros(self.n_infosets, np.uint32)
+        self._ck(self._L.scopa_visited_get(self._h, _ptr(seq)), "scopa_visited_get")
+        return seq
+
     def mccfr_replay(self, n_iters, uniforms):
         u = np.ascontiguousarray(uniforms, np.float64)
         used = C.c_int64()
@@ -270,6 +285,17 @@ class Context:
         v = C.c_uint32()
         self._ck(self._L.scopa_mccfr_iteration_counter(self._h, C.byref(v)), "scopa_mccfr_iteration_counter")
         return v.value
+
+    def exploitability(self, policy=None, return_policy=False):
+        """-> dict(exploitability, br0, br1, value_p0[, policy]); policy=None evaluates the average policy."""
+        pin = None if policy is None else np.ascontiguousarray(policy, np.float64)
+        out = np.zeros(4)
+        pout = np.zeros((self.n_infosets, 4)) if return_policy else None
+        self._ck(self._L.scopa_exploitability(self._h, _ptr(pin), _ptr(out), _ptr(pout)), "scopa_exploitability")
+        res = dict(exploitability=out[0], br0=out[1], br1=out[2], value_p0=out[3])
+        if return_policy:
+            res["policy"] = pout
+        return res
 
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()

@@ -33,7 +33,9 @@ __device__ __forceinline__ void regret_match(const double *R, int n, double *out
 __global__ void __launch_bounds__(256)
 k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, double *__restrict__ g_regret,
             double *__restrict__ g_strat, double *__restrict__ g_local, int n_infosets, int n_traversals, int first_traverser,
-            double *__restrict__ root_values, unsigned long long *__restrict__ g_counters, int use_lds) {
+            double *__restrict__ root_values, unsigned long long *__restrict__ g_counters, int use_lds,
+            uint32_t *__restrict__ g_visit, int32_t *__restrict__ g_meta, int start_depth, int start_idx, double start_r0,
+            double start_r1) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint16_t s_inf[1656];
     __shared__ int8_t s_pay[kTerminal];
@@ -52,18 +54,25 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
 
     if (tid == 0) {
         unsigned long long dvis = 0, tvis = 0;
+        uint32_t seq = (uint32_t)g_meta[1];
         for (int t = 0; t < n_traversals; t++) {
             const int trav = (first_traverser + t) & 1;  // train(): for i in range(num_players) (:108-110)
-            int d = 0;
-            fr[0].idx = 0; fr[0].i = -1; fr[0].r0 = 1.0; fr[0].r1 = 1.0;
+            int d = start_depth;
+            fr[d].idx = start_idx; fr[d].i = -1; fr[d].r0 = start_r0; fr[d].r1 = start_r1;
             double ret = 0.0;
-            while (d >= 0) {
+            if (d == kPlies) {  // a terminal state was passed in (:58-59)
+                const int p0 = s_pay[start_idx];
+                ret = 0.5 * (double)(trav == 0 ? p0 : -p0);
+                tvis++;
+                d = start_depth - 1;
+            }
+            while (d >= start_depth) {
                 if (d == kPlies) {  // terminal (:58-59)
                     const int p0 = s_pay[fr[d].idx];
                     ret = 0.5 * (double)(trav == 0 ? p0 : -p0);
                     tvis++;
                     d--;
-                    fr[d].au[fr[d].i] = ret;
+                    fr[d].au[fr[d].i] = ret;  // d >= start_depth here: a terminal start never enters the loop
                     continue;
                 }
                 CfrFrame &f = fr[d];
@@ -72,6 +81,7 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
                     dvis++;
                     f.I = s_inf[level_offset(d) + f.idx];
                     f.i = 0;
+                    if (g_visit[f.I] == 0u) g_visit[f.I] = ++seq;  // dict insertion on first visit (:51-54)
                 } else {
                     f.i++;  // child f.i returned into au[f.i]
                 }
@@ -98,19 +108,21 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
                 regret_match(R + f.I * 4, n, ls);  // local_strategy refresh on EVERY visit (:97)
                 ret = v;
                 d--;
-                if (d >= 0) fr[d].au[fr[d].i] = ret;
+                if (d >= start_depth) fr[d].au[fr[d].i] = ret;
             }
             if (root_values) root_values[t] = ret;
         }
         g_counters[0] += dvis;
         g_counters[1] += tvis;
+        g_meta[1] = (int32_t)seq;
     }
     __syncthreads();
     if (use_lds)
         for (int i = tid; i < cells; i += blockDim.x) { g_regret[i] = R[i]; g_strat[i] = S[i]; g_local[i] = L[i]; }
 }
 
-static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, double *h_values) {
+static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, double *h_values, int start_depth = 0,
+                         int start_idx = 0, double r0 = 1.0, double r1 = 1.0) {
     SC_HIP(ctx, hipSetDevice(ctx->device));
     { const int32_t rc = ensure_scratch(ctx, (size_t)(n_traversals > 0 ? n_traversals : 1) * sizeof(double)); if (rc != SCOPA_OK) return rc; }
     const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 3;
@@ -124,7 +136,7 @@ static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, 
     }
     hipLaunchKernelGGL(k_cfr_exact, dim3(1), dim3(256), use_lds ? lds : 0, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                        ctx->d_regret, ctx->d_strat, ctx->d_local, ctx->n_infosets, n_traversals, first_traverser,
-                       ctx->d_scratch, ctx->d_counters, use_lds);
+                       ctx->d_scratch, ctx->d_counters, use_lds, ctx->d_visit, ctx->d_meta, start_depth, start_idx, r0, r1);
     SC_HIP(ctx, hipGetLastError());
     if (h_values && n_traversals > 0)
         SC_HIP(ctx, hipMemcpyAsync(h_values, ctx->d_scratch, (size_t)n_traversals * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
@@ -145,6 +157,18 @@ int32_t scopa_cfr_exact_traverse(scopa_ctx *ctx, int32_t traverser, double *h_va
     if (!ctx || traverser < 0 || traverser > 1) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_cfr_exact_traverse: no deal set");
     return run_exact(ctx, 1, traverser, h_value);
+}
+
+int32_t scopa_cfr_exact_traverse_from(scopa_ctx *ctx, int32_t traverser, int32_t depth, const int32_t *path, double reach_p0,
+                                      double reach_p1, double *h_value) {
+    if (!ctx || traverser < 0 || traverser > 1 || depth < 0 || depth > kPlies || (depth > 0 && !path)) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_cfr_exact_traverse_from: no deal set");
+    int idx = 0;
+    for (int d = 0; d < depth; d++) {
+        SC_REQUIRE(ctx, path[d] >= 0 && path[d] < nlegal_at(d), SCOPA_EINVAL, "scopa_cfr_exact_traverse_from: path index out of range");
+        idx = idx * nlegal_at(d) + path[d];
+    }
+    return run_exact(ctx, 1, traverser, h_value, depth, idx, reach_p0, reach_p1);
 }
 
 }  // extern "C"

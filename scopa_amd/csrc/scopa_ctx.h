@@ -36,7 +36,9 @@ struct scopa_ctx {
     uint16_t *d_infoset = nullptr;
     int8_t *d_payoff = nullptr;
     uint64_t *d_key = nullptr;
-    int32_t *d_meta = nullptr;  // [0] = n_infosets
+    int32_t *d_meta = nullptr;  // [0] = n_infosets, [1] = first-visit sequence counter
+    uint32_t *d_visit = nullptr;  // [kDecision] first-visit sequence number per infoset (0 = unvisited)
+    uint8_t *d_seen_slabs = nullptr;  // [n_cus][kDecision] per-workgroup 'infoset seen' flags of one batched launch
 
     double *d_regret = nullptr, *d_strat = nullptr, *d_local = nullptr;
     double *d_delta = nullptr;        // buffer in use (internal or caller-bound)

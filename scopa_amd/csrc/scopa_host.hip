@@ -104,6 +104,8 @@ int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
               hipMalloc(&ctx->d_payoff, kTerminal) == hipSuccess &&
               hipMalloc(&ctx->d_key, sizeof(uint64_t) * kDecision) == hipSuccess &&
               hipMalloc(&ctx->d_meta, sizeof(int32_t) * 8) == hipSuccess &&
+              hipMalloc(&ctx->d_visit, sizeof(uint32_t) * kDecision) == hipSuccess &&
+              hipMalloc(&ctx->d_seen_slabs, (size_t)1024 * kDecision) == hipSuccess &&
               hipMalloc(&ctx->d_regret, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_strat, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_local, rows * 4 * sizeof(double)) == hipSuccess &&
@@ -123,7 +125,7 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
-                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs};
+                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs, ctx->d_visit, ctx->d_seen_slabs};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -286,6 +288,14 @@ int32_t scopa_tables_set(scopa_ctx *ctx, const double *h_regret, const double *h
     if (h_regret) SC_HIP(ctx, hipMemcpyAsync(ctx->d_regret, h_regret, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (h_strategy) SC_HIP(ctx, hipMemcpyAsync(ctx->d_strat, h_strategy, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (h_local) SC_HIP(ctx, hipMemcpyAsync(ctx->d_local, h_local, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_visited_get(scopa_ctx *ctx, uint32_t *h_seq) {
+    if (!ctx || !h_seq) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_visited_get: no deal set");
+    SC_HIP(ctx, hipMemcpyAsync(h_seq, ctx->d_visit, (size_t)ctx->n_infosets * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCOPA_OK;
 }

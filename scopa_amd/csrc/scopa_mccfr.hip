@@ -59,7 +59,7 @@ __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
                  const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret, double *__restrict__ g_slabs,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
-                 unsigned long long *__restrict__ g_wg_counts) {
+                 unsigned long long *__restrict__ g_wg_counts, uint8_t *__restrict__ g_seen_slabs) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     const int I = n_infosets;
@@ -72,6 +72,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     int *s_px2 = reinterpret_cast<int *>(s_u + (size_t)tasks_per_wg * kSlots);    // [tasks][128]
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(s_px2 + (size_t)tasks_per_wg * kTaskLanes);  // [1653] (+pad)
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);   // [576]
+    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);  // [I] infoset visited by any lane of this workgroup
 
     const int tid = threadIdx.x;
     if (tid < 2) s_vis[tid] = 0u;
@@ -85,6 +86,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         choice_cdf(sg, n, cd);
         for (int c = 0; c < 4; c++) { s_sigma[r * 4 + c] = sg[c]; s_cdf[r * 4 + c] = cd[c]; s_dR[r * 4 + c] = 0.0; }
         s_cnt[r] = 0u;
+        s_seen[r] = 0;
     }
     for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
@@ -131,6 +133,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                 const int n = 4 - (d >> 1);
                 const int In = s_inf[level_offset(d) + idx];
                 const bool is_trav = (d & 1) == trav;
+                s_seen[In] = 1;  // benign race: every writer stores 1
                 int a = 0;
                 if (n > 1) {
                     const double2 uu = my_u[slot_of(ntl, dig)];
@@ -184,6 +187,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
             const int r = c / 5, k = c - r * 5;
             slab[c] = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
         }
+        uint8_t *seen = g_seen_slabs + (size_t)blockIdx.x * kDecision;
+        for (int r = tid; r < I; r += blockDim.x) seen[r] = s_seen[r];
     }
     // exact visit counters: wave reduce -> LDS -> ONE plain store per workgroup, summed by k_mccfr_reduce.  (v1 issued
     // one global atomicAdd per wavefront: 8192 same-address atomics at ~12 ns each = the ~100 us fixed cost measured.)
@@ -201,7 +206,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 // one slab; the 16 partial sums per cell are then combined in chunk order through LDS.
 __global__ void __launch_bounds__(256)
 k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_cells,
-               const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters) {
+               const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters,
+               const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit) {
     __shared__ double part[16][17];
     __shared__ unsigned long long s_tot[2];
     if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch: one lane per workgroup record, LDS reduce
@@ -212,6 +218,14 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
         if (d | t) { atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t); }
         __syncthreads();
         if (threadIdx.x < 2) g_counters[threadIdx.x] += s_tot[threadIdx.x];
+    }
+    {   // infosets first seen by this launch: 16 per workgroup, 16 lanes OR the slabs' flags
+        const int r = blockIdx.x * 16 + (threadIdx.x & 15);
+        const int n_rows = n_cells / 5;
+        unsigned int any = 0u;
+        if (r < n_rows)
+            for (int w = threadIdx.x >> 4; w < n_slabs; w += 16) any |= g_seen_slabs[(size_t)w * kDecision + r];
+        if (any && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;  // racing writers store the same value
     }
     const int cell_l = threadIdx.x & 15, chunk = threadIdx.x >> 4;
     const int c = blockIdx.x * 16 + cell_l;
@@ -271,11 +285,13 @@ struct ReplayFrame {
 __global__ void __launch_bounds__(64)
 k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
                double *__restrict__ g_regret, double *__restrict__ g_strat, const double *__restrict__ uniforms,
-               long long n_uniforms, int n_iters, unsigned long long *__restrict__ g_counters, long long *__restrict__ consumed) {
+               long long n_uniforms, int n_iters, unsigned long long *__restrict__ g_counters, long long *__restrict__ consumed,
+               uint32_t *__restrict__ g_visit, int32_t *__restrict__ g_meta) {
     __shared__ ReplayFrame fr[kPlies + 1];
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     long long upos = 0;
     unsigned long long dvis = 0, tvis = 0;
+    uint32_t seq = (uint32_t)g_meta[1];
     for (int it = 0; it < n_iters; it++) {
         for (int trav = 0; trav < 2; trav++) {  // iteration(), mc_cfr.py:88-92
             int d = 0;
@@ -297,6 +313,7 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
                 if (!returning) {  // node entry (:49-55)
                     dvis++;
                     f.I = g_infoset[level_offset(d) + f.idx];
+                    if (g_visit[f.I] == 0u) g_visit[f.I] = ++seq;  // _get_node inserts on first visit (mc_cfr.py:32-35)
                     double R[4];
                     for (int c = 0; c < 4; c++) R[c] = g_regret[f.I * 4 + c];
                     mc_sigma(R, n, f.sigma);
@@ -343,6 +360,7 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
     }
     g_counters[0] += dvis;
     g_counters[1] += tvis;
+    g_meta[1] = (int32_t)seq;
     *consumed = upos;
 }
 
@@ -352,7 +370,7 @@ static size_t traverse_lds_bytes(int n_infosets, int threads) {
     size_t b = (size_t)n_infosets * 4 * 8 * 3;
     b += ((size_t)n_infosets * 4 + 15) & ~(size_t)15;
     b += (size_t)tasks * kSlots * 16 + (size_t)tasks * kTaskLanes * 4;
-    b += 1656 * 2 + 576;
+    b += 1656 * 2 + 576 + (size_t)n_infosets;
     return (b + 15) & ~(size_t)15;
 }
 
@@ -381,11 +399,11 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     prof_begin(ctx);
     hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                        ctx->d_key, ctx->d_regret, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed,
-                       (uint32_t)(ctx->seed >> 32), iteration, b0, nb, ctx->d_counters + 8);
+                       (uint32_t)(ctx->seed >> 32), iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
     prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
     hipLaunchKernelGGL(k_mccfr_reduce, dim3((n_cells + 15) / 16), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
-                       ctx->d_delta, n_cells, ctx->d_counters + 8, ctx->d_counters);
+                       ctx->d_delta, n_cells, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -488,7 +506,8 @@ int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_unif
     double *d_u = ctx->d_scratch + 8;
     if (n_uniforms) SC_HIP(ctx, hipMemcpyAsync(d_u, h_uniforms, ubytes, hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_mccfr_replay, dim3(1), dim3(64), 0, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key,
-                       ctx->d_regret, ctx->d_strat, d_u, (long long)n_uniforms, (int)n_iters, ctx->d_counters, d_consumed);
+                       ctx->d_regret, ctx->d_strat, d_u, (long long)n_uniforms, (int)n_iters, ctx->d_counters, d_consumed,
+                       ctx->d_visit, ctx->d_meta);
     SC_HIP(ctx, hipGetLastError());
     long long used = 0;
     SC_HIP(ctx, hipMemcpyAsync(&used, d_consumed, sizeof used, hipMemcpyDeviceToHost, ctx->stream));

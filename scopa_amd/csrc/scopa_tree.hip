@@ -171,6 +171,8 @@ int32_t scopa_tables_reset(scopa_ctx *ctx) {
     hipLaunchKernelGGL(k_tables_reset, dim3(8), dim3(1024), 0, ctx->stream, ctx->d_regret, ctx->d_strat, ctx->d_local,
                        ctx->d_key, ctx->d_meta);
     SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipMemsetAsync(ctx->d_visit, 0, sizeof(uint32_t) * kDecision, ctx->stream));
+    SC_HIP(ctx, hipMemsetAsync(ctx->d_meta + 1, 0, sizeof(int32_t), ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(ctx->d_delta, 0, (size_t)(ctx->d_delta == ctx->d_delta_own ? kDecision : ctx->n_infosets) * 5 * sizeof(double), ctx->stream));
     ctx->iteration = 0;
     return SCOPA_OK;

@@ -1,0 +1,171 @@
+"""GPU tests of the drop-in Python boundary: the reference's class names / call signatures over the HIP engine,
+checked against golden vectors produced by the reference itself."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def game(ctx):  # `ctx` only to skip on boxes without a GPU
+    from scopa_amd.envs import load_game
+    return load_game("mini_scopa")
+
+
+def test_cfr_trainer_reproduces_reference_tables(game, golden):
+    from scopa_amd.algorithms import CFRTrainer
+    g = golden.npz("vanilla_cfr.npz")
+    tr = CFRTrainer(game)
+    assert tr.info_set_map == {}
+    assert tr.train(steps=5, eval_interval=5, compute_exploitability=False) == []
+    m = tr.info_set_map
+    assert list(m.keys()) == list(g["keys"]) and len(m) == 738
+    for i, (k, node) in enumerate(m.items()):
+        n = int(g["nlegal"][i])
+        assert list(node.legal_actions) == list(g["legal"][i, :n])
+        assert np.array_equal(node.regret_sum, g["it5_regret"][i, :n])
+        assert np.array_equal(node.strategy_sum, g["it5_strategy"][i, :n])
+        assert np.array_equal(node.local_strategy, g["it5_local"][i, :n])
+    root = m["P0:H[9f-6p-5f-7f]_T[]"]
+    np.testing.assert_allclose(root.policy, [0.11066738, 0.65885247, 0.07278481, 0.15769534], atol=1e-8)  # SURVEY §4 KAT
+
+
+def test_cfr_recursive_direct_calls(game, golden, oracle):
+    """run_vanilla_cfr_experiment.py:89-91 drives _cfr_recursive(state, p, 1.0, 1.0) itself."""
+    from scopa_amd.algorithms import CFRTrainer
+    g = golden.npz("vanilla_cfr.npz")
+    tr = CFRTrainer(game)
+    for it in range(2):
+        for p in range(game.num_players()):
+            v = tr._cfr_recursive(game.new_initial_state(), p, 1.0, 1.0)
+            assert v == g["root_values"][it, p]
+    m = tr.info_set_map
+    assert np.array_equal(np.array([m[k].regret_sum[0] for k in m]), g["it2_regret"][:, 0])
+    # a non-root state with non-unit reaches, against the oracle
+    t = oracle.Tree(seed=42)
+    R, S, L = t.tables()
+    t.cfr_exact(R, S, L, 2)
+    s = game.new_initial_state()
+    s.apply_action(s.legal_actions()[2])
+    s.apply_action(s.legal_actions()[1])
+    v = tr._cfr_recursive(s, 1, 0.3, 0.7)
+    assert v == t.cfr_exact_from(R, S, L, [2, 1], 1, 0.3, 0.7)
+    Rg, Sg, Lg = tr._engine.ctx.tables_get()
+    assert np.array_equal(Rg, R) and np.array_equal(Sg, S) and np.array_equal(Lg, L)
+    # terminal state: returns the reward, touches nothing
+    while not s.is_terminal():
+        s.apply_action(s.legal_actions()[0])
+    assert tr._cfr_recursive(s, 0, 1.0, 1.0) == s.rewards()[0]
+
+
+def test_evaluate_agent_reproduces_reference_numbers(game, golden):
+    from scopa_amd.algorithms.vanilla_cfr import CFRTrainer, RandomPolicy, evaluate_agent
+    ref = golden.json("evaluate.json")
+    tr = CFRTrainer(game)
+    tr.train(steps=5)
+    pol = tr.get_openspiel_policy()
+    np.random.seed(7)
+    avg, hist, stats = evaluate_agent(game, pol, RandomPolicy(game), num_episodes=200)
+    r = ref["vanilla_it5_seed7_ep200"]
+    assert avg == r["avg_reward"] and hist[:10] == r["hist_head"] and hist[-5:] == r["hist_tail"]
+    assert stats["trained_avg"] == r["trained_avg"] and stats["opponent_avg"] == r["opponent_avg"]
+    assert stats["difference"] == r["difference"] and stats["data_collected"] is True
+    s = game.new_initial_state()
+    while not s.is_terminal():
+        ap = pol.action_probabilities(s)
+        want = ref["vanilla_it5_policy_first_legal_line"][s.history_str()]
+        assert {str(k): float(v) for k, v in ap.items()} == want
+        s.apply_action(s.legal_actions()[0])
+    assert pol.action_probabilities(s) == {}
+
+
+def test_mccfr_trainer_reference_mode(game, golden):
+    """np.random.seed(k); MCCFRTrainer(game).train(n): same tables, same dict keys in the same order, same
+    consumption of the global numpy stream as the reference."""
+    from scopa_amd.algorithms import MCCFRTrainer
+    m = golden.npz("mccfr.npz")
+    for seed, iters in ((0, 10), (2, 200)):
+        tag = f"s{seed}_it{iters}"
+        np.random.seed(seed)
+        tr = MCCFRTrainer(game)
+        if iters == 10:
+            for _ in range(iters):
+                tr.iteration()
+        else:
+            assert tr.train(iterations=iters) == []
+        assert np.random.random_sample() == m[tag + "_next_u"][0]
+        keys = [f"{p}|{s}" for p, s in tr.info_sets.keys()]
+        assert keys == list(m[tag + "_keys"])
+        for i, node in enumerate(tr.info_sets.values()):
+            n = int(m[tag + "_nlegal"][i])
+            assert list(node.legal_actions) == list(m[tag + "_legal"][i, :n])
+            assert np.array_equal(node.regret_sum, m[tag + "_regret"][i, :n])
+            assert np.array_equal(node.strategy_sum, m[tag + "_strategy"][i, :n])
+
+
+def test_mccfr_then_evaluate_reproduces_reference(game, golden):
+    from scopa_amd.algorithms.mc_cfr import MCCFRTrainer, RandomPolicy, evaluate_agent
+    r = golden.json("evaluate.json")["mccfr_seed3_it50_ep200"]
+    np.random.seed(3)
+    tr = MCCFRTrainer(game)
+    tr.train(iterations=50)
+    avg, hist, stats = evaluate_agent(game, tr.tabular_policy(), RandomPolicy(game), num_episodes=200)
+    assert len(tr.info_sets) == r["n_infosets"]
+    assert avg == r["avg_reward"] and hist[:10] == r["hist_head"] and hist[-5:] == r["hist_tail"]
+    assert stats["trained_avg"] == r["trained_avg"] and stats["opponent_avg"] == r["opponent_avg"]
+
+
+def test_mccfr_trainer_batched_mode(game, oracle):
+    from scopa_amd.algorithms import MCCFRTrainer
+    tr = MCCFRTrainer(game, batch=512, seed=77)
+    tr.train(iterations=20)
+    t = oracle.Tree(seed=42)
+    R, S, _ = t.tables()
+    t.mccfr_batched(R, S, 77, 0, 20, 512)
+    e_gpu = tr.exploitability()
+    e_cpu, _ = t.exploitability(t.average_policy(S))
+    assert abs(e_gpu - e_cpu) < 1e-9 and e_gpu < 1.0    # uniform policy: 2.26
+    assert 600 < len(tr.info_sets) <= 738
+    for (p, k), node in tr.info_sets.items():
+        i = t.infoset_strings.index(k)
+        np.testing.assert_allclose(node.regret_sum, R[i, :node.legal_actions.size], rtol=1e-9, atol=1e-9)
+
+
+def test_exploitability_matches_oracle_bit_exact(ctx, sl, oracle, golden):
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    uni = ctx.exploitability(return_policy=True)            # zero strategy table -> uniform policy
+    e, br = t.exploitability(t.average_policy(np.zeros((t.n_infosets, 4))))
+    assert (uni["exploitability"], uni["br0"], uni["br1"]) == (e, br[0], br[1])
+    assert abs(uni["value_p0"] - golden.json("evaluate.json")["uniform_ev_p0"]) < 1e-12
+    assert uni["value_p0"] == t.policy_value(uni["policy"])
+    ctx.cfr_exact_iterate(40)
+    R, S, L = ctx.tables_get()
+    got = ctx.exploitability(return_policy=True)
+    P = t.average_policy(S)
+    assert np.array_equal(got["policy"], P)
+    e, br = t.exploitability(P)
+    assert (got["exploitability"], got["br0"], got["br1"], got["value_p0"]) == (e, br[0], br[1], t.policy_value(P))
+    assert 0 <= got["exploitability"] < uni["exploitability"]
+    # an explicit policy argument
+    rnd = np.random.RandomState(0).rand(t.n_infosets, 4)
+    for i in range(t.n_infosets):
+        rnd[i, t.infoset_nlegal[i]:] = 0
+        rnd[i] /= rnd[i].sum()
+    assert ctx.exploitability(rnd)["exploitability"] == t.exploitability(rnd)[0]
+
+
+def test_exploitability_curve_falls(game):
+    """'exploitability vs iters' (BASELINE metric, parity unpinned): monotone-ish decrease under vanilla CFR."""
+    from scopa_amd.algorithms import CFRTrainer
+    tr = CFRTrainer(game)
+    hist = tr.train(steps=60, eval_interval=20, compute_exploitability=True)
+    assert [t for t, _ in hist] == [20, 40, 60]
+    assert hist[0][1] > hist[-1][1] >= 0
+
+
+def test_entry_scripts_run(ctx):
+    from scopa_amd import cfr_mini_scopa, mccfr_mini_scopa
+    np.random.seed(0)
+    assert cfr_mini_scopa.main(steps=20, num_episodes=100, do_plot=False) > 0          # beats the random agent
+    assert isinstance(mccfr_mini_scopa.main(iterations=30, num_episodes=50), float)
