@@ -141,6 +141,7 @@ static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, 
     if (h_values && n_traversals > 0)
         SC_HIP(ctx, hipMemcpyAsync(h_values, ctx->d_scratch, (size_t)n_traversals * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sigcdf_valid = false;
     return SCOPA_OK;
 }
 

@@ -44,6 +44,8 @@ struct scopa_ctx {
     double *d_delta = nullptr;        // buffer in use (internal or caller-bound)
     double *d_delta_own = nullptr;    // the internal one
     double *d_scratch = nullptr;  // root values / uniforms staging
+    double *d_sigcdf = nullptr;   // [kDecision][8] sigma | cdf rows of the frozen regret table
+    bool sigcdf_valid = false;    // false whenever d_regret changed outside k_mccfr_apply
     double *d_slabs = nullptr;    // [workgroups][n_infosets][5] per-workgroup partial deltas of one traversal launch
     size_t slab_bytes = 0;
     size_t scratch_bytes = 0;

@@ -105,6 +105,7 @@ int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
               hipMalloc(&ctx->d_key, sizeof(uint64_t) * kDecision) == hipSuccess &&
               hipMalloc(&ctx->d_meta, sizeof(int32_t) * 8) == hipSuccess &&
               hipMalloc(&ctx->d_visit, sizeof(uint32_t) * kDecision) == hipSuccess &&
+              hipMalloc(&ctx->d_sigcdf, (size_t)kDecision * 8 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_seen_slabs, (size_t)1024 * kDecision) == hipSuccess &&
               hipMalloc(&ctx->d_regret, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_strat, rows * 4 * sizeof(double)) == hipSuccess &&
@@ -125,7 +126,7 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     (void)hipStreamSynchronize(ctx->stream);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
-                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs, ctx->d_visit, ctx->d_seen_slabs};
+                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs, ctx->d_visit, ctx->d_seen_slabs, ctx->d_sigcdf};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -289,6 +290,7 @@ int32_t scopa_tables_set(scopa_ctx *ctx, const double *h_regret, const double *h
     if (h_strategy) SC_HIP(ctx, hipMemcpyAsync(ctx->d_strat, h_strategy, bytes, hipMemcpyHostToDevice, ctx->stream));
     if (h_local) SC_HIP(ctx, hipMemcpyAsync(ctx->d_local, h_local, bytes, hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sigcdf_valid = false;
     return SCOPA_OK;
 }
 

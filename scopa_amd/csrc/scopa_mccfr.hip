@@ -52,20 +52,73 @@ __device__ __forceinline__ int slot_of(int ntl, uint32_t dig) {
     return ntl == 0 ? 0 : ntl == 1 ? 1 + b0 : ntl == 2 ? 6 + b0 * 4 + b1 : 26 + (b0 * 4 + b1) * 3 + b2;
 }
 
+// One leaf path of traverser TRAV: 8 plies, each { node -> infoset row (sigma[4] | cdf[4], 64 B in LDS); sampled action =
+// #{cdf <= u}; at a traverser ply the lane's branch digit may override it }.  Returns the leaf's BFS index; IX / wX
+// are the infoset and importance weight (mc_cfr.py:81-82) of the one traverser node this lane updates in phase C.
+template <int TRAV>
+__device__ __forceinline__ int walk_path(const uint16_t *__restrict__ s_inf, const double *__restrict__ s_sigcdf,
+                                         uint8_t *__restrict__ s_seen, const double2 *__restrict__ my_u, uint32_t bpack,
+                                         int kstar, int &IX, double &wX) {
+    int idx = 0;
+    uint32_t dig = 0;
+    double reach = 1.0, samp = 1.0, reachX = 0.0, sampX = 0.0;
+#pragma unroll
+    for (int d = 0; d < kPlies; d++) {
+        constexpr int dummy = 0; (void)dummy;
+        const int n = 4 - (d >> 1);
+        const bool is_trav = (d & 1) == TRAV;
+        const int ntl = TRAV == 0 ? (d + 1) >> 1 : d >> 1;  // traverser plies strictly above ply d
+        const int In = s_inf[level_offset(d) + idx];
+        s_seen[In] = 1;  // benign race: every writer stores 1
+        const double *row = s_sigcdf + In * 8;
+        int a = 0;
+        if (n > 1) {
+            const double2 uu = my_u[slot_of(ntl, dig)];
+            const double u = is_trav ? uu.y : uu.x;
+            a = (row[4] <= u) + (row[5] <= u) + (row[6] <= u) + (row[7] <= u);
+            a = a < n - 1 ? a : n - 1;
+        }
+        if (is_trav) {
+            const int dg = (int)((bpack >> (3 * ntl)) & 7u);
+            if (dg) a = dg - 1;
+            if (ntl == kstar) { IX = In; reachX = reach; sampX = samp; }
+            if (n > 1) samp *= row[a];
+            dig |= (uint32_t)dg << (3 * ntl);
+        } else if (n > 1) {
+            reach *= row[a];
+        }
+        idx = idx * n + a;
+    }
+    wX = sampX > 0.0 ? reachX / sampX : 0.0;  // weight = opp_reach / sampling_probs[player] if > 0 else 0
+    return idx;
+}
+
 }  // namespace
+
+// sigma | cdf rows of the frozen regret table, [n_infosets][8] float64, computed once per iteration
+__global__ void __launch_bounds__(256)
+k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret, double *__restrict__ g_sigcdf, int n_infosets) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_infosets) return;
+    const int n = (int)((g_key[r] >> 1) & 7);
+    double R[4], sg[4], cd[4];
+    for (int c = 0; c < 4; c++) R[c] = g_regret[r * 4 + c];
+    mc_sigma(R, n, sg);
+    choice_cdf(sg, n, cd);
+    for (int c = 0; c < 4; c++) { g_sigcdf[r * 8 + c] = sg[c]; g_sigcdf[r * 8 + 4 + c] = cd[c]; }
+}
 
 // ---------------------------------------------------------------------------------------------------------------------
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
-                 const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret, double *__restrict__ g_slabs,
+                 const double *__restrict__ g_sigcdf, double *__restrict__ g_slabs,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
                  unsigned long long *__restrict__ g_wg_counts, uint8_t *__restrict__ g_seen_slabs) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     const int I = n_infosets;
-    double *s_sigma = reinterpret_cast<double *>(smem);          // [I][4]
-    double *s_cdf = s_sigma + (size_t)I * 4;                     // [I][4]
-    double *s_dR = s_cdf + (size_t)I * 4;                        // [I][4]
+    double *s_sigcdf = reinterpret_cast<double *>(smem);         // [I][8]: sigma[4] | normalised cdf[4]
+    double *s_dR = s_sigcdf + (size_t)I * 8;                     // [I][4]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_dR + (size_t)I * 4);  // [I]
     const int tasks_per_wg = blockDim.x / kTaskLanes;
     double2 *s_u = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));
@@ -77,17 +130,11 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const int tid = threadIdx.x;
     if (tid < 2) s_vis[tid] = 0u;
     // ---- prologue: freeze this iteration's strategy in LDS ----------------------------------------------------------
-    for (int r = tid; r < I; r += blockDim.x) {
-        const int n = (int)((g_key[r] >> 1) & 7);
-        double R[4], sg[4], cd[4];
-        const double2 ra = reinterpret_cast<const double2 *>(g_regret)[r * 2], rb = reinterpret_cast<const double2 *>(g_regret)[r * 2 + 1];
-        R[0] = ra.x; R[1] = ra.y; R[2] = rb.x; R[3] = rb.y;
-        mc_sigma(R, n, sg);
-        choice_cdf(sg, n, cd);
-        for (int c = 0; c < 4; c++) { s_sigma[r * 4 + c] = sg[c]; s_cdf[r * 4 + c] = cd[c]; s_dR[r * 4 + c] = 0.0; }
-        s_cnt[r] = 0u;
-        s_seen[r] = 0;
+    for (int i = tid; i < I * 4; i += blockDim.x) {  // 16-byte copies of the prepared rows
+        reinterpret_cast<double2 *>(s_sigcdf)[i] = reinterpret_cast<const double2 *>(g_sigcdf)[i];
+        s_dR[i] = 0.0;
     }
+    for (int r = tid; r < I; r += blockDim.x) { s_cnt[r] = 0u; s_seen[r] = 0; }
     for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
     __syncthreads();
@@ -121,40 +168,14 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         }
         __syncthreads();
 
-        // ---- phase B: walk root -> leaf ----------------------------------------------------------------------------
+        // ---- phase B: walk root -> leaf (specialised on the wave-uniform traverser: ply roles are compile-time) ---
         int IX = 0;
         double wX = 0.0;
         if (live && l < kPaths) {
-            int idx = 0, ntl = 0;
-            uint32_t dig = 0;
-            double reach = 1.0, samp = 1.0;
-#pragma unroll
-            for (int d = 0; d < kPlies; d++) {
-                const int n = 4 - (d >> 1);
-                const int In = s_inf[level_offset(d) + idx];
-                const bool is_trav = (d & 1) == trav;
-                s_seen[In] = 1;  // benign race: every writer stores 1
-                int a = 0;
-                if (n > 1) {
-                    const double2 uu = my_u[slot_of(ntl, dig)];
-                    const double u = is_trav ? uu.y : uu.x;
-                    const double *c = s_cdf + In * 4;
-                    a = (c[0] <= u) + (c[1] <= u) + (c[2] <= u) + (c[3] <= u);
-                    a = a < n - 1 ? a : n - 1;
-                }
-                if (is_trav) {
-                    const int dg = (int)((bpack >> (3 * ntl)) & 7u);
-                    if (dg) a = dg - 1;
-                    if (ntl == kstar) { IX = In; wX = samp > 0.0 ? reach / samp : 0.0; }
-                    if (n > 1) samp *= s_sigma[In * 4 + a];
-                    dig |= (uint32_t)dg << (3 * ntl);
-                    ntl++;
-                } else if (n > 1) {
-                    reach *= s_sigma[In * 4 + a];
-                }
-                idx = idx * n + a;
-            }
-            const int p0 = s_pay[idx];
+            int leaf;
+            if (trav == 0) leaf = walk_path<0>(s_inf, s_sigcdf, s_seen, my_u, bpack, kstar, IX, wX);
+            else           leaf = walk_path<1>(s_inf, s_sigcdf, s_seen, my_u, bpack, kstar, IX, wX);
+            const int p0 = s_pay[leaf];
             my_px2[l] = trav == 0 ? p0 : -p0;
             my_tvis += 1;
             my_dvis += kstar < 0 ? 8 : 7 - trav - 2 * kstar;
@@ -170,7 +191,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
             double v = 0.0, mine = 0.0;
             for (int j = 0; j < nX; j++) {
                 const double cfv = 0.5 * (double)my_px2[base + (j + 1) * stride];
-                v = fma(s_sigma[IX * 4 + j], cfv, v);  // np.dot on this numpy build: an fma chain (see oracle)
+                v = fma(s_sigcdf[IX * 8 + j], cfv, v);  // np.dot on this numpy build: an fma chain (see oracle)
                 if (j == dg - 1) mine = cfv;
             }
             const double delta = wX * (mine - v);
@@ -256,7 +277,7 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
 // regret += delta; strategy_sum += count * sigma(frozen regret); delta <- 0
 __global__ void __launch_bounds__(256)
 k_mccfr_apply(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret, double *__restrict__ g_strat,
-              double *__restrict__ g_delta, int n_infosets) {
+              double *__restrict__ g_delta, int n_infosets, double *__restrict__ g_sigcdf) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_infosets) return;
     const int n = (int)((g_key[r] >> 1) & 7);
@@ -265,10 +286,16 @@ k_mccfr_apply(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret,
     mc_sigma(R, n, sg);
     const double cnt = g_delta[r * 5 + 4];
     for (int c = 0; c < n; c++) {
-        g_regret[r * 4 + c] = R[c] + g_delta[r * 5 + c];
+        R[c] += g_delta[r * 5 + c];
+        g_regret[r * 4 + c] = R[c];
         g_strat[r * 4 + c] += cnt * sg[c];
     }
     for (int c = 0; c < 5; c++) g_delta[r * 5 + c] = 0.0;
+    // next iteration's frozen strategy rows (what k_mccfr_prepare would compute)
+    double cd[4];
+    mc_sigma(R, n, sg);
+    choice_cdf(sg, n, cd);
+    for (int c = 0; c < 4; c++) { g_sigcdf[r * 8 + c] = sg[c]; g_sigcdf[r * 8 + 4 + c] = cd[c]; }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -396,9 +423,15 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
         SC_HIP(ctx, hipMalloc(&ctx->d_slabs, want > slab_bytes ? want : slab_bytes));
         ctx->slab_bytes = want > slab_bytes ? want : slab_bytes;
     }
+    if (!ctx->sigcdf_valid) {  // tables were changed by another entry point since the last apply
+        hipLaunchKernelGGL(k_mccfr_prepare, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
+                           ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
+        SC_HIP(ctx, hipGetLastError());
+        ctx->sigcdf_valid = true;
+    }
     prof_begin(ctx);
     hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
-                       ctx->d_key, ctx->d_regret, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed,
+                       ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed,
                        (uint32_t)(ctx->seed >> 32), iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
     prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
@@ -470,8 +503,9 @@ int32_t scopa_mccfr_apply(scopa_ctx *ctx) {
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_apply: no deal set");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_mccfr_apply, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
-                       ctx->d_regret, ctx->d_strat, ctx->d_delta, ctx->n_infosets);
+                       ctx->d_regret, ctx->d_strat, ctx->d_delta, ctx->n_infosets, ctx->d_sigcdf);
     SC_HIP(ctx, hipGetLastError());
+    ctx->sigcdf_valid = true;
     ctx->iteration++;
     return SCOPA_OK;
 }
@@ -512,6 +546,7 @@ int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_unif
     long long used = 0;
     SC_HIP(ctx, hipMemcpyAsync(&used, d_consumed, sizeof used, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sigcdf_valid = false;
     if (consumed) *consumed = used;
     return SCOPA_OK;
 }

@@ -175,6 +175,7 @@ int32_t scopa_tables_reset(scopa_ctx *ctx) {
     SC_HIP(ctx, hipMemsetAsync(ctx->d_meta + 1, 0, sizeof(int32_t), ctx->stream));
     SC_HIP(ctx, hipMemsetAsync(ctx->d_delta, 0, (size_t)(ctx->d_delta == ctx->d_delta_own ? kDecision : ctx->n_infosets) * 5 * sizeof(double), ctx->stream));
     ctx->iteration = 0;
+    ctx->sigcdf_valid = false;
     return SCOPA_OK;
 }
 

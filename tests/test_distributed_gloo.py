@@ -1,0 +1,97 @@
+"""The N>1 path on CPU: world_size-2 gloo processes drive scopa_amd.distributed.ShardedMCCFR.
+
+There is no GPU here, so each rank's engine is a test double whose traverse step is the ORACLE (allowed: tests may
+call the oracle as the checker).  What is under test is the product's host logic: the partition of global traversal
+ids, the single sum-all-reduce of the [n_infosets][5] delta per iteration, and every rank applying the same sum --
+i.e. that 2 ranks reproduce the 1-rank result (integer visit counts exactly, float64 sums to 1e-12)."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+
+class OracleEngine:
+    """Same three calls as scopa_amd._lib.Context, computed by the oracle; delta layout [I][5] like the device buffer."""
+
+    def __init__(self, seed):
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import oracle as O
+        self.t = O.Tree(seed=42)
+        self.R, self.S, _ = self.t.tables()
+        self.delta = np.zeros((self.t.n_infosets, 5))
+        self.seed, self.it = seed, 0
+
+    def mccfr_iteration(self):
+        return self.it
+
+    def mccfr_traverse(self, iteration, b0, nb):
+        dR, dS, _, _ = self.t.mccfr_batched_delta(self.R, self.seed, iteration, b0, nb)
+        self.delta[:, :4] += dR
+        self.delta[:, 4] += np.rint(dS.sum(1))
+
+    def mccfr_apply(self):
+        # k_mccfr_apply: regret += delta; strategy += count * sigma(frozen regret); delta <- 0
+        pos = np.maximum(self.R, 0)
+        s = pos.sum(1, keepdims=True)
+        n = self.t.infoset_nlegal.astype(int)
+        uni = np.array([[1.0 / n[i] if c < n[i] else 0.0 for c in range(4)] for i in range(len(n))])
+        sigma = np.where(s == 0, uni, pos / np.where(s == 0, 1, s))
+        self.R += self.delta[:, :4]
+        self.S += self.delta[:, 4:5] * sigma
+        self.delta[:] = 0
+        self.it += 1
+
+
+def _worker(rank, world, port, batch, iters, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from scopa_amd.distributed import ShardedMCCFR
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    eng = OracleEngine(seed=31337)
+    buf = torch.from_numpy(eng.delta)  # aliases the delta buffer, as the bound torch tensor does on the GPU
+
+    def all_reduce():
+        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+
+    ShardedMCCFR(eng, rank, world, all_reduce).run(batch, iters)
+    np.savez(out.format(rank=rank), R=eng.R, S=eng.S)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_shard_range_partitions_exactly():
+    from scopa_amd.distributed import shard_range
+    for total in (0, 1, 7, 4096, 262144, 1000003):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and sum(nb for _, nb in spans) == total
+            assert all(spans[r][0] + spans[r][1] == spans[r + 1][0] for r in range(world - 1))
+            assert max(nb for _, nb in spans) - min(nb for _, nb in spans) <= 1
+
+
+def test_two_ranks_reproduce_one_rank(tmp_path):
+    import torch.multiprocessing as mp
+    batch, iters, world = 37, 4, 2   # odd batch: uneven shards
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank{rank}.npz")
+    mp.spawn(_worker, args=(world, port, batch, iters, out), nprocs=world, join=True)
+    single = OracleEngine(seed=31337)
+    from scopa_amd.distributed import ShardedMCCFR
+    ShardedMCCFR(single, 0, 1).run(batch, iters)
+    r0, r1 = np.load(out.format(rank=0)), np.load(out.format(rank=1))
+    assert np.array_equal(r0["R"], r1["R"]) and np.array_equal(r0["S"], r1["S"])   # replicas stay bit-identical
+    np.testing.assert_allclose(r0["R"], single.R, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(r0["S"], single.S, rtol=1e-12, atol=1e-12)
+    # and the host-side apply of the test double is the oracle's own batched iteration
+    ref = OracleEngine(seed=31337)
+    ref.t.mccfr_batched(ref.R, ref.S, 31337, 0, iters, batch)
+    np.testing.assert_allclose(single.R, ref.R, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(single.S, ref.S, rtol=1e-12, atol=1e-12)
