@@ -155,6 +155,38 @@ int32_t scopa_mccfr_delta_set(scopa_ctx *ctx, const double *h_delta);
 int32_t scopa_mccfr_apply(scopa_ctx *ctx);
 int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration);
 
+/* ---- SDCFR: level-synchronous external-sampling traversal (DeepCFR._external_sampling_cfr, deep_cfr.py:284-365) ---------
+ * B traversals of one traverser advance ply by ply; the advantage MLP runs in PyTorch between the two calls of a ply.
+ * Frontier slot s of ply d refers to tree node d_idx[s] (index within the ply); a traversal owns `width` consecutive slots
+ * (scopa_sdcfr_frontier_width: 1,4,4,12,12,24,24,24,24 for traverser 0; 1,1,4,4,12,12,24,24,24 for traverser 1).
+ *   features : DeepCFR._state_to_features + ._get_legal_actions_mask (:213-282) -> d_feats[n][34], d_mask[n][16] float32
+ *   expand   : positive_regret_policy (nets.py:93-101) of d_adv[n][16] (raw net output); traverser ply -> all legal
+ *              children d_child_idx[n*nlegal] (hand order), opponent ply -> ONE sampled child d_child_idx[n]
+ *              (np.random.choice arithmetic; draws from d_uniforms[n] if given, else Philox keyed by the global
+ *              traversal id b0 + s/width); d_pol[n][4] = policy of the legal actions in hand order
+ *   terminal_values : float(rewards[player]) at ply 8
+ *   backward : traverser ply: value = sum pol*child value (float32, hand order), regrets = cfv - value over all 16 slots
+ *              (illegal slots = -value, as the reference), divided by max|.|+1e-8, and the memory row (feats, regrets, mask)
+ *              written to ring position (write_base + traversal*41 + DFS-post-order rank) % capacity, i.e. in the
+ *              reference's append order (AdvantageNetwork.add_experience :70-75); opponent ply: value = child's value */
+int32_t scopa_sdcfr_frontier_width(int32_t traverser, int32_t ply);
+int32_t scopa_sdcfr_features(scopa_ctx *ctx, int32_t ply, int64_t n, const int32_t *d_idx, float *d_feats, float *d_mask);
+int32_t scopa_sdcfr_expand(scopa_ctx *ctx, int32_t ply, int32_t traverser, int64_t n, const int32_t *d_idx, const float *d_adv,
+                           int32_t *d_child_idx, float *d_pol, const double *d_uniforms, uint32_t iteration, uint32_t b0);
+int32_t scopa_sdcfr_terminal_values(scopa_ctx *ctx, int32_t traverser, int64_t n, const int32_t *d_idx, float *d_val);
+int32_t scopa_sdcfr_backward(scopa_ctx *ctx, int32_t ply, int32_t traverser, int64_t n, const int32_t *d_idx, const float *d_pol,
+                             const float *d_child_val, float *d_val, const float *d_feats, const float *d_mask, float *d_mem_feat,
+                             float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base);
+int32_t scopa_sdcfr_visits(scopa_ctx *ctx, uint64_t *decision_visits);
+/* features / masks of arbitrary device-resident states for the player to move (DeepCFR.get_policy, :497-504) */
+int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask);
+/* batched evaluation episodes (evaluate_vs_random :367-429; evaluate_agent vanilla_cfr.py:157-216): n copies of the deal's
+ * root state; one ply of play: the seat d_trained_seat[i] samples from d_probs[i][16] (uniform if it has no positive mass),
+ * the other seat plays uniformly at random; finished episodes are left untouched.  Philox stream (seed, stream_id, ply_tag, i). */
+int32_t scopa_eval_init_states(scopa_ctx *ctx, scopa_state *d_states, int64_t n);
+int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const float *d_probs, const int32_t *d_trained_seat,
+                        uint32_t stream_id, uint32_t ply_tag);
+
 /* ---- policy value / exploitability (build-defined; the reference only calls OpenSpiel's, vanilla_cfr.py:112-118) --
  * h_policy[n_infosets][4] or NULL = the average policy of the strategy table (InfoNode.policy, vanilla_cfr.py:32-39).
  * h_out4 = {exploitability = (BR0+BR1)/2, BR0, BR1, value of the policy for player 0}; h_policy_out (optional)

@@ -304,6 +304,9 @@ def gen_evaluate(ns):
 
 # ----------------------------------------------------------------------------------
 def gen_sdcfr(ns):
+    """DeepCFR (deep_cfr.py): feature encoder, one traversal per player with saved weights, one train() call.
+    The freshly initialised nets give all-zero regret-matching policies (every value 0.0), which would pin
+    nothing, so the head biases are shifted by a fixed ramp before the traversals; the weights used are saved."""
     import importlib
     import random as pyrandom
     import torch
@@ -314,13 +317,15 @@ def gen_sdcfr(ns):
     np.random.seed(0)
     d = dc.DeepCFR(game, num_players=2, device="cpu")
     out = {"input_dim": np.array([d.input_dim])}
-    # saved weights (f32) of both advantage nets, in state_dict order
     for p in range(2):
+        with torch.no_grad():
+            ramp = torch.linspace(0.15, 1.25, 16)
+            d.advantage_nets[p].net.head.bias += ramp if p == 0 else ramp.flip(0)
         sd = d.advantage_nets[p].net.state_dict()
         out[f"net{p}_names"] = np.array(list(sd.keys()))
         for k, v in sd.items():
             out[f"net{p}__{k}"] = v.detach().numpy().copy()
-    # features / masks along the first-legal line and at the root for both players
+    # features / masks along the first-legal line for both players
     s = game.new_initial_state()
     feats, masks, players, hists = [], [], [], []
     while not s.is_terminal():
@@ -334,9 +339,10 @@ def gen_sdcfr(ns):
     out["mask_line"] = np.array(masks, np.float32)
     out["feat_line_player"] = np.array(players, np.int8)
     out["feat_line_hist"] = np.array(hists)
-    # one traversal per player with the seeded nets; record node log via a wrapped get_advantages
+    # one traversal per player; log every node visit and every np.random.choice call
+    orig_choice = np.random.choice
     for trav in (0, 1):
-        log = []
+        log, draws = [], []
         for p in range(2):
             net = d.advantage_nets[p]
             def wrap(f, m, _orig=net.get_advantages, _p=p):
@@ -344,29 +350,53 @@ def gen_sdcfr(ns):
                 log.append((_p, np.array(f, np.float32).copy(), np.array(m, np.float32).copy(), np.array(adv, np.float32).reshape(-1).copy()))
                 return adv
             net.get_advantages = wrap
+        def choice(a, size=None, replace=True, p=None):
+            r = orig_choice(a, size=size, replace=replace, p=p)
+            draws.append((0 if p is None else 1, int(r)))
+            return r
+        np.random.choice = choice
         n_before = [len(d.advantage_nets[p].buffer) for p in range(2)]
         np.random.seed(100 + trav)
-        val = d._external_sampling_cfr(game.new_initial_state(), trav)
+        try:
+            val = d._external_sampling_cfr(game.new_initial_state(), trav)
+        finally:
+            np.random.choice = orig_choice
         for p in range(2):
             del d.advantage_nets[p].get_advantages
         rows = list(d.advantage_nets[trav].buffer)[n_before[trav]:]
+        assert all(k == 1 for k, _ in draws), "a uniform-fallback draw occurred: the draw stream is no longer one random_sample per opponent visit"
         out[f"trav{trav}_value"] = np.array([float(val)])
         out[f"trav{trav}_value_is_f32"] = np.array([isinstance(val, np.float32)])
         out[f"trav{trav}_visit_player"] = np.array([l[0] for l in log], np.int8)
         out[f"trav{trav}_visit_feat"] = np.array([l[1] for l in log], np.float32)
         out[f"trav{trav}_visit_mask"] = np.array([l[2] for l in log], np.float32)
         out[f"trav{trav}_visit_adv"] = np.array([l[3] for l in log], np.float32)
+        out[f"trav{trav}_draw_action"] = np.array([a for _, a in draws], np.int8)
         out[f"trav{trav}_row_feat"] = np.array([r[0] for r in rows], np.float32)
         out[f"trav{trav}_row_regret"] = np.array([r[1] for r in rows], np.float32)
         out[f"trav{trav}_row_mask"] = np.array([r[2] for r in rows], np.float32)
-        print(f"sdcfr trav {trav}: visits={len(log)} rows={len(rows)} value={float(val)!r} type={type(val).__name__}")
-    # one train() call pins the loss pipeline (random.sample stream is fixed by the deck re-seed side effect)
+        print(f"sdcfr trav {trav}: visits={len(log)} rows={len(rows)} draws={len(draws)} value={float(val)!r} type={type(val).__name__}")
+    # one train() call pins the loss pipeline.  In the reference the global `random` state at this point is
+    # "seed(42) + shuffle of the 16-card deck" (every clone() re-seeds, mini_scopa_game.py:25-28); restore exactly that.
     pyrandom.seed(42)
+    pyrandom.shuffle(list(range(16)))
     loss = d.advantage_nets[0].train(epochs=2)
     out["train_loss_p0_epochs2"] = np.array([loss])
+    out["train_buffer_len"] = np.array([len(d.advantage_nets[0].buffer)])
     for k, v in d.advantage_nets[0].net.state_dict().items():
         out[f"net0_after__{k}"] = v.detach().numpy().copy()
-    print("sdcfr train loss", loss)
+    print("sdcfr train loss", loss, "buffer", len(d.advantage_nets[0].buffer))
+    # get_policy with one strategy snapshot per player (weights = the saved nets, iteration weight 2)
+    for p in range(2):
+        snap = dc.FlexibleNet(mode="mlp", input_shape=(d.input_dim,), output_dim=16, mlp_hidden=dc.HIDDEN, mlp_act="relu", mlp_norm="none")
+        snap.load_state_dict({k: torch.from_numpy(out[f"net{p}__{k}"]) for k in out[f"net{p}_names"]})
+        d.strategy_buffers[p].add_strategy(snap, 1)
+    s = game.new_initial_state()
+    pols = []
+    while not s.is_terminal():
+        pols.append(d.get_policy(s, s.current_player()))
+        s.apply_action(s.legal_actions()[0])
+    out["policy_line"] = np.array(pols, np.float32)
     np.savez_compressed(os.path.join(OUT, "sdcfr.npz"), **out)
 
 

@@ -23,7 +23,9 @@ SYMBOLS = [
     "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
     "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
-    "scopa_mccfr_iteration_counter", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
+    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_features_from_states",
+    "scopa_eval_init_states", "scopa_eval_step", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -58,6 +60,12 @@ def lib():
     global _lib
     if _lib is not None:
         return _lib
+    try:
+        # PyTorch-ROCm bundles its own HIP/HSA runtime.  If libscopa_hip.so pulled in /opt/rocm's copy first, torch would
+        # later start a SECOND runtime in the process and find no GPU; loading torch first makes both share one.
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     if not os.path.exists(LIB_PATH):
         raise OSError(f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` or `python scopa_amd/build.py` "
                       "(the MiniScopa solver path has no fallback)")
@@ -103,6 +111,15 @@ def lib():
         "scopa_mccfr_apply": (i32, [vp]),
         "scopa_mccfr_iteration_counter": (i32, [vp, C.POINTER(u32)]),
         "scopa_exploitability": (i32, [vp, vp, vp, vp]),
+        "scopa_sdcfr_frontier_width": (i32, [i32, i32]),
+        "scopa_sdcfr_features": (i32, [vp, i32, i64, vp, vp, vp]),
+        "scopa_sdcfr_expand": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, vp, u32, u32]),
+        "scopa_sdcfr_terminal_values": (i32, [vp, i32, i64, vp, vp]),
+        "scopa_sdcfr_backward": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64]),
+        "scopa_sdcfr_visits": (i32, [vp, C.POINTER(u64)]),
+        "scopa_features_from_states": (i32, [vp, vp, i64, vp, vp]),
+        "scopa_eval_init_states": (i32, [vp, vp, i64]),
+        "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
@@ -296,6 +313,39 @@ class Context:
         if return_policy:
             res["policy"] = pout
         return res
+
+    # ---- SDCFR / evaluation building blocks (device pointers: torch tensors' data_ptr()) --------------
+    def sdcfr_features(self, ply, n, idx_ptr, feats_ptr, mask_ptr):
+        self._ck(self._L.scopa_sdcfr_features(self._h, ply, n, C.c_void_p(idx_ptr), C.c_void_p(feats_ptr), C.c_void_p(mask_ptr)), "scopa_sdcfr_features")
+
+    def sdcfr_expand(self, ply, traverser, n, idx_ptr, adv_ptr, child_ptr, pol_ptr, uniforms_ptr, iteration, b0):
+        self._ck(self._L.scopa_sdcfr_expand(self._h, ply, traverser, n, C.c_void_p(idx_ptr), C.c_void_p(adv_ptr), C.c_void_p(child_ptr),
+                                            C.c_void_p(pol_ptr), C.c_void_p(uniforms_ptr) if uniforms_ptr else None, iteration, b0), "scopa_sdcfr_expand")
+
+    def sdcfr_terminal_values(self, traverser, n, idx_ptr, val_ptr):
+        self._ck(self._L.scopa_sdcfr_terminal_values(self._h, traverser, n, C.c_void_p(idx_ptr), C.c_void_p(val_ptr)), "scopa_sdcfr_terminal_values")
+
+    def sdcfr_backward(self, ply, traverser, n, idx_ptr, pol_ptr, child_val_ptr, val_ptr, feats_ptr, mask_ptr, mem_feat_ptr, mem_regret_ptr,
+                       mem_mask_ptr, capacity, write_base):
+        vp = lambda x: C.c_void_p(x) if x else None
+        self._ck(self._L.scopa_sdcfr_backward(self._h, ply, traverser, n, vp(idx_ptr), vp(pol_ptr), vp(child_val_ptr), vp(val_ptr), vp(feats_ptr),
+                                              vp(mask_ptr), vp(mem_feat_ptr), vp(mem_regret_ptr), vp(mem_mask_ptr), capacity, write_base),
+                 "scopa_sdcfr_backward")
+
+    def sdcfr_visits(self):
+        v = C.c_uint64()
+        self._ck(self._L.scopa_sdcfr_visits(self._h, C.byref(v)), "scopa_sdcfr_visits")
+        return v.value
+
+    def features_from_states(self, states_ptr, n, feats_ptr, mask_ptr):
+        self._ck(self._L.scopa_features_from_states(self._h, C.c_void_p(states_ptr), n, C.c_void_p(feats_ptr), C.c_void_p(mask_ptr)), "scopa_features_from_states")
+
+    def eval_init_states(self, states_ptr, n):
+        self._ck(self._L.scopa_eval_init_states(self._h, C.c_void_p(states_ptr), n), "scopa_eval_init_states")
+
+    def eval_step(self, states_ptr, n, probs_ptr, seat_ptr, stream_id, ply_tag):
+        self._ck(self._L.scopa_eval_step(self._h, C.c_void_p(states_ptr), n, C.c_void_p(probs_ptr) if probs_ptr else None, C.c_void_p(seat_ptr),
+                                         stream_id, ply_tag), "scopa_eval_step")
 
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()

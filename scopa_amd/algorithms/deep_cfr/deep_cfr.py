@@ -1,0 +1,332 @@
+"""Single Deep CFR on MiniScopa with the reference's interface (mirrors src/algorithms/deep_cfr/deep_cfr.py).
+
+What moved to the GPU: the external-sampling traversal (level-synchronous HIP kernels, `batch` traversals at once,
+ONE batched MLP forward per ply instead of a batch-1 forward per node), feature/mask encoding, regret normalisation and
+the advantage memory (a device-resident FIFO ring the kernels write into directly), and evaluation vs random (all
+episodes in lockstep on the device step kernel).  What stays PyTorch: the advantage MLP, Adam, the MSE loss -- on
+PyTorch-ROCm.  `batch=1` is the reference's shape (one traversal per player per iteration, 41 rows each).
+"""
+import random
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.optim as optim
+
+from ...engine import Engine
+from ... import _lib
+from .nets import FlexibleNet, positive_regret_policy
+
+HIDDEN = [128, 64]
+ROWS_PER_TRAVERSAL = 41  # traverser-node visits of one traversal (1 + 4 + 12 + 24)
+
+
+class DeviceMemory:
+    """FIFO advantage memory (the reference's deque(maxlen=100000), deep_cfr.py:52) as three device tensors."""
+
+    def __init__(self, capacity, input_dim, device):
+        self.capacity = capacity
+        self.feat = torch.zeros((capacity, input_dim), dtype=torch.float32, device=device)
+        self.regret = torch.zeros((capacity, 16), dtype=torch.float32, device=device)
+        self.mask = torch.zeros((capacity, 16), dtype=torch.float32, device=device)
+        self.total = 0  # rows ever appended
+
+    def __len__(self):
+        return min(self.total, self.capacity)
+
+    @property
+    def write_base(self):
+        return self.total % self.capacity
+
+    def advance(self, rows):
+        self.total += rows
+
+    def logical_to_physical(self, idx):
+        """deque index (0 = oldest) -> ring row."""
+        start = self.total % self.capacity if self.total > self.capacity else 0
+        return (idx + start) % self.capacity
+
+    def rows(self, idx):
+        r = self.logical_to_physical(idx)
+        return self.feat[r], self.regret[r], self.mask[r]
+
+    def __getitem__(self, i):
+        f, r, m = self.rows(torch.tensor([i % max(len(self), 1)], device=self.feat.device))
+        return f[0].cpu().numpy(), r[0].cpu().numpy(), m[0].cpu().numpy()
+
+
+class AdvantageNetwork:
+    """Advantage net + Adam + memory for one player (deep_cfr.py:24-116)."""
+
+    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4):
+        self.device = device
+        self.num_actions = num_actions
+        self.net = FlexibleNet(mode="mlp", input_shape=(input_dim,), output_dim=num_actions, mlp_hidden=HIDDEN,
+                               mlp_act="relu", mlp_norm="none", mlp_dropout=0.0).to(device)
+        for layer in self.net.modules():
+            if isinstance(layer, nn.Linear):
+                nn.init.xavier_uniform_(layer.weight)
+                nn.init.constant_(layer.bias, 0.1)
+        self.optimizer = optim.Adam(self.net.parameters(), lr=lr)
+        self.criterion = nn.MSELoss()
+        self.buffer = DeviceMemory(100000, input_dim, device)
+        self._rng = random.Random()
+
+    def get_advantages(self, state_features, legal_actions_mask):
+        with torch.no_grad():
+            x = torch.as_tensor(np.asarray(state_features), dtype=torch.float32, device=self.device)
+            m = torch.as_tensor(np.asarray(legal_actions_mask), dtype=torch.float32, device=self.device)
+            if x.dim() == 1:
+                x, m = x.unsqueeze(0), m.unsqueeze(0)
+            adv = self.net(x)
+            return (adv * m - 1e6 * (1 - m)).cpu().numpy()
+
+    def sample_indices(self, n, batch_size):
+        """The reference's `random.sample(self.buffer, batch_size)` (:88).  There the global `random` stream was last
+        seeded by a MiniDeck() built during the traversal (seed 42 + one 16-card shuffle, mini_scopa_game.py:25-28), so
+        the sample is a deterministic function of the buffer length; the same stream is rebuilt here privately."""
+        return self._rng.sample(range(n), batch_size)
+
+    def train(self, batch_size=128, epochs=1):
+        n = len(self.buffer)
+        if n < batch_size:
+            batch_size = min(n, 32)
+            if batch_size == 0:
+                return 0.0
+        self._rng.seed(42)
+        self._rng.shuffle(list(range(16)))
+        total_loss = 0.0
+        for _ in range(epochs):
+            idx = torch.tensor(self.sample_indices(n, batch_size), device=self.device)
+            states, target_adv, masks = self.buffer.rows(idx)
+            self.optimizer.zero_grad()
+            pred_adv = self.net(states)
+            loss = self.criterion(pred_adv * masks, target_adv * masks)
+            loss.backward()
+            torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm=1.0)
+            self.optimizer.step()
+            total_loss += loss.item()
+        return total_loss / epochs
+
+
+class StrategyBuffer:
+    """<= max_size net snapshots, weight = iteration + 1 (deep_cfr.py:119-160)."""
+
+    def __init__(self, max_size=100):
+        self.strategies, self.weights, self.max_size = [], [], max_size
+
+    def add_strategy(self, strategy_net, iteration):
+        if len(self.strategies) >= self.max_size:
+            self.strategies.pop(0)
+            self.weights.pop(0)
+        self.strategies.append(strategy_net)
+        self.weights.append(iteration + 1)
+
+    def average_policy_batch(self, feats, masks):
+        """[N,34],[N,16] device tensors -> [N,16] weighted average of the snapshots' regret-matching policies."""
+        if not self.strategies:
+            return masks / masks.sum(dim=-1, keepdim=True)
+        total = float(sum(self.weights))
+        out = torch.zeros_like(masks)
+        with torch.no_grad():
+            for net, w in zip(self.strategies, self.weights):
+                out += positive_regret_policy(net(feats), masks) * (w / total)
+        return out
+
+    def get_average_policy(self, state_features, legal_actions_mask):
+        dev = next(self.strategies[0].parameters()).device if self.strategies else "cpu"
+        f = torch.as_tensor(np.asarray(state_features), dtype=torch.float32, device=dev).unsqueeze(0)
+        m = torch.as_tensor(np.asarray(legal_actions_mask), dtype=torch.float32, device=dev).unsqueeze(0)
+        return self.average_policy_batch(f, m)[0].cpu().numpy()
+
+
+class RandomPolicy:
+    def action_probabilities(self, state, player_id=None):
+        if state.is_terminal():
+            return {}
+        if player_id is None:
+            player_id = state.current_player()
+        legal_actions = state.legal_actions(player_id)
+        prob = 1.0 / len(legal_actions)
+        return {action: prob for action in legal_actions}
+
+
+class DeepCFR:
+    """`DeepCFR(game, num_players=2, device="cuda").train(iterations, advantage_epochs, eval_freq)`."""
+
+    def __init__(self, game, num_players=2, device="cuda", batch=1, seed=0x5C09A, stream=None):
+        if not str(device).startswith("cuda"):
+            raise ValueError("the SDCFR traversal runs on the GPU (HIP kernels): device must be a cuda device")
+        self.game = game
+        self.num_players = num_players
+        self.device = device
+        self.batch = int(batch)
+        dev_index = torch.device(device).index or 0
+        self._stream = stream if stream is not None else torch.cuda.Stream(device=dev_index)
+        self._engine = Engine(game, device=dev_index, stream=self._stream.cuda_stream)
+        self._engine.ctx.mccfr_seed(seed)
+        self.input_dim = self._estimate_input_dim()
+        print(f"Estimated input dimension: {self.input_dim}")
+        with torch.cuda.stream(self._stream):
+            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device) for _ in range(num_players)]
+        self.strategy_buffers = [StrategyBuffer() for _ in range(num_players)]
+        self.training_history = {"losses": [[] for _ in range(num_players)], "values": [[] for _ in range(num_players)],
+                                 "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}
+        self._iteration = 0
+        self._eval_calls = 0
+
+    # ---- encoders (host-facing, single state) ----------------------------------------------------------------------
+    def _estimate_input_dim(self):
+        return len(self._state_to_features(self.game.new_initial_state(), 0))
+
+    def _state_to_features(self, state, player):
+        """f32[34] = hand one-hot | table multi-hot | [player == current_player, 0] (deep_cfr.py:213-275)."""
+        f = np.zeros(34, np.float32)
+        if state.is_terminal():
+            return f
+        g = state.env.game
+        for c in g.players[player].hand:
+            f[c.id] = 1
+        for c in g.table:
+            f[16 + c.id] = 1
+        f[32] = float(player == state.current_player())
+        return f
+
+    def _get_legal_actions_mask(self, state, player):
+        mask = np.zeros(16, dtype=np.float32)
+        mask[state.legal_actions(player)] = 1.0
+        return mask
+
+    # ---- the traversal ----------------------------------------------------------------------------------------------
+    def _traverse_batch(self, player, batch, uniforms=None, advantage_fn=None):
+        """`batch` external-sampling traversals for `player` from the root; returns the root values [batch] (float32).
+        uniforms: optional {ply: float64 tensor [n]} of draws for the opponent plies (replay / tests);
+        advantage_fn(cur_player, feats, mask) -> raw advantages, default the current nets."""
+        ctx, dev = self._engine.ctx, self.device
+        mem = self.advantage_nets[player].buffer
+        with torch.cuda.stream(self._stream), torch.no_grad():
+            idx = torch.zeros(batch, dtype=torch.int32, device=dev)
+            saved = []
+            for ply in range(8):
+                n = idx.numel()
+                cur = ply & 1
+                nl = 4 - (ply >> 1)
+                feats = torch.empty((n, 34), dtype=torch.float32, device=dev)
+                mask = torch.empty((n, 16), dtype=torch.float32, device=dev)
+                ctx.sdcfr_features(ply, n, idx.data_ptr(), feats.data_ptr(), mask.data_ptr())
+                adv = (advantage_fn(cur, feats, mask) if advantage_fn else self.advantage_nets[cur].net(feats)).contiguous()
+                child = torch.empty(n * nl if cur == player else n, dtype=torch.int32, device=dev)
+                pol = torch.empty((n, 4), dtype=torch.float32, device=dev)
+                u = uniforms.get(ply) if uniforms else None
+                ctx.sdcfr_expand(ply, player, n, idx.data_ptr(), adv.data_ptr(), child.data_ptr(), pol.data_ptr(),
+                                 u.data_ptr() if u is not None else 0, self._iteration, 0)
+                saved.append((idx, pol, feats, mask))
+                idx = child
+            val = torch.empty(idx.numel(), dtype=torch.float32, device=dev)
+            ctx.sdcfr_terminal_values(player, idx.numel(), idx.data_ptr(), val.data_ptr())
+            for ply in range(7, -1, -1):
+                nidx, pol, feats, mask = saved[ply]
+                out = torch.empty(nidx.numel(), dtype=torch.float32, device=dev)
+                ctx.sdcfr_backward(ply, player, nidx.numel(), nidx.data_ptr(), pol.data_ptr(), val.data_ptr(), out.data_ptr(),
+                                   feats.data_ptr(), mask.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), mem.mask.data_ptr(),
+                                   mem.capacity, mem.write_base)
+                val = out
+            mem.advance(batch * ROWS_PER_TRAVERSAL)
+        self._stream.synchronize()
+        return val
+
+    def _external_sampling_cfr(self, state, player, depth=0, prob=1.0):
+        """One traversal from the initial state (the only way the reference calls it, deep_cfr.py:442-443)."""
+        if state.is_terminal():
+            return float(state.rewards()[player])
+        if getattr(state, "action_history", None):
+            raise NotImplementedError("_external_sampling_cfr starts at the initial state (as every reference caller does)")
+        return float(self._traverse_batch(player, 1)[0].item())
+
+    # ---- evaluation ----------------------------------------------------------------------------------------------------
+    def get_policy(self, state, player):
+        return self.strategy_buffers[player].get_average_policy(self._state_to_features(state, player),
+                                                                self._get_legal_actions_mask(state, player))
+
+    def evaluate_vs_random(self, num_episodes=100):
+        """Average policy vs uniform random, seats swapped at half time (deep_cfr.py:367-429); all episodes advance in
+        lockstep on the device (k_eval_step on packed states); the trained seat's policy is one batched forward per ply."""
+        ctx, dev = self._engine.ctx, self.device
+        n = int(num_episodes)
+        self._eval_calls += 1
+        with torch.cuda.stream(self._stream), torch.no_grad():
+            states = torch.zeros((n, 4), dtype=torch.int32, device=dev)  # 16-byte packed states
+            ctx.eval_init_states(states.data_ptr(), n)
+            seat = torch.tensor([0 if e < n / 2 else 1 for e in range(n)], dtype=torch.int32, device=dev)
+            feats = torch.empty((n, 34), dtype=torch.float32, device=dev)
+            mask = torch.empty((n, 16), dtype=torch.float32, device=dev)
+            for ply in range(8):
+                ctx.features_from_states(states.data_ptr(), n, feats.data_ptr(), mask.data_ptr())
+                probs = self.strategy_buffers[ply & 1].average_policy_batch(feats, mask).contiguous()
+                ctx.eval_step(states.data_ptr(), n, probs.data_ptr(), seat.data_ptr(), 8, (self._eval_calls << 4) | ply)
+            raw = states.cpu().numpy().view(_lib.STATE_DTYPE).reshape(-1)
+        self._stream.synchronize()
+        seat_h = np.array([0 if e < n / 2 else 1 for e in range(n)])
+        r = raw["ncap"].astype(np.int64) + 2 * raw["scopas"].astype(np.int64)
+        total = r.sum(1)
+        rewards = np.where(total[:, None] == 0, 0.0, r - total[:, None] / 2.0)   # evaluate_game (mini_scopa_game.py:106-114)
+        ar = np.arange(n)
+        avg_reward = float(rewards[ar, seat_h].mean()) if n else 0.0
+        trained = float(raw["scopas"][ar, seat_h].mean()) if n else 0.0
+        rnd = float(raw["scopas"][ar, 1 - seat_h].mean()) if n else 0.0
+        self.training_history["eval_rewards"].append(avg_reward)
+        self.training_history["eval_scopas"].append([trained, rnd])
+        return avg_reward, [trained, rnd]
+
+    # ---- training loop (deep_cfr.py:431-495) -------------------------------------------------------------------------
+    def train(self, iterations=100, advantage_epochs=10, eval_freq=5, verbose=False):
+        for iteration in range(iterations):
+            iteration_losses, iteration_values = [], []
+            for player in range(self.num_players):
+                vals = self._traverse_batch(player, self.batch)
+                value = float(vals.mean().item())
+                with torch.cuda.stream(self._stream):
+                    loss = self.advantage_nets[player].train(epochs=advantage_epochs)
+                self._stream.synchronize()
+                iteration_losses.append(loss)
+                iteration_values.append(value)
+                self.training_history["losses"][player].append(loss)
+                self.training_history["values"][player].append(value)
+                self.training_history["buffer_sizes"][player].append(len(self.advantage_nets[player].buffer))
+            if iteration > 0:
+                for player in range(self.num_players):
+                    snap = FlexibleNet(mode="mlp", input_shape=(self.input_dim,), output_dim=16, mlp_hidden=HIDDEN,
+                                       mlp_act="relu", mlp_norm="none").to(self.device)
+                    snap.load_state_dict(self.advantage_nets[player].net.state_dict())
+                    self.strategy_buffers[player].add_strategy(snap, iteration)
+            if iteration % eval_freq == 0:
+                eval_reward, eval_scopas = self.evaluate_vs_random(num_episodes=50)
+                if verbose:
+                    print(f"iter {iteration}: P0 loss {iteration_losses[0]:.4f} P1 loss {iteration_losses[1]:.4f} "
+                          f"eval vs random {eval_reward:.3f} scopas {eval_scopas[0]:.2f}/{eval_scopas[1]:.2f}")
+            self._iteration += 1
+
+    def plot_training_progress(self, path="deep_cfr_training.png"):
+        try:
+            import matplotlib
+            matplotlib.use("Agg")
+            import matplotlib.pyplot as plt
+        except ImportError:
+            return
+        fig, axes = plt.subplots(2, 2, figsize=(16, 12))
+        for p in range(self.num_players):
+            axes[0][0].plot(self.training_history["losses"][p], label=f"Player {p}")
+            axes[0][1].plot(self.training_history["values"][p], label=f"Player {p}")
+            axes[1][0].plot(self.training_history["buffer_sizes"][p], label=f"Player {p}")
+        axes[0][0].set_title("Advantage Network Loss"); axes[0][1].set_title("Traversal value"); axes[1][0].set_title("Memory rows")
+        axes[1][1].plot(self.training_history["eval_rewards"]); axes[1][1].set_title("Eval reward vs random")
+        for a in axes.flat:
+            a.grid(True)
+        fig.savefig(path, dpi=120)
+
+
+if __name__ == "__main__":
+    from scopa_amd.envs import load_game
+    d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda")
+    d.train(iterations=10, advantage_epochs=5, eval_freq=5, verbose=True)
+    print(d.evaluate_vs_random(100))

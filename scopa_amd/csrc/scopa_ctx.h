@@ -53,6 +53,7 @@ struct scopa_ctx {
     unsigned long long *d_counters = nullptr;  // [0] decision visits, [1] terminal visits, [2] aux
 
     uint64_t seed = 0x5C09A;
+    uint64_t sdcfr_visits = 0;  // decision-node visits of SDCFR traversals (one per frontier slot featurised)
     uint32_t iteration = 0;
 
     // profiling of the dominant kernel

@@ -1,0 +1,292 @@
+// scopa_sdcfr.hip -- external-sampling traversal for Single Deep CFR, level-synchronous over the 8 plies.
+//
+// Reference behaviour: DeepCFR._external_sampling_cfr / ._state_to_features / ._get_legal_actions_mask
+// (src/algorithms/deep_cfr/deep_cfr.py:213-365), AdvantageNetwork.add_experience (:70-75),
+// positive_regret_policy (src/algorithms/deep_cfr/nets.py:93-101).  The reference walks ONE traversal depth-first
+// and runs a batch-1 MLP forward per node (its whole traversal time).  Here B traversals advance together: per ply
+//   k_sdcfr_features : frontier nodes -> feats[N][34], mask[N][16]            (then ONE batched MLP forward in PyTorch)
+//   k_sdcfr_expand   : advantages -> regret-matching policy; traverser ply: all legal children,
+//                      opponent ply: one sampled child
+// and after the last ply the values flow back up with k_sdcfr_backward, which also emits the advantage-memory rows
+// (features, max-abs-normalised regrets incl. the reference's "-value at illegal slots" quirk, mask) straight into
+// the caller's ring buffers in the reference's append order (DFS post-order within a traversal).
+// A traversal's frontier is regular: widths 1,4,4,12,12,24,24,24,24 (traverser 0) / 1,1,4,4,12,12,24,24,24
+// (traverser 1); slot s of ply d has children s*n+k (traverser ply) or s (opponent ply).  All arithmetic is float32
+// in the reference's operation order (NEP-50 scalar rules make `value` float32 there).
+#include "scopa_ctx.h"
+#include "scopa_philox.h"
+
+using namespace scopa;
+
+namespace {
+
+__host__ __device__ __forceinline__ int frontier_width(int traverser, int ply) {
+    int w = 1;
+    for (int d = 0; d < ply; d++)
+        if ((d & 1) == traverser) w *= nlegal_at(d);
+    return w;
+}
+
+}  // namespace
+
+// ---- features + mask (deep_cfr.py:213-282) ------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sdcfr_features(const scopa_state *__restrict__ g_states, int ply, long long n, const int32_t *__restrict__ idx,
+                 float *__restrict__ feats, float *__restrict__ mask) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const scopa_state s = idx ? g_states[level_offset(ply) + idx[i]] : g_states[i];  // tree node, or a free-standing state
+    const int p = s.step & 1;                                                           // == ply & 1 on the tree
+    uint32_t hand_bits = 0, table_bits = 0;
+    for (int k = 0; k < s.nh[p]; k++) hand_bits |= 1u << nib(s.hand[p], k);
+    for (int k = 0; k < s.nt; k++) table_bits |= 1u << nib(s.table, k);
+    float *f = feats + i * 34;
+    float *m = mask + i * 16;
+    for (int c = 0; c < 16; c++) {
+        const float h = (float)((hand_bits >> c) & 1u);
+        f[c] = h;                                   // hand one-hot by card id (order-free)
+        f[16 + c] = (float)((table_bits >> c) & 1u);  // table multi-hot
+        m[c] = h;                                   // legal actions = cards in hand (openspiel_mini_scopa.py:22-47)
+    }
+    f[32] = 1.0f;  // float(player == state.current_player()): features are always taken for the player to move
+    f[33] = 0.0f;
+}
+
+// ---- policy + expansion (deep_cfr.py:315-365) --------------------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sdcfr_expand(const scopa_state *__restrict__ g_states, int ply, int traverser, long long n, const int32_t *__restrict__ idx,
+               const float *__restrict__ adv, int32_t *__restrict__ child_idx, float *__restrict__ pol,
+               const double *__restrict__ uniforms, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, int width) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const scopa_state s = g_states[level_offset(ply) + idx[i]];
+    const int p = ply & 1, nl = s.nh[p];  // == nlegal_at(ply) on the tree
+    // positive_regret_policy (nets.py:93-101) on advantages*mask - 1e6*(1-mask): relu kills the illegal slots
+    float pos[4], z = 0.0f;
+    {
+        uint32_t hand_bits = 0;
+        for (int k = 0; k < nl; k++) hand_bits |= 1u << nib(s.hand[p], k);
+        for (int c = 0; c < 16; c++) {  // sum over all 16 outputs in index order
+            const float a = adv[i * 16 + c];
+            z += ((hand_bits >> c) & 1u) ? (a > 0.0f ? a : 0.0f) : 0.0f;
+        }
+    }
+    const float zc = z > 1e-8f ? z : 1e-8f;  // clamp_min(eps)
+    for (int k = 0; k < 4; k++) {
+        float v = 0.0f;
+        if (k < nl) { const float a = adv[i * 16 + nib(s.hand[p], k)]; v = (a > 0.0f ? a : 0.0f) / zc; }
+        pos[k] = v;
+        pol[i * 4 + k] = v;
+    }
+    if (p == traverser) {  // recurse on ALL legal actions, hand order (:326-336)
+        for (int k = 0; k < nl; k++) child_idx[i * nl + k] = idx[i] * nl + k;
+        return;
+    }
+    // opponent: sample ONE action (:347-365)
+    float sum = pos[0];
+    for (int k = 1; k < nl; k++) sum += pos[k];  // action_probs.sum(), float32, left to right
+    double u;
+    if (uniforms) u = uniforms[i];
+    else {
+        const uint32_t b = b0 + (uint32_t)(i / width), slot = (uint32_t)(i % width);
+        const philox_out x = philox4x32_10(slot + 1024u * (uint32_t)ply, b, iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
+        u = u53(x.x0, x.x1);
+    }
+    int a;
+    if (sum == 0.0f) {  // np.random.choice(legal_actions): uniform
+        a = (int)(u * (double)nl);
+        a = a < nl - 1 ? a : nl - 1;
+    } else {  // np.random.choice(legal, p=action_probs / sum): float32 p, float64 cdf
+        double c = 0.0, cdf[4];
+        for (int k = 0; k < nl; k++) { const double pk = (double)(pos[k] / sum); c = k ? c + pk : pk; cdf[k] = c; }
+        const double last = cdf[nl - 1];
+        a = 0;
+        for (int k = 0; k < nl; k++) if (cdf[k] / last <= u) a = k + 1;
+        a = a < nl - 1 ? a : nl - 1;
+    }
+    child_idx[i] = idx[i] * nl + a;
+}
+
+// ---- terminal values: float(rewards[player]) (:286-293) -----------------------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sdcfr_terminal(const int8_t *__restrict__ g_payoff, int traverser, long long n, const int32_t *__restrict__ idx, float *__restrict__ val) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p0 = g_payoff[idx[i]];
+    val[i] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
+}
+
+// ---- backward: node values and advantage-memory rows (:321-346, :70-75) ----------------------------------------------------
+__global__ void __launch_bounds__(256)
+k_sdcfr_backward(const scopa_state *__restrict__ g_states, int ply, int traverser, long long n, const int32_t *__restrict__ idx,
+                 const float *__restrict__ pol, const float *__restrict__ child_val, float *__restrict__ val,
+                 const float *__restrict__ feats, const float *__restrict__ mask, float *__restrict__ mem_feat,
+                 float *__restrict__ mem_regret, float *__restrict__ mem_mask, long long capacity, long long write_base, int width) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int p = ply & 1;
+    if (p != traverser) { val[i] = child_val[i]; return; }  // the sampled child's value is returned unchanged (:363-365)
+    const scopa_state s = g_states[level_offset(ply) + idx[i]];
+    const int nl = s.nh[p];
+    float value = 0.0f, cfv[16];
+    for (int c = 0; c < 16; c++) cfv[c] = 0.0f;  // counterfactual_values = zeros(16) (:324)
+    for (int k = 0; k < nl; k++) {
+        const float av = child_val[i * nl + k];
+        value += pol[i * 4 + k] * av;            // value += policy[action] * action_value, float32 (:335)
+        cfv[nib(s.hand[p], k)] = av;
+    }
+    val[i] = value;
+    float mx = 0.0f, reg[16];
+    for (int c = 0; c < 16; c++) { reg[c] = cfv[c] - value; const float a = fabsf(reg[c]); mx = a > mx ? a : mx; }  // illegal slots = -value
+    if (mx > 0.0f) { const float den = mx + 1e-8f; for (int c = 0; c < 16; c++) reg[c] = reg[c] / den; }        // add_experience (:73-74)
+    // ring position: the reference appends in DFS post-order; rank of this traverser node within its traversal
+    const int m = (ply - traverser) >> 1;      // 0..3: which traverser ply
+    const long long b = i / width;
+    int j = (int)(i % width);
+    const int T[4] = {41, 10, 3, 1};           // traverser nodes in the subtree of a traverser node of ply index m
+    int rank = T[m] - 1;
+    for (int q = m - 1; q >= 0; q--) {         // digits of j, radices 4,3,2 for q = 0,1,2
+        const int radix = 4 - q;
+        rank += (j % radix) * T[q + 1];
+        j /= radix;
+    }
+    long long row = (write_base + b * 41 + rank) % capacity;
+    for (int c = 0; c < 34; c++) mem_feat[row * 34 + c] = feats[i * 34 + c];
+    for (int c = 0; c < 16; c++) { mem_regret[row * 16 + c] = reg[c]; mem_mask[row * 16 + c] = mask[i * 16 + c]; }
+}
+
+// ---- batched play vs a uniform-random opponent: states advance with the same device step as everything else -------------
+// (evaluate_vs_random, deep_cfr.py:367-429).  probs[N][16]: the trained seat's policy at the lanes where it
+// moves (ignored elsewhere); one lane per episode.
+__global__ void __launch_bounds__(256)
+k_eval_step(scopa_state *__restrict__ states, long long n, const float *__restrict__ probs, const int32_t *__restrict__ trained_seat,
+            uint32_t seed_lo, uint32_t seed_hi, uint32_t stream, uint32_t ply_tag) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    scopa_state s = states[i];
+    if (is_terminal(s)) return;
+    const int p = s.step & 1, nl = s.nh[p];
+    const philox_out x = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), ply_tag, stream, seed_lo, seed_hi);
+    const double u = u53(x.x0, x.x1);
+    int k;
+    double w[4], tot = 0.0;
+    for (int q = 0; q < nl; q++) { w[q] = (p == trained_seat[i] && probs) ? (double)probs[i * 16 + nib(s.hand[p], q)] : 1.0; if (!(w[q] > 0.0)) w[q] = 0.0; tot += w[q]; }
+    if (!(tot > 0.0)) { for (int q = 0; q < nl; q++) w[q] = 1.0; tot = (double)nl; }  // nan / non-positive -> uniform (:394-395)
+    double c = 0.0;
+    k = nl - 1;
+    for (int q = 0; q < nl; q++) { c += w[q] / tot; if (u < c) { k = q; break; } }
+    step(s, nib(s.hand[p], k));
+    states[i] = s;
+}
+
+extern "C" {
+
+int32_t scopa_sdcfr_frontier_width(int32_t traverser, int32_t ply) {
+    if (traverser < 0 || traverser > 1 || ply < 0 || ply > kPlies) return SCOPA_EINVAL;
+    return frontier_width(traverser, ply);
+}
+
+#define SC_GRID(n) dim3((unsigned)(((n) + 255) / 256)), dim3(256), 0, ctx->stream
+
+int32_t scopa_sdcfr_features(scopa_ctx *ctx, int32_t ply, int64_t n, const int32_t *d_idx, float *d_feats, float *d_mask) {
+    if (!ctx || ply < 0 || ply >= kPlies || n < 0 || (n && (!d_idx || !d_feats || !d_mask))) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_features: no deal set");
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sdcfr_features, SC_GRID(n), ctx->d_states, (int)ply, (long long)n, d_idx, d_feats, d_mask);
+    SC_HIP(ctx, hipGetLastError());
+    ctx->sdcfr_visits += (uint64_t)n;
+    return SCOPA_OK;
+}
+
+int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask) {
+    /* DeepCFR.get_policy's encoder (deep_cfr.py:497-504) on arbitrary (non-terminal) states, e.g. evaluation episodes */
+    if (!ctx || n < 0 || (n && (!d_states || !d_feats || !d_mask))) return SCOPA_EINVAL;
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sdcfr_features, SC_GRID(n), d_states, 0, (long long)n, (const int32_t *)nullptr, d_feats, d_mask);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+int32_t scopa_sdcfr_visits(scopa_ctx *ctx, uint64_t *decision_visits) {
+    if (!ctx || !decision_visits) return SCOPA_EINVAL;
+    *decision_visits = ctx->sdcfr_visits;
+    return SCOPA_OK;
+}
+
+int32_t scopa_sdcfr_expand(scopa_ctx *ctx, int32_t ply, int32_t traverser, int64_t n, const int32_t *d_idx, const float *d_adv,
+                           int32_t *d_child_idx, float *d_pol, const double *d_uniforms, uint32_t iteration, uint32_t b0) {
+    if (!ctx || ply < 0 || ply >= kPlies || traverser < 0 || traverser > 1 || n < 0 || (n && (!d_idx || !d_adv || !d_child_idx || !d_pol)))
+        return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_expand: no deal set");
+    const int width = frontier_width(traverser, ply);
+    SC_REQUIRE(ctx, n % width == 0, SCOPA_EINVAL, "scopa_sdcfr_expand: n is not a multiple of the ply's frontier width");
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sdcfr_expand, SC_GRID(n), ctx->d_states, (int)ply, (int)traverser, (long long)n, d_idx, d_adv, d_child_idx,
+                       d_pol, d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0, width);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+int32_t scopa_sdcfr_terminal_values(scopa_ctx *ctx, int32_t traverser, int64_t n, const int32_t *d_idx, float *d_val) {
+    if (!ctx || traverser < 0 || traverser > 1 || n < 0 || (n && (!d_idx || !d_val))) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_terminal_values: no deal set");
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sdcfr_terminal, SC_GRID(n), ctx->d_payoff, (int)traverser, (long long)n, d_idx, d_val);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+int32_t scopa_sdcfr_backward(scopa_ctx *ctx, int32_t ply, int32_t traverser, int64_t n, const int32_t *d_idx, const float *d_pol,
+                             const float *d_child_val, float *d_val, const float *d_feats, const float *d_mask, float *d_mem_feat,
+                             float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base) {
+    if (!ctx || ply < 0 || ply >= kPlies || traverser < 0 || traverser > 1 || n < 0 || (n && (!d_idx || !d_pol || !d_child_val || !d_val)))
+        return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_backward: no deal set");
+    const bool trav_ply = (ply & 1) == traverser;
+    if (trav_ply && n)
+        SC_REQUIRE(ctx, d_feats && d_mask && d_mem_feat && d_mem_regret && d_mem_mask && capacity >= 41 && write_base >= 0, SCOPA_EINVAL,
+                   "scopa_sdcfr_backward: memory buffers required at a traverser ply");
+    const int width = frontier_width(traverser, ply);
+    SC_REQUIRE(ctx, n % width == 0, SCOPA_EINVAL, "scopa_sdcfr_backward: n is not a multiple of the ply's frontier width");
+    if (trav_ply) SC_REQUIRE(ctx, (n / width) * 41 <= capacity, SCOPA_EINVAL, "scopa_sdcfr_backward: batch larger than the memory ring");
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sdcfr_backward, SC_GRID(n), ctx->d_states, (int)ply, (int)traverser, (long long)n, d_idx, d_pol, d_child_val, d_val,
+                       d_feats, d_mask, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, width);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+int32_t scopa_eval_init_states(scopa_ctx *ctx, scopa_state *d_states, int64_t n) {
+    if (!ctx || n < 0 || (n && !d_states)) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_eval_init_states: no deal set");
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    // every episode starts from the context's deal: broadcast the root state (d_states[0] of the tree)
+    scopa_state root;
+    state_init(root, ctx->perm);
+    std::vector<scopa_state> h((size_t)(n < 65536 ? n : 65536), root);
+    for (int64_t off = 0; off < n; off += (int64_t)h.size()) {
+        const size_t cnt = (size_t)((n - off) < (int64_t)h.size() ? (n - off) : (int64_t)h.size());
+        SC_HIP(ctx, hipMemcpyAsync(d_states + off, h.data(), cnt * sizeof(scopa_state), hipMemcpyHostToDevice, ctx->stream));
+    }
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const float *d_probs, const int32_t *d_trained_seat,
+                        uint32_t stream_id, uint32_t ply_tag) {
+    if (!ctx || n < 0 || (n && (!d_states || !d_trained_seat))) return SCOPA_EINVAL;
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_eval_step, SC_GRID(n), d_states, (long long)n, d_probs, d_trained_seat, (uint32_t)ctx->seed,
+                       (uint32_t)(ctx->seed >> 32), stream_id, ply_tag);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+}  // extern "C"

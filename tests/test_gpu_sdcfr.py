@@ -1,0 +1,174 @@
+"""GPU tests of the SDCFR path against tests/golden/sdcfr.npz (produced by running the reference's DeepCFR).
+
+Integer-valued outputs (features, masks, which rows are produced, their order) must match exactly; float32 values
+within 2e-5 (the MLP forward runs through rocBLAS here and through CPU BLAS in the reference)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ATOL = 2e-5
+
+
+@pytest.fixture()
+def dcfr(ctx, golden):
+    import torch
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    g = golden.npz("sdcfr.npz")
+    torch.manual_seed(0)
+    d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0")
+    for p in range(2):
+        sd = {str(k): torch.from_numpy(g[f"net{p}__{k}"]).to("cuda:0") for k in g[f"net{p}_names"]}
+        d.advantage_nets[p].net.load_state_dict(sd)
+    return d, g
+
+
+def _opponent_draw_order(trav):
+    """(ply, slot) of every opponent visit in the reference's DFS order (one np.random.choice each)."""
+    order = []
+
+    def rec(ply, slot):
+        if ply == 8:
+            return
+        n = 4 - (ply >> 1)
+        if (ply & 1) == trav:
+            for k in range(n):
+                rec(ply + 1, slot * n + k)
+        else:
+            order.append((ply, slot))
+            rec(ply + 1, slot)
+    rec(0, 0)
+    return order
+
+
+def test_constants_and_host_encoders(dcfr):
+    d, g = dcfr
+    assert d.input_dim == 34 == int(g["input_dim"][0])
+    assert sum(p.numel() for p in d.advantage_nets[0].net.parameters()) == 13776
+    s = d.game.new_initial_state()
+    k = 0
+    while not s.is_terminal():
+        for pl in (0, 1):
+            assert np.array_equal(d._state_to_features(s, pl), g["feat_line"][k]), (k, pl)
+            assert np.array_equal(d._get_legal_actions_mask(s, pl), g["mask_line"][k])
+            k += 1
+        s.apply_action(s.legal_actions()[0])
+    root = d._state_to_features(d.game.new_initial_state(), 0)
+    assert list(np.nonzero(root)[0]) == [5, 6, 7, 9, 32]   # SURVEY §4 KAT
+
+
+@pytest.mark.parametrize("trav", [0, 1])
+def test_traversal_replay_matches_reference(dcfr, trav):
+    import torch
+    d, g = dcfr
+    order = _opponent_draw_order(trav)
+    u = np.random.RandomState(100 + trav).random_sample(len(order))
+    assert len(order) == len(g[f"trav{trav}_draw_action"])
+    uni = {}
+    for ply in range(8):
+        if (ply & 1) != trav:
+            width = max(s for p, s in order if p == ply) + 1
+            arr = np.zeros(width)
+            for k, (p, s) in enumerate(order):
+                if p == ply:
+                    arr[s] = u[k]
+            uni[ply] = torch.from_numpy(arr).to("cuda:0")
+    seen = []
+
+    def adv_fn(cur, feats, mask):
+        seen.append((cur, feats.cpu().numpy().copy(), mask.cpu().numpy().copy()))
+        return d.advantage_nets[cur].net(feats)
+
+    v0 = d._engine.ctx.sdcfr_visits()
+    val = d._traverse_batch(trav, 1, uniforms=uni, advantage_fn=adv_fn)
+    assert d._engine.ctx.sdcfr_visits() - v0 == (105, 82)[trav]
+    assert abs(float(val[0]) - float(g[f"trav{trav}_value"][0])) < ATOL
+    # every node the reference visited was featurised identically (as multisets per ply: DFS vs level order)
+    ref_f = g[f"trav{trav}_visit_feat"]
+    mine = np.concatenate([f for _, f, _ in seen])
+    assert mine.shape == ref_f.shape
+    assert sorted(map(bytes, mine)) == sorted(map(bytes, ref_f))
+    # the 41 memory rows, in the reference's append order
+    mem = d.advantage_nets[trav].buffer
+    assert len(mem) == 41
+    f, r, m = mem.rows(torch.arange(41, device="cuda:0"))
+    assert np.array_equal(f.cpu().numpy(), g[f"trav{trav}_row_feat"])
+    assert np.array_equal(m.cpu().numpy(), g[f"trav{trav}_row_mask"])
+    np.testing.assert_allclose(r.cpu().numpy(), g[f"trav{trav}_row_regret"], atol=ATOL, rtol=0)
+
+
+def test_advantage_train_step_matches_reference(dcfr):
+    import torch
+    d, g = dcfr
+    # put the reference's 41 rows into player 0's memory, then the same two Adam steps on the same 32-row samples
+    mem = d.advantage_nets[0].buffer
+    mem.feat[:41] = torch.from_numpy(g["trav0_row_feat"]).cuda()
+    mem.regret[:41] = torch.from_numpy(g["trav0_row_regret"]).cuda()
+    mem.mask[:41] = torch.from_numpy(g["trav0_row_mask"]).cuda()
+    mem.advance(41)
+    assert int(g["train_buffer_len"][0]) == 41
+    loss = d.advantage_nets[0].train(epochs=2)
+    assert abs(loss - float(g["train_loss_p0_epochs2"][0])) < 1e-5
+    for k, v in d.advantage_nets[0].net.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), g[f"net0_after__{k}"], atol=2e-5, rtol=0)
+
+
+def test_get_policy_matches_reference(dcfr):
+    import torch
+    from scopa_amd.algorithms.deep_cfr import FlexibleNet
+    d, g = dcfr
+    for p in range(2):
+        snap = FlexibleNet(mode="mlp", input_shape=(34,), output_dim=16, mlp_hidden=[128, 64]).to("cuda:0")
+        snap.load_state_dict(d.advantage_nets[p].net.state_dict())
+        d.strategy_buffers[p].add_strategy(snap, 1)
+    s = d.game.new_initial_state()
+    k = 0
+    while not s.is_terminal():
+        np.testing.assert_allclose(d.get_policy(s, s.current_player()), g["policy_line"][k], atol=ATOL, rtol=0)
+        s.apply_action(s.legal_actions()[0])
+        k += 1
+
+
+def test_batched_traversal_invariants(dcfr):
+    import torch
+    d, _ = dcfr
+    B = 512
+    vals = d._traverse_batch(0, B)
+    assert vals.shape == (B,) and float(vals.abs().max()) <= 4.0
+    mem = d.advantage_nets[0].buffer
+    assert len(mem) == B * 41
+    f, r, m = mem.rows(torch.arange(B * 41, device="cuda:0"))
+    f, r, m = f.cpu().numpy(), r.cpu().numpy(), m.cpu().numpy()
+    assert np.array_equal(f[:, :16], m) and (f[:, 32] == 1).all() and (f[:, 33] == 0).all()
+    nl = m.sum(1).reshape(B, 41)
+    assert np.array_equal(np.sort(nl, axis=1), np.tile(np.sort([4] + [3] * 4 + [2] * 12 + [1] * 24), (B, 1)))
+    assert (nl[:, -1] == 4).all()                          # post-order: the root's row is a traversal's last
+    assert np.abs(r).max() <= 1.0 + 1e-6
+    mx = np.abs(r).max(1)
+    assert ((np.abs(mx - 1.0) < 1e-6) | (mx == 0)).all()   # max-abs normalisation
+    # different traversals sample different opponent actions (Philox keyed by traversal id)
+    assert len({bytes(x) for x in f.reshape(B, 41, 34)[:, 0]}) > 1
+
+
+def test_train_loop_and_history(ctx):
+    import torch
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    torch.manual_seed(1)
+    d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=8)
+    d.train(iterations=3, advantage_epochs=2, eval_freq=1)
+    h = d.training_history
+    assert set(h) == {"losses", "values", "buffer_sizes", "eval_rewards", "eval_scopas"}
+    assert h["buffer_sizes"][0] == [328, 656, 984] and len(h["losses"][1]) == 3 and len(h["eval_rewards"]) == 3
+    assert len(d.strategy_buffers[0].strategies) == 2 and d.strategy_buffers[0].weights == [2, 3]
+    reward, scopas = d.evaluate_vs_random(200)
+    assert -4 <= reward <= 4 and len(scopas) == 2
+
+
+def test_evaluate_vs_random_uniform_is_zero_mean(ctx):
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0")
+    reward, scopas = d.evaluate_vs_random(40000)   # no snapshots: uniform vs uniform, seats swapped at half time
+    assert abs(reward) < 0.06                       # +-0.92 per seat cancels; sigma/sqrt(n) ~ 0.01
+    assert abs(scopas[0] - scopas[1]) < 0.03
