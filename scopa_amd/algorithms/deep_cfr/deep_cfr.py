@@ -58,7 +58,7 @@ class DeviceMemory:
 class AdvantageNetwork:
     """Advantage net + Adam + memory for one player (deep_cfr.py:24-116)."""
 
-    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4):
+    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4, memory_size=100000):
         self.device = device
         self.num_actions = num_actions
         self.net = FlexibleNet(mode="mlp", input_shape=(input_dim,), output_dim=num_actions, mlp_hidden=HIDDEN,
@@ -69,8 +69,9 @@ class AdvantageNetwork:
                 nn.init.constant_(layer.bias, 0.1)
         self.optimizer = optim.Adam(self.net.parameters(), lr=lr)
         self.criterion = nn.MSELoss()
-        self.buffer = DeviceMemory(100000, input_dim, device)
+        self.buffer = DeviceMemory(memory_size, input_dim, device)
         self._rng = random.Random()
+        self.grad_sync = None  # set by DeepCFR for N>1: callable(parameters) averaging the gradients over ranks
 
     def get_advantages(self, state_features, legal_actions_mask):
         with torch.no_grad():
@@ -103,6 +104,8 @@ class AdvantageNetwork:
             pred_adv = self.net(states)
             loss = self.criterion(pred_adv * masks, target_adv * masks)
             loss.backward()
+            if self.grad_sync is not None:
+                self.grad_sync(self.net.parameters())
             torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm=1.0)
             self.optimizer.step()
             total_loss += loss.item()
@@ -154,7 +157,11 @@ class RandomPolicy:
 class DeepCFR:
     """`DeepCFR(game, num_players=2, device="cuda").train(iterations, advantage_epochs, eval_freq)`."""
 
-    def __init__(self, game, num_players=2, device="cuda", batch=1, seed=0x5C09A, stream=None):
+    def __init__(self, game, num_players=2, device="cuda", batch=1, seed=0x5C09A, stream=None, rank=0, world=1,
+                 memory_size=None):
+        """rank/world: data parallelism over torch.distributed (one process per GPU).  Each rank traverses `batch`
+        traversals with global ids [rank*batch, (rank+1)*batch) into its own memory ring and the advantage-net
+        gradients are averaged with one all-reduce per optimiser step (55 104 B), so every replica's nets stay equal."""
         if not str(device).startswith("cuda"):
             raise ValueError("the SDCFR traversal runs on the GPU (HIP kernels): device must be a cuda device")
         self.game = game
@@ -168,12 +175,34 @@ class DeepCFR:
         self.input_dim = self._estimate_input_dim()
         print(f"Estimated input dimension: {self.input_dim}")
         with torch.cuda.stream(self._stream):
-            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device) for _ in range(num_players)]
+            # the reference keeps 100 000 rows (~2 400 traversals); a batch of B traversals appends 41*B rows at once,
+            # so large batches get a ring of >= 8 iterations' worth (FIFO semantics unchanged)
+            if memory_size is None:
+                memory_size = max(100000, 8 * ROWS_PER_TRAVERSAL * self.batch)
+            if memory_size < ROWS_PER_TRAVERSAL * self.batch:
+                raise ValueError("memory_size must hold at least one batch of traversals (41 rows each)")
+            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device, memory_size=memory_size) for _ in range(num_players)]
         self.strategy_buffers = [StrategyBuffer() for _ in range(num_players)]
         self.training_history = {"losses": [[] for _ in range(num_players)], "values": [[] for _ in range(num_players)],
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}
         self._iteration = 0
         self._eval_calls = 0
+        self.rank, self.world = int(rank), int(world)
+        if self.world > 1:
+            import torch.distributed as dist
+            from ...distributed import allreduce_gradients, broadcast_parameters
+
+            def _ar(t):
+                with torch.cuda.stream(self._stream):
+                    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+
+            def _bc(t):
+                with torch.cuda.stream(self._stream):
+                    dist.broadcast(t, src=0)
+
+            for a in self.advantage_nets:
+                broadcast_parameters(a.net, _bc)
+                a.grad_sync = lambda params: allreduce_gradients(params, self.world, _ar)
 
     # ---- encoders (host-facing, single state) ----------------------------------------------------------------------
     def _estimate_input_dim(self):
@@ -219,7 +248,7 @@ class DeepCFR:
                 pol = torch.empty((n, 4), dtype=torch.float32, device=dev)
                 u = uniforms.get(ply) if uniforms else None
                 ctx.sdcfr_expand(ply, player, n, idx.data_ptr(), adv.data_ptr(), child.data_ptr(), pol.data_ptr(),
-                                 u.data_ptr() if u is not None else 0, self._iteration, 0)
+                                 u.data_ptr() if u is not None else 0, self._iteration, self.rank * batch)
                 saved.append((idx, pol, feats, mask))
                 idx = child
             val = torch.empty(idx.numel(), dtype=torch.float32, device=dev)

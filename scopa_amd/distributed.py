@@ -57,3 +57,28 @@ def make_gpu_engine(local_rank, perm16, seed, world=1):
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)
 
     return ctx, delta, stream, (all_reduce if world > 1 else (lambda: None))
+
+
+# ---- SDCFR data parallelism (BASELINE configs[4]) ---------------------------------------------------------------------
+def allreduce_gradients(parameters, world, all_reduce):
+    """Average the gradients of `parameters` over `world` ranks with ONE flat all-reduce (13 776 float32 = 55 104 B for the
+    34-128-64-16 advantage MLP): every rank then takes the identical Adam step, so the replicas' nets stay identical.
+    `all_reduce(tensor)` must sum in place across ranks (torch.distributed.all_reduce on RCCL / gloo)."""
+    import torch
+    params = [p for p in parameters if p.grad is not None]
+    if world <= 1 or not params:
+        return
+    flat = torch.cat([p.grad.reshape(-1) for p in params])
+    all_reduce(flat)
+    flat /= float(world)
+    off = 0
+    for p in params:
+        n = p.grad.numel()
+        p.grad.copy_(flat[off:off + n].view_as(p.grad))
+        off += n
+
+
+def broadcast_parameters(module, broadcast):
+    """Make rank 0's initial weights everyone's (`broadcast(tensor)` = in-place broadcast from rank 0)."""
+    for t in list(module.parameters()) + list(module.buffers()):
+        broadcast(t.data)

@@ -95,3 +95,55 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     ref.t.mccfr_batched(ref.R, ref.S, 31337, 0, iters, batch)
     np.testing.assert_allclose(single.R, ref.R, rtol=1e-12, atol=1e-12)
     np.testing.assert_allclose(single.S, ref.S, rtol=1e-12, atol=1e-12)
+
+
+# ---- SDCFR data parallelism: gradient averaging keeps replicas identical (BASELINE configs[4]) -----------------------
+def _grad_worker(rank, world, port, out):
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, ROOT)
+    from scopa_amd.distributed import allreduce_gradients, broadcast_parameters
+    from scopa_amd.algorithms.deep_cfr.nets import FlexibleNet
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(100 + rank)                       # different init per rank ...
+    net = FlexibleNet(input_shape=(34,), output_dim=16, mlp_hidden=[128, 64])
+    broadcast_parameters(net, lambda t: dist.broadcast(t, src=0))   # ... made identical
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.rand(64, 34, generator=g), torch.rand(64, 16, generator=g)   # the global batch, same on both ranks
+    lo, hi = rank * 32, rank * 32 + 32                                          # each rank owns half of it
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(X[lo:hi]), Y[lo:hi]).backward()
+        allreduce_gradients(net.parameters(), world, lambda t: dist.all_reduce(t, op=dist.ReduceOp.SUM))
+        opt.step()
+    torch.save(net.state_dict(), out.format(rank=rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_allreduce_equals_full_batch_training(tmp_path):
+    import torch
+    import torch.multiprocessing as mp
+    sys.path.insert(0, ROOT)
+    from scopa_amd.algorithms.deep_cfr.nets import FlexibleNet
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "net{rank}.pt")
+    mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+    a, b = torch.load(out.format(rank=0), weights_only=True), torch.load(out.format(rank=1), weights_only=True)
+    assert all(torch.equal(a[k], b[k]) for k in a)      # replicas identical after 3 steps
+    # and equal to single-process training on the whole batch (mean of two half-batch MSE grads = full-batch grad)
+    torch.manual_seed(100)
+    net = FlexibleNet(input_shape=(34,), output_dim=16, mlp_hidden=[128, 64])
+    opt = torch.optim.Adam(net.parameters(), lr=5e-4)
+    g = torch.Generator().manual_seed(7)
+    X, Y = torch.rand(64, 34, generator=g), torch.rand(64, 16, generator=g)
+    for _ in range(3):
+        opt.zero_grad()
+        torch.nn.functional.mse_loss(net(X), Y).backward()
+        opt.step()
+    for k, v in net.state_dict().items():
+        assert torch.allclose(v, a[k], atol=1e-6), k
