@@ -3,31 +3,37 @@
 // Reference behaviour: MCCFRTrainer._sample / .iteration (src/algorithms/mc_cfr.py:37-92).  One traversal of the
 // reference is a recursion tree: at a traverser node the sampled child is followed (:55-67) and then EVERY legal
 // action is re-expanded by a fresh sampled sub-traversal (:69-78); at an opponent node only the sampled child is
-// followed.  With the 4,4,3,3,2,2,1,1 legal profile that recursion tree always has 291 (traverser 0) / 172
-// (traverser 1) decision visits and 120 leaves: 5*4*3*2 branch combinations at the four traverser nodes of a path.
+// followed.  With the 4,4,3,3,2,2,1,1 legal profile that recursion tree is always the same shape: per ply
+// 1,5,5,20,20,60,60,120 nodes for traverser 0 and 1,1,5,5,20,20,60,60 for traverser 1 (291 / 172 decision visits,
+// 120 leaves), a node being named by the branch digits taken at the traverser plies above it (0 = the sampled child,
+// i+1 = re-expansion of action i).
 //
-// Kernel design (k_mccfr_traverse): one LANE per LEAF PATH.  A traversal is a "task" of 128 lanes (120 paths + 8
-// idle) = 2 wavefronts; lane l decodes its four branch digits (mixed radix 5,4,3,2; digit 0 = follow the sampled
-// child, digit i+1 = re-expansion of action i) and walks root -> leaf in 8 dependent steps instead of the
-// reference's 231-visit serial DFS.  Lanes that share a prefix recompute the same nodes and agree, because every
-// random draw is keyed by the PATH (Philox4x32-10, scopa_philox.h), not by visit order; the draws themselves are
-// produced once per task in a dense pass (86 / 26 Philox blocks) and staged in LDS.  Everything the walk touches
-// -- sigma and normalised-cdf rows of the frozen regret table, the node -> infoset map, leaf payoffs -- is LDS
-// resident (~93 KB for 738 infosets; one persistent 1024-thread workgroup per CU).  Regret deltas are reduced with
-// LDS float64 atomics per workgroup; each workgroup then writes its partial table as one coalesced SLAB in HBM
-// (plain stores) and k_mccfr_reduce sums the slabs in a fixed order.  (v1 flushed with global float64 atomics:
-// 256 workgroups hammering the same 29.5 KB cost ~105 us per launch, 6x the traversal itself -- measured.)
-// Strategy sums are accumulated as integer visit counts (sigma is frozen, so strategy_sum += count * sigma).
+// Kernel design (k_mccfr_traverse, v4): LEVEL-SYNCHRONOUS over the recursion tree, one lane per UNIQUE node, one
+// WAVEFRONT per traversal pair.  Ply d of a pair is one step over its 2, 6, 10, 25, 40, 80 nodes (plies 0..5), each
+// lane deriving its node from its parent's 32-byte record in LDS (index arithmetic: the game tree is regular),
+// sampling its action from the frozen sigma|cdf row and leaving its own record for the next ply.  The 16 wavefronts
+// of a workgroup run their pairs independently -- only wave-level LDS ordering between plies, no workgroup barrier
+// in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).  Random draws are Philox4x32-10 blocks keyed by the node's
+// PATH (ntl + 16*digits, global traversal id, iteration, traverser): an opponent node computes the block, uses words
+// 0,1 and hands words 2,3 to the traverser node below it -- so results do not depend on launch geometry, pass size or
+// GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
+// The update step then gives one lane per traverser node (26 per task): v as the reference's fma chain over <= 4 leaf
+// payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Everything a pair touches is LDS resident
+// (sigma|cdf rows 47 KB, delta 24 KB, 16 x 4.4 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
+// 1024-thread workgroup per CU); each workgroup finally writes its partial table as one coalesced SLAB in HBM and
+// k_mccfr_reduce sums the slabs in a fixed order.  Strategy sums are integer visit counts (sigma is frozen, so
+// strategy_sum += count * sigma).
+//
+// History (rocprofv3, B = 4096 per traverser, profiles/): v1 one lane per leaf path + global f64 atomics + one global
+// counter atomic per wavefront: 122 us (100 us of it 8192 same-address atomics); v2 slabs + per-workgroup counters +
+// traverser-specialised walk: 20-23 us, 2.8 us per 16 tasks (issue-bound at ~1.5 cycles/instruction); v3 unique
+// nodes with workgroup-wide plies: same time (latency-bound); v4 unique nodes per wavefront: see DESIGN.md.
 #include "scopa_ctx.h"
 #include "scopa_philox.h"
 
 using namespace scopa;
 
 namespace {
-
-constexpr int kTaskLanes = 128;   // 120 leaf paths, padded to two wavefronts
-constexpr int kPaths = 120;
-constexpr int kSlots = 86;        // Philox blocks per task (traverser 0); traverser 1 needs the first 26
 
 // InfoNode.current_strategy, mc_cfr.py:20-24  (np.maximum, ndarray.sum left-to-right, elementwise divide)
 __device__ __forceinline__ void mc_sigma(const double *R, int n, double *sigma) {
@@ -47,51 +53,24 @@ __device__ __forceinline__ void choice_cdf(const double *sigma, int n, double *c
     for (int i = 0; i < 4; i++) cdf[i] = i < n ? cdf[i] / last : 2.0;  // 2.0 > any u: padding never counts
 }
 
-__device__ __forceinline__ int slot_of(int ntl, uint32_t dig) {
-    const int b0 = dig & 7, b1 = (dig >> 3) & 7, b2 = (dig >> 6) & 7;
-    return ntl == 0 ? 0 : ntl == 1 ? 1 + b0 : ntl == 2 ? 6 + b0 * 4 + b1 : 26 + (b0 * 4 + b1) * 3 + b2;
+// traverser plies strictly above ply d, and nodes of ply d (d <= 6) in one task's recursion tree
+__host__ __device__ constexpr int ntl_at(int trav, int d) { return trav == 0 ? (d + 1) >> 1 : d >> 1; }
+__host__ __device__ constexpr int task_nodes(int trav, int d) {
+    return ntl_at(trav, d) == 0 ? 1 : ntl_at(trav, d) == 1 ? 5 : ntl_at(trav, d) == 2 ? 20 : 60;
 }
 
-// One leaf path of traverser TRAV: 8 plies, each { node -> infoset row (sigma[4] | cdf[4], 64 B in LDS); sampled action =
-// #{cdf <= u}; at a traverser ply the lane's branch digit may override it }.  Returns the leaf's BFS index; IX / wX
-// are the infoset and importance weight (mc_cfr.py:81-82) of the one traverser node this lane updates in phase C.
-template <int TRAV>
-__device__ __forceinline__ int walk_path(const uint16_t *__restrict__ s_inf, const double *__restrict__ s_sigcdf,
-                                         uint8_t *__restrict__ s_seen, const double2 *__restrict__ my_u, uint32_t bpack,
-                                         int kstar, int &IX, double &wX) {
-    int idx = 0;
-    uint32_t dig = 0;
-    double reach = 1.0, samp = 1.0, reachX = 0.0, sampX = 0.0;
-#pragma unroll
-    for (int d = 0; d < kPlies; d++) {
-        constexpr int dummy = 0; (void)dummy;
-        const int n = 4 - (d >> 1);
-        const bool is_trav = (d & 1) == TRAV;
-        const int ntl = TRAV == 0 ? (d + 1) >> 1 : d >> 1;  // traverser plies strictly above ply d
-        const int In = s_inf[level_offset(d) + idx];
-        s_seen[In] = 1;  // benign race: every writer stores 1
-        const double *row = s_sigcdf + In * 8;
-        int a = 0;
-        if (n > 1) {
-            const double2 uu = my_u[slot_of(ntl, dig)];
-            const double u = is_trav ? uu.y : uu.x;
-            a = (row[4] <= u) + (row[5] <= u) + (row[6] <= u) + (row[7] <= u);
-            a = a < n - 1 ? a : n - 1;
-        }
-        if (is_trav) {
-            const int dg = (int)((bpack >> (3 * ntl)) & 7u);
-            if (dg) a = dg - 1;
-            if (ntl == kstar) { IX = In; reachX = reach; sampX = samp; }
-            if (n > 1) samp *= row[a];
-            dig |= (uint32_t)dg << (3 * ntl);
-        } else if (n > 1) {
-            reach *= row[a];
-        }
-        idx = idx * n + a;
-    }
-    wX = sampX > 0.0 ? reachX / sampX : 0.0;  // weight = opp_reach / sampling_probs[player] if > 0 else 0
-    return idx;
-}
+struct NodeRec {      // 32 bytes, one per recursion-tree node of the ply being handed down
+    double reach;     // product of the opponent's sigma on the path          (reach_probs[1 - traverser])
+    double samp;      // product of the traverser's sigma on the path         (sampling_probs[traverser])
+    double u_next;    // words 2,3 of the Philox block, for the traverser node below an opponent node
+    uint16_t idx;     // BFS index of the game-tree node within its ply
+    uint16_t dig;     // branch digits so far, 3 bits per traverser ply
+    uint8_t a;        // sampled action index (np.random.choice)
+    uint8_t pad[3];
+};
+static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+
+constexpr int kUpd = 26;  // traverser nodes with > 1 legal action per task: 1 + 5 + 20
 
 }  // namespace
 
@@ -109,6 +88,92 @@ k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Per-wavefront scratch in LDS: the records of one traversal pair (2 tasks) + what the update step needs.
+struct WaveScratch {
+    NodeRec recA[40];        // even plies: <= 20 + 20 nodes
+    NodeRec recB[80];        // odd plies:  <= 60 + 20 nodes
+    double updr[2 * kUpd];   // opponent reach ...
+    double upds[2 * kUpd];   // ... and own sampling probability at every traverser node with > 1 action
+    uint16_t updI[2 * kUpd]; // ... and its infoset
+    int8_t p6[2 * 60];       // resolved leaf payoffs x2 (traverser's sign) per task
+};
+static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch must keep 16-byte alignment");
+
+// LDS traffic between lanes of ONE wavefront: DS operations of a wave execute in issue order, so only the compiler
+// has to be kept from reordering, and outstanding LDS returns drained, before other lanes' records are read.
+__device__ __forceinline__ void wave_lds_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// One ply of one traversal pair: lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's.
+template <int D>
+__device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf,
+                                                 const double *__restrict__ s_sigcdf, uint8_t *__restrict__ s_seen,
+                                                 unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration,
+                                                 uint32_t seed_lo, uint32_t seed_hi) {
+    constexpr int n = 4 - (D >> 1);
+    constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
+    NodeRec *rec_out = (D & 1) ? ws.recB : ws.recA;
+    const NodeRec *rec_in = (D & 1) ? ws.recA : ws.recB;
+    unsigned int visited = 0;
+#pragma unroll
+    for (int t0 = 0; t0 < c0 + c1; t0 += 64) {
+        const int t = t0 + lane;
+        if (t < c0 + c1) {
+            const int trav = t < c0 ? 0 : 1;
+            const int j = trav ? t - c0 : t;
+            const bool is_trav = (D & 1) == trav;
+            const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
+            int idx = 0;
+            uint32_t dig = 0;
+            double reach = 1.0, samp = 1.0, u_in = 0.0;
+            if (D > 0) {
+                constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
+                const bool p_trav = (pd & 1) == trav;
+                int pj = j, k = 0;
+                if (p_trav) { pj = j / (pn + 1); k = j - pj * (pn + 1); }
+                const NodeRec pr = rec_in[(trav ? task_nodes(0, pd) : 0) + pj];
+                const int act = (p_trav && k > 0) ? k - 1 : pr.a;
+                const double sg = s_sigcdf[s_inf[level_offset(pd) + pr.idx] * 8 + act];
+                idx = pr.idx * pn + act;
+                dig = pr.dig;
+                if (p_trav) { samp = pr.samp * sg; reach = pr.reach; dig |= (uint32_t)k << (3 * (trav == 0 ? (pd + 1) >> 1 : pd >> 1)); }
+                else        { reach = pr.reach * sg; samp = pr.samp; }
+                u_in = pr.u_next;
+            }
+            const int In = s_inf[level_offset(D) + idx];
+            s_seen[In] = 1;  // benign race: every writer stores 1
+            double u = u_in, u_next = 0.0;
+            if (!is_trav || D == 0) {  // opponent node (or traverser 0's root): this path prefix's Philox block
+                const philox_out x = philox4x32_10((uint32_t)ntl + 16u * dig, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
+                u_next = u53(x.x2, x.x3);
+                u = is_trav ? u_next : u53(x.x0, x.x1);
+            }
+            const double *row = s_sigcdf + In * 8;
+            int a = (row[4] <= u) + (row[5] <= u) + (row[6] <= u) + (row[7] <= u);
+            a = a < n - 1 ? a : n - 1;
+            if (is_trav) {  // what the update step needs (mc_cfr.py:81-82)
+                const int x = trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + j;
+                ws.updI[x] = (uint16_t)In;
+                ws.updr[x] = reach;
+                ws.upds[x] = samp;
+                atomicAdd(&s_cnt[In], 1u);
+            }
+            NodeRec out;
+            out.reach = reach; out.samp = samp; out.u_next = u_next;
+            out.idx = (uint16_t)idx; out.dig = (uint16_t)dig; out.a = (uint8_t)a;
+            out.pad[0] = out.pad[1] = out.pad[2] = 0;
+            rec_out[t] = out;
+            visited += 1;
+        }
+    }
+    wave_lds_sync();
+    return visited;
+}
+
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_slabs,
@@ -117,19 +182,17 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     const int I = n_infosets;
-    double *s_sigcdf = reinterpret_cast<double *>(smem);         // [I][8]: sigma[4] | normalised cdf[4]
-    double *s_dR = s_sigcdf + (size_t)I * 8;                     // [I][4]
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_dR + (size_t)I * 4);  // [I]
-    const int tasks_per_wg = blockDim.x / kTaskLanes;
-    double2 *s_u = reinterpret_cast<double2 *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));
-    int *s_px2 = reinterpret_cast<int *>(s_u + (size_t)tasks_per_wg * kSlots);    // [tasks][128]
-    uint16_t *s_inf = reinterpret_cast<uint16_t *>(s_px2 + (size_t)tasks_per_wg * kTaskLanes);  // [1653] (+pad)
-    int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);   // [576]
-    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);  // [I] infoset visited by any lane of this workgroup
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][8]: sigma[4] | normalised cdf[4]
+    double *s_dR = s_sigcdf + (size_t)I * 8;                                     // [I][4]
+    WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [16]
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + 16);         // [I] traverser visits
+    uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));  // [1653] (+pad)
+    int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);                    // [576]
+    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);            // [I]
 
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     if (tid < 2) s_vis[tid] = 0u;
-    // ---- prologue: freeze this iteration's strategy in LDS ----------------------------------------------------------
+    // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
     for (int i = tid; i < I * 4; i += blockDim.x) {  // 16-byte copies of the prepared rows
         reinterpret_cast<double2 *>(s_sigcdf)[i] = reinterpret_cast<const double2 *>(g_sigcdf)[i];
         s_dR[i] = 0.0;
@@ -139,67 +202,63 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
     __syncthreads();
 
-    const int task_in_wg = tid / kTaskLanes, l = tid % kTaskLanes;
-    const uint32_t n_tasks = nb * 2u;
-    const uint32_t n_groups = (n_tasks + tasks_per_wg - 1) / tasks_per_wg;
-    // static per-lane path description
-    const int d0 = l / 24, d1 = (l / 6) % 4, d2 = (l >> 1) % 3, d3 = l & 1;
-    const uint32_t bpack = (uint32_t)d0 | ((uint32_t)d1 << 3) | ((uint32_t)d2 << 6) | ((uint32_t)d3 << 9);
-    const int kstar = l >= kPaths ? -2 : d3 ? 3 : d2 ? 2 : d1 ? 1 : d0 ? 0 : -1;
+    WaveScratch &ws = s_wave[wave];
     unsigned int my_dvis = 0, my_tvis = 0;
-
-    for (uint32_t g = blockIdx.x; g < n_groups; g += gridDim.x) {
-        const uint32_t task = g * tasks_per_wg + task_in_wg;
-        const bool live = task < n_tasks;
-        const uint32_t b = b0 + (task >> 1);
-        const int trav = (int)(task & 1u);
-        double2 *my_u = s_u + (size_t)task_in_wg * kSlots;
-        int *my_px2 = s_px2 + (size_t)task_in_wg * kTaskLanes;
-
-        // ---- phase A: this task's random draws, one Philox block per (ntl, branch prefix) ------------------------
-        if (live && l < (trav == 0 ? 86 : 26)) {
-            int ntl; uint32_t dig;
-            if (l == 0) { ntl = 0; dig = 0; }
-            else if (l < 6) { ntl = 1; dig = (uint32_t)(l - 1); }
-            else if (l < 26) { ntl = 2; const int q = l - 6; dig = (uint32_t)(q / 4) | ((uint32_t)(q % 4) << 3); }
-            else { ntl = 3; const int q = l - 26; dig = (uint32_t)(q / 12) | ((uint32_t)((q / 3) % 4) << 3) | ((uint32_t)(q % 3) << 6); }
-            const philox_out x = philox4x32_10((uint32_t)ntl + 16u * dig, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
-            my_u[l] = make_double2(u53(x.x0, x.x1), u53(x.x2, x.x3));
+    // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
+    for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
+        const uint32_t b = b0 + pg;
+        // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time)
+        my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+        my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+        my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+        my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+        my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+        my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+        // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts
+        for (int t = lane; t < 2 * 60; t += 64) {
+            const int trav = t < 60 ? 0 : 1;
+            const int j = trav ? t - 60 : t;
+            // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
+            int pj = j, k = 0;
+            if (trav == 1) { pj = j / 3; k = j - pj * 3; }
+            const NodeRec pr = ws.recB[(trav ? 60 : 0) + pj];
+            const int act = (trav == 1 && k > 0) ? k - 1 : pr.a;
+            const int idx6 = pr.idx * 2 + act;                 // = index of the ply-7 node and of the leaf as well
+            const int I6 = s_inf[level_offset(6) + idx6], I7 = s_inf[level_offset(7) + idx6];
+            s_seen[I6] = 1;
+            s_seen[I7] = 1;
+            atomicAdd(&s_cnt[trav == 0 ? I6 : I7], 1u);       // the traverser's single-action node: strategy_sum += [1.0]
+            const int p0 = s_pay[idx6];
+            ws.p6[t] = (int8_t)(trav == 0 ? p0 : -p0);
+            my_dvis += trav == 0 ? 3 : 2;                       // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
+            my_tvis += 2;
         }
-        __syncthreads();
-
-        // ---- phase B: walk root -> leaf (specialised on the wave-uniform traverser: ply roles are compile-time) ---
-        int IX = 0;
-        double wX = 0.0;
-        if (live && l < kPaths) {
-            int leaf;
-            if (trav == 0) leaf = walk_path<0>(s_inf, s_sigcdf, s_seen, my_u, bpack, kstar, IX, wX);
-            else           leaf = walk_path<1>(s_inf, s_sigcdf, s_seen, my_u, bpack, kstar, IX, wX);
-            const int p0 = s_pay[leaf];
-            my_px2[l] = trav == 0 ? p0 : -p0;
-            my_tvis += 1;
-            my_dvis += kstar < 0 ? 8 : 7 - trav - 2 * kstar;
-        }
-        __syncthreads();
-
-        // ---- phase C: one (traverser node, action) regret update per lane (mc_cfr.py:79-84) ----------------------
-        if (live && kstar >= 0) {
-            const int nX = 4 - kstar;
-            const int stride = kstar == 0 ? 24 : kstar == 1 ? 6 : kstar == 2 ? 2 : 1;
-            const int dg = (int)((bpack >> (3 * kstar)) & 7u);
-            const int base = l - dg * stride;
-            double v = 0.0, mine = 0.0;
-            for (int j = 0; j < nX; j++) {
-                const double cfv = 0.5 * (double)my_px2[base + (j + 1) * stride];
-                v = fma(s_sigcdf[IX * 8 + j], cfv, v);  // np.dot on this numpy build: an fma chain (see oracle)
-                if (j == dg - 1) mine = cfv;
+        wave_lds_sync();
+        // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84)
+        if (lane < 2 * kUpd) {
+            const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
+            const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
+            const int j = x - (m == 0 ? 0 : m == 1 ? 1 : 6);
+            const int nX = 4 - m;
+            const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
+            const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
+            const int IX = ws.updI[lane];
+            const double rX = ws.updr[lane], sX = ws.upds[lane];
+            const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
+            const int8_t *p6 = ws.p6 + trav * 60;
+            double cfv[4], v = 0.0;
+            for (int i = 0; i < nX; i++) {
+                cfv[i] = 0.5 * (double)p6[base + (i + 1) * stride];
+                v = fma(s_sigcdf[IX * 8 + i], cfv[i], v);      // np.dot on this numpy build: an fma chain (see oracle)
             }
-            const double delta = wX * (mine - v);
-            if (delta != 0.0) atomicAdd(&s_dR[IX * 4 + dg - 1], delta);
-            if (dg == 1) atomicAdd(&s_cnt[IX], 1u);
+            for (int i = 0; i < nX; i++) {
+                const double delta = w * (cfv[i] - v);
+                if (delta != 0.0) atomicAdd(&s_dR[IX * 4 + i], delta);
+            }
         }
-        __syncthreads();
+        wave_lds_sync();  // the next pair overwrites this wave's scratch
     }
+    __syncthreads();
 
     // ---- epilogue: this workgroup's partial delta table -> its slab, [n_infosets][5] like the delta buffer ----------
     {
@@ -211,13 +270,12 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         uint8_t *seen = g_seen_slabs + (size_t)blockIdx.x * kDecision;
         for (int r = tid; r < I; r += blockDim.x) seen[r] = s_seen[r];
     }
-    // exact visit counters: wave reduce -> LDS -> ONE plain store per workgroup, summed by k_mccfr_reduce.  (v1 issued
-    // one global atomicAdd per wavefront: 8192 same-address atomics at ~12 ns each = the ~100 us fixed cost measured.)
+    // exact visit counters: wave reduce -> LDS -> ONE plain store per workgroup, summed by k_mccfr_reduce
     for (int off = 32; off > 0; off >>= 1) {
         my_dvis += __shfl_down(my_dvis, off);
         my_tvis += __shfl_down(my_tvis, off);
     }
-    if ((tid & 63) == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
+    if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
     __syncthreads();
     if (tid < 2) g_wg_counts[blockIdx.x * 2 + tid] = s_vis[tid];
 }
@@ -271,6 +329,94 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
         double t = part[0][cell_l];
         for (int k = 1; k < 16; k++) t += part[k][cell_l];
         g_delta[c] += t;
+    }
+}
+
+// Single-GPU fusion of k_mccfr_reduce + k_mccfr_apply: a workgroup owns 4 infoset rows = 20 contiguous cells of every
+// slab.  Thread (chunk = tid / 10, pair = tid % 10) owns two adjacent cells (one 16-byte load per slab) and the slabs
+// chunk, chunk+24, ... (<= 11 at 256 slabs); all its loads are issued before the first add.  The 24 partial sums per cell
+// are combined in chunk order through LDS, then 4 lanes apply their rows exactly as k_mccfr_apply does.
+// Deterministic: the order of every float64 sum is fixed by n_slabs, not by timing.
+namespace { constexpr int kRaRows = 4, kRaCells = kRaRows * 5, kRaPairs = kRaCells / 2, kRaChunks = 24; }
+
+__global__ void __launch_bounds__(256)
+k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_infosets,
+                     const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters,
+                     const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit, const uint64_t *__restrict__ g_key,
+                     double *__restrict__ g_regret, double *__restrict__ g_strat, double *__restrict__ g_sigcdf) {
+    __shared__ double part[kRaChunks][kRaCells];
+    __shared__ unsigned int s_any[kRaRows];
+    __shared__ unsigned long long s_tot[2];
+    const int tid = threadIdx.x, n_cells = n_infosets * 5;
+    if (tid < kRaRows) s_any[tid] = 0u;
+    if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch
+        if (tid < 2) s_tot[tid] = 0ull;
+        __syncthreads();
+        unsigned long long d = 0ull, t = 0ull;
+        for (int w = tid; w < n_slabs; w += blockDim.x) { d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1]; }
+        if (d | t) { atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t); }
+        __syncthreads();
+        if (tid < 2) g_counters[tid] += s_tot[tid];
+    }
+    __syncthreads();
+    const int row0 = blockIdx.x * kRaRows;
+    {   // infosets first seen by this launch: 4 rows x 64 lanes OR the slabs' flags
+        const int rl = tid & 3, r = row0 + rl;
+        unsigned int any = 0u;
+        if (r < n_infosets)
+            for (int w = tid >> 2; w < n_slabs; w += 64) any |= g_seen_slabs[(size_t)w * kDecision + r];
+        if (any) s_any[rl] = 1u;  // benign race
+    }
+    const int chunk = tid / kRaPairs, pr = tid - chunk * kRaPairs;
+    const int c = row0 * 5 + pr * 2;  // even: row0*5 is a multiple of 20
+    if (tid < kRaChunks * kRaPairs) {
+        double2 acc = make_double2(0.0, 0.0);
+        if (c < n_cells) {
+            const bool has2 = c + 1 < n_cells;
+            for (int base = chunk; base < n_slabs; base += kRaChunks * 12) {
+                double2 v[12];
+#pragma unroll
+                for (int q = 0; q < 12; q++) {
+                    const int sl = base + kRaChunks * q;
+                    v[q] = make_double2(0.0, 0.0);
+                    if (sl < n_slabs) {
+                        const size_t off = (size_t)sl * n_cells + c;
+                        if (has2 && (off & 1) == 0) v[q] = *reinterpret_cast<const double2 *>(g_slabs + off);
+                        else { v[q].x = g_slabs[off]; if (has2) v[q].y = g_slabs[off + 1]; }
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 12; q++) { acc.x += v[q].x; acc.y += v[q].y; }
+            }
+        }
+        part[chunk][pr * 2] = acc.x;
+        part[chunk][pr * 2 + 1] = acc.y;
+    }
+    __syncthreads();
+    if (tid < kRaRows) {
+        const int r = row0 + tid;
+        if (r < n_infosets) {
+            if (s_any[tid] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
+            double d[5];
+            for (int k = 0; k < 5; k++) {
+                double t = g_delta[r * 5 + k];                 // whatever earlier launches of this iteration left there
+                for (int q = 0; q < kRaChunks; q++) t += part[q][tid * 5 + k];
+                d[k] = t;
+            }
+            const int n = (int)((g_key[r] >> 1) & 7);
+            double R[4], sg[4], cd[4];
+            for (int k = 0; k < 4; k++) R[k] = g_regret[r * 4 + k];
+            mc_sigma(R, n, sg);
+            for (int k = 0; k < n; k++) {
+                R[k] += d[k];
+                g_regret[r * 4 + k] = R[k];
+                g_strat[r * 4 + k] += d[4] * sg[k];
+            }
+            for (int k = 0; k < 5; k++) g_delta[r * 5 + k] = 0.0;
+            mc_sigma(R, n, sg);
+            choice_cdf(sg, n, cd);
+            for (int k = 0; k < 4; k++) { g_sigcdf[r * 8 + k] = sg[k]; g_sigcdf[r * 8 + 4 + k] = cd[k]; }
+        }
     }
 }
 
@@ -392,18 +538,18 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-static size_t traverse_lds_bytes(int n_infosets, int threads) {
-    const int tasks = threads / kTaskLanes;
-    size_t b = (size_t)n_infosets * 4 * 8 * 3;
-    b += ((size_t)n_infosets * 4 + 15) & ~(size_t)15;
-    b += (size_t)tasks * kSlots * 16 + (size_t)tasks * kTaskLanes * 4;
-    b += 1656 * 2 + 576 + (size_t)n_infosets;
+static size_t traverse_lds_bytes(int n_infosets) {
+    size_t b = (size_t)n_infosets * (8 + 4) * sizeof(double);  // sigma|cdf rows, delta table
+    b += 16 * sizeof(WaveScratch);                             // per-wavefront records
+    b += (((size_t)n_infosets * 4 + 15) & ~(size_t)15);        // visit counts
+    b += 1656 * 2 + 576;                                       // node -> infoset, leaf payoffs
+    b += (size_t)n_infosets;                                   // seen flags
     return (b + 15) & ~(size_t)15;
 }
 
-static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
-    const int threads = 1024;
-    const size_t lds = traverse_lds_bytes(ctx->n_infosets, threads);
+static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb, bool fuse_apply = false) {
+    const int threads = 1024, waves = threads / 64;
+    const size_t lds = traverse_lds_bytes(ctx->n_infosets);
     SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
     static bool attr_set = false;
     if (!attr_set) {
@@ -411,8 +557,8 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
                                         hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 64));  // 8 B of static LDS (s_vis)
         attr_set = true;
     }
-    const uint32_t n_groups = (nb * 2u + (threads / kTaskLanes) - 1) / (threads / kTaskLanes);
-    const uint32_t grid = n_groups < (uint32_t)ctx->n_cus ? n_groups : (uint32_t)ctx->n_cus;
+    const uint32_t n_passes = (nb + waves - 1) / waves;  // one traversal pair per wavefront pass
+    const uint32_t grid = n_passes < (uint32_t)ctx->n_cus ? n_passes : (uint32_t)ctx->n_cus;
     const int n_cells = ctx->n_infosets * 5;
     const size_t slab_bytes = (size_t)grid * n_cells * sizeof(double);
     if (slab_bytes > ctx->slab_bytes) {
@@ -431,10 +577,19 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     }
     prof_begin(ctx);
     hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
-                       ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed,
-                       (uint32_t)(ctx->seed >> 32), iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
+                       ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
+                       iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
     prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
+    if (fuse_apply) {  // single-GPU iteration: reduce + apply in one kernel
+        hipLaunchKernelGGL(k_mccfr_reduce_apply, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+                           ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
+                           ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf);
+        SC_HIP(ctx, hipGetLastError());
+        ctx->sigcdf_valid = true;
+        ctx->iteration++;
+        return SCOPA_OK;
+    }
     hipLaunchKernelGGL(k_mccfr_reduce, dim3((n_cells + 15) / 16), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
                        ctx->d_delta, n_cells, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit);
     SC_HIP(ctx, hipGetLastError());
@@ -522,9 +677,7 @@ int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
     SC_REQUIRE(ctx, batch > 0 && batch <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_iterate: bad batch");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     for (uint32_t it = 0; it < n_iters; it++) {
-        int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch);
-        if (rc != SCOPA_OK) return rc;
-        rc = scopa_mccfr_apply(ctx);
+        const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch, /*fuse_apply=*/true);
         if (rc != SCOPA_OK) return rc;
     }
     return SCOPA_OK;

@@ -45,6 +45,7 @@ __global__ void __launch_bounds__(1024) k_tree_build(const uint8_t *__restrict__
                                                       uint16_t *__restrict__ infoset_of, int8_t *__restrict__ payoff,
                                                       uint64_t *__restrict__ key_of_infoset, int32_t *__restrict__ meta) {
     __shared__ uint64_t s_key[576];            // keys of the ply being processed
+    __shared__ int s_dfs[576];                 // their DFS indices
     __shared__ int s_first[kDecision];         // per decision node (BFS): DFS index of the first node sharing its key
     __shared__ int s_scan[kNodes + 1];         // indexed by DFS index: 1 where an infoset is first visited -> prefix sum
     const int tid = threadIdx.x, nt = blockDim.x;
@@ -79,23 +80,38 @@ __global__ void __launch_bounds__(1024) k_tree_build(const uint8_t *__restrict__
     // plies never collide (the hand size differs), so first-occurrence search runs per ply.
     for (int d = 0; d < kPlies; d++) {
         const int w = level_width(d), off = level_offset(d);
-        for (int j = tid; j < w; j += nt) s_key[j] = infoset_key(states[off + j], d & 1);
+        for (int j = tid; j < w; j += nt) { s_key[j] = infoset_key(states[off + j], d & 1); s_dfs[j] = dfs_index(d, j); }
         __syncthreads();
         for (int j = tid; j < w; j += nt) {
             const uint64_t k = s_key[j];
-            int first = dfs_index(d, j);
-            for (int m = 0; m < w; m++)
-                if (s_key[m] == k) { const int f = dfs_index(d, m); first = f < first ? f : first; }
+            int first = s_dfs[j];
+            for (int m = 0; m < w; m++) {  // DFS order within a ply is index order: the first match is the minimum
+                if (s_key[m] == k) { first = s_dfs[m]; break; }
+            }
             s_first[off + j] = first;
-            if (first == dfs_index(d, j)) s_scan[first + 1] = 1;  // this node is where the reference inserts the key
+            if (first == s_dfs[j]) s_scan[first + 1] = 1;  // this node is where the reference inserts the key
         }
         __syncthreads();
     }
-    // dense ids in DFS first-visit order (= dict insertion order, vanilla_cfr.py:51-54): inclusive scan of the flags
-    if (tid == 0) {
-        int acc = 0;
-        for (int i = 0; i <= kNodes; i++) { acc += s_scan[i]; s_scan[i] = acc; }
-        meta[0] = acc;
+    // dense ids in DFS first-visit order (= dict insertion order, vanilla_cfr.py:51-54): inclusive scan of the flags.
+    // 4 elements per lane, wavefront shuffle scan, 16 wavefront totals through LDS.
+    {
+        __shared__ int s_wsum[16];
+        const int lane = tid & 63, wave = tid >> 6, base = tid * 4;
+        int v[4], sum = 0;
+        for (int q = 0; q < 4; q++) { v[q] = base + q <= kNodes ? s_scan[base + q] : 0; sum += v[q]; }
+        int x = sum;
+        for (int o = 1; o < 64; o <<= 1) { const int y = __shfl_up(x, o); if (lane >= o) x += y; }
+        if (lane == 63) s_wsum[wave] = x;
+        __syncthreads();
+        if (tid == 0) {
+            int acc = 0;
+            for (int w = 0; w < 16; w++) { const int t = s_wsum[w]; s_wsum[w] = acc; acc += t; }
+            meta[0] = acc;
+        }
+        __syncthreads();
+        int run = x - sum + s_wsum[wave];
+        for (int q = 0; q < 4; q++) { run += v[q]; if (base + q <= kNodes) s_scan[base + q] = run; }
     }
     __syncthreads();
     for (int d = 0; d < kPlies; d++) {
