@@ -55,12 +55,13 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
     ap.add_argument("--prof-stride", type=int, default=8, help="bracket every n-th traversal launch with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from scopa_amd import _lib
-    from scopa_amd.distributed import ShardedMCCFR, make_gpu_engine
+    from scopa_amd.distributed import ShardedMCCFR, make_gpu_engine, shard_range
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -71,23 +72,30 @@ def main():
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the solver path has no CPU fallback")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        dist.init_process_group(backend="nccl", device_id=torch.device(f"cuda:{local_rank}"))
+    use_dist = world > 1 or args.force_dist
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     perm = _lib.deal_py_seed(42)
-    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=world)
+    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=2 if use_dist else 1)
     batch_total = args.batch * world
     drv = ShardedMCCFR(ctx, rank, world, all_reduce)
+    if use_dist:
+        drv.world = max(world, 2)  # forces the all-reduce branch; shard_range below still uses the true world size
+        drv.iteration = lambda bt, _d=drv: (_d.engine.mccfr_traverse(_d.engine.mccfr_iteration(), *shard_range(bt, rank, world)),
+                                            _d.all_reduce(), _d.engine.mccfr_apply())
 
     def run(k):
-        if world == 1:
+        if not use_dist:
             ctx.mccfr_iterate(args.batch, k)  # in-library launch loop: traverse + apply per iteration
         else:
             drv.run(batch_total, k)
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
 
@@ -104,7 +112,7 @@ def main():
     ctx.prof_enable(0)
     d1, _ = ctx.counters()
 
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -147,7 +155,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

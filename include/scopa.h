@@ -127,6 +127,10 @@ int32_t scopa_cfr_exact_traverse(scopa_ctx *ctx, int32_t traverser, double *h_va
 int32_t scopa_cfr_exact_traverse_from(scopa_ctx *ctx, int32_t traverser, int32_t depth, const int32_t *path,
                                       double reach_p0, double reach_p1, double *h_value);
 
+/* ---- synchronous CFR (build-defined): sigma = regret-match(regret) frozen per iteration, both players updated from
+ * one level-parallel sweep.  Not the reference's visit-order-dependent algorithm: same fixed point, different trajectory. */
+int32_t scopa_cfr_sync_iterate(scopa_ctx *ctx, int32_t n_iters);
+
 /* ---- MCCFR replay: MCCFRTrainer.iteration() (mc_cfr.py:37-92) driven by a host-supplied uniform stream
  * (one float64 per decision visit in DFS order = what np.random.choice draws); bit-exact vs the reference. */
 int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_uniforms, int64_t n_uniforms,
@@ -186,6 +190,11 @@ int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, 
 int32_t scopa_eval_init_states(scopa_ctx *ctx, scopa_state *d_states, int64_t n);
 int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const float *d_probs, const int32_t *d_trained_seat,
                         uint32_t stream_id, uint32_t ply_tag);
+
+/* one ply of n lockstep evaluation episodes of a TABULAR policy d_policy[n_infosets][4] (float64, hand order) vs uniform
+ * random: evaluate_agent (vanilla_cfr.py:157-216).  d_node_idx[n] tracks each episode's tree node (start at 0). */
+int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *d_node_idx, int64_t n, int32_t ply,
+                                const double *d_policy, const int32_t *d_trained_seat, uint32_t stream_id);
 
 /* ---- policy value / exploitability (build-defined; the reference only calls OpenSpiel's, vanilla_cfr.py:112-118) --
  * h_policy[n_infosets][4] or NULL = the average policy of the strategy table (InfoNode.policy, vanilla_cfr.py:32-39).

@@ -25,7 +25,7 @@ SYMBOLS = [
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_features_from_states",
-    "scopa_eval_init_states", "scopa_eval_step", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -120,6 +120,8 @@ def lib():
         "scopa_features_from_states": (i32, [vp, vp, i64, vp, vp]),
         "scopa_eval_init_states": (i32, [vp, vp, i64]),
         "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
+        "scopa_eval_tabular_step": (i32, [vp, vp, vp, i64, i32, vp, vp, u32]),
+        "scopa_cfr_sync_iterate": (i32, [vp, i32]),
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
@@ -346,6 +348,13 @@ class Context:
     def eval_step(self, states_ptr, n, probs_ptr, seat_ptr, stream_id, ply_tag):
         self._ck(self._L.scopa_eval_step(self._h, C.c_void_p(states_ptr), n, C.c_void_p(probs_ptr) if probs_ptr else None, C.c_void_p(seat_ptr),
                                          stream_id, ply_tag), "scopa_eval_step")
+
+    def eval_tabular_step(self, states_ptr, idx_ptr, n, ply, policy_ptr, seat_ptr, stream_id):
+        self._ck(self._L.scopa_eval_tabular_step(self._h, C.c_void_p(states_ptr), C.c_void_p(idx_ptr), n, ply, C.c_void_p(policy_ptr),
+                                                 C.c_void_p(seat_ptr), stream_id), "scopa_eval_tabular_step")
+
+    def cfr_sync_iterate(self, n_iters):
+        self._ck(self._L.scopa_cfr_sync_iterate(self._h, int(n_iters)), "scopa_cfr_sync_iterate")
 
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()

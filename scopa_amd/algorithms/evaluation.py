@@ -1,0 +1,45 @@
+"""Batched on-device evaluation of a tabular policy vs a uniform-random opponent.
+
+The reference's evaluate_agent (vanilla_cfr.py:157-216, mc_cfr.py:146-206) plays episodes one by one in Python and is
+where its experiment scripts spend most of their wall time (500 episodes every 5 iterations,
+run_mccfr_experiment.py:101-105).  Here all episodes advance in lockstep: the packed states are stepped by the device
+step function, the trained seat's action comes from its policy row (np.random.choice arithmetic) and the opponent's is
+uniform.  Seats are swapped at half time as in the reference.  Draws are Philox, so the numbers are statistically -- not
+bitwise -- equivalent to the reference's np.random stream; `evaluate_agent` in vanilla_cfr / mc_cfr remains the
+bit-reproducing host version."""
+import numpy as np
+
+from .. import _lib
+
+
+def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16):
+    """-> (avg_reward, scopa_stats) for `trainer`'s average policy (or an explicit [n_infosets][4] table)."""
+    import torch
+    eng = trainer._engine
+    ctx = eng.ctx
+    n = int(num_episodes)
+    if policy is None:
+        policy = ctx.exploitability(return_policy=True)["policy"]     # the average policy, computed on device
+    dev = f"cuda:{ctx.device}"
+    pol = torch.as_tensor(np.ascontiguousarray(policy, np.float64), device=dev)
+    states = torch.zeros((n, 4), dtype=torch.int32, device=dev)
+    ctx.eval_init_states(states.data_ptr(), n)
+    idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    seat_h = np.array([0 if e < n / 2 else 1 for e in range(n)], np.int32)
+    seat = torch.as_tensor(seat_h, device=dev)
+    torch.cuda.synchronize()
+    for ply in range(8):
+        ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, pol.data_ptr(), seat.data_ptr(), stream_id)
+    ctx.synchronize()
+    raw = states.cpu().numpy().view(_lib.STATE_DTYPE).reshape(-1)
+    r = raw["ncap"].astype(np.int64) + 2 * raw["scopas"].astype(np.int64)
+    total = r.sum(1)
+    rewards = np.where(total[:, None] == 0, 0.0, r - total[:, None] / 2.0)   # evaluate_game (mini_scopa_game.py:106-114)
+    ar = np.arange(n)
+    mine = rewards[ar, seat_h]
+    t_sc = raw["scopas"][ar, seat_h].astype(np.float64)
+    o_sc = raw["scopas"][ar, 1 - seat_h].astype(np.float64)
+    stats = {"trained_avg": float(t_sc.mean()), "opponent_avg": float(o_sc.mean()),
+             "difference": float(t_sc.mean() - o_sc.mean()), "data_collected": n > 0,
+             "reward_std_error": float(mine.std() / np.sqrt(max(n, 1)))}
+    return float(mine.mean()), stats

@@ -37,8 +37,14 @@ class InfoNode:
 class CFRTrainer:
     """`CFRTrainer(game).train(steps)`; `.info_set_map`: dict[infoset string -> InfoNode] in first-visit order."""
 
-    def __init__(self, game, device=0):
+    def __init__(self, game, device=0, mode="exact"):
+        """mode="exact": the reference's sequential semantics (bit-identical tables).  mode="sync": textbook
+        simultaneous-update CFR (strategy frozen per iteration, level-parallel kernel) -- same fixed point, not the
+        reference's trajectory."""
+        if mode not in ("exact", "sync"):
+            raise ValueError("mode must be 'exact' or 'sync'")
         self.game = game
+        self.mode = mode
         self._engine = Engine(game, device=device)
         self._map = {}
         self._stale = False
@@ -64,7 +70,10 @@ class CFRTrainer:
             chunk = steps - done
             if compute_exploitability:
                 chunk = min(chunk, eval_interval - (done % eval_interval))
-            ctx.cfr_exact_iterate(chunk)
+            if self.mode == "exact":
+                ctx.cfr_exact_iterate(chunk)
+            else:
+                ctx.cfr_sync_iterate(chunk)
             done += chunk
             self._stale = True
             if compute_exploitability and done % eval_interval == 0:

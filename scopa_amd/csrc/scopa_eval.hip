@@ -9,6 +9,7 @@
 //
 // One workgroup, level-synchronous over the 9 plies; reach, value, policy and q tables live in LDS (~85 KB).
 #include "scopa_ctx.h"
+#include "scopa_philox.h"
 
 using namespace scopa;
 
@@ -125,3 +126,153 @@ extern "C" int32_t scopa_exploitability(scopa_ctx *ctx, const double *h_policy, 
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCOPA_OK;
 }
+
+// =====================================================================================================================
+// Synchronous ("frozen strategy") CFR -- the parallel variant SURVEY §8b lists next to the exact one (H1): sigma =
+// regret-match(regret) is frozen for the whole iteration and BOTH players' regrets are updated from one sweep.  It is
+// NOT the reference's algorithm (whose tables depend on DFS visit order, vanilla_cfr.py:97); it is the textbook
+// simultaneous-update CFR, defined by oracle/scopa_oracle.c og_cfr_sync and matched bit-for-bit: every float64 sum
+// runs in the oracle's order (children left to right; an infoset's nodes in ply order).
+// One workgroup, everything in LDS (regret, strategy, sigma 3 x 23.6 KB, reach x2 + value 53 KB), n_iters per launch.
+__global__ void __launch_bounds__(1024)
+k_cfr_sync(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
+           double *__restrict__ g_regret, double *__restrict__ g_strat, int n_infosets, int n_iters,
+           unsigned long long *__restrict__ g_counters, uint32_t *__restrict__ g_visit, int32_t *__restrict__ g_meta) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int I = n_infosets, tid = threadIdx.x, nt = blockDim.x;
+    double *s_R = reinterpret_cast<double *>(smem);   // [I][4]
+    double *s_S = s_R + (size_t)I * 4;                // [I][4]
+    double *s_sig = s_S + (size_t)I * 4;              // [I][4]
+    double *s_r0 = s_sig + (size_t)I * 4;             // [kNodes] reach of player 0 (BFS order)
+    double *s_r1 = s_r0 + kNodes;                     // [kNodes]
+    double *s_val = s_r1 + kNodes;                    // [kNodes] value for player 0
+    uint16_t *s_inf = reinterpret_cast<uint16_t *>(s_val + kNodes);  // [1653]
+    for (int i = tid; i < I * 4; i += nt) { s_R[i] = g_regret[i]; s_S[i] = g_strat[i]; }
+    for (int i = tid; i < kDecision; i += nt) s_inf[i] = g_infoset[i];
+    __syncthreads();
+    for (int it = 0; it < n_iters; it++) {
+        for (int r = tid; r < I; r += nt) {  // InfoNode.get_strategy (vanilla_cfr.py:23-30)
+            const int n = (int)((g_key[r] >> 1) & 7);
+            double pos[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int c = 0; c < n; c++) pos[c] = s_R[r * 4 + c] > 0.0 ? s_R[r * 4 + c] : 0.0;
+            double s = pos[0];
+            for (int c = 1; c < n; c++) s += pos[c];
+            for (int c = 0; c < 4; c++) s_sig[r * 4 + c] = c < n ? (s > 0.0 ? pos[c] / s : 1.0 / (double)n) : 0.0;
+        }
+        if (tid == 0) { s_r0[0] = 1.0; s_r1[0] = 1.0; }
+        __syncthreads();
+        for (int d = 0; d < kPlies; d++) {  // reach probabilities, top down
+            const int n = nlegal_at(d), w1 = level_width(d + 1), p = d & 1;
+            for (int j = tid; j < w1; j += nt) {
+                const int par = j / n, a = j - par * n;
+                const double sg = s_sig[s_inf[level_offset(d) + par] * 4 + a];
+                const double a0 = s_r0[level_offset(d) + par], a1 = s_r1[level_offset(d) + par];
+                s_r0[level_offset(d + 1) + j] = p == 0 ? a0 * sg : a0;
+                s_r1[level_offset(d + 1) + j] = p == 1 ? a1 * sg : a1;
+            }
+            __syncthreads();
+        }
+        for (int j = tid; j < kTerminal; j += nt) s_val[level_offset(8) + j] = 0.5 * (double)g_payoff[j];
+        __syncthreads();
+        for (int d = kPlies - 1; d >= 0; d--) {  // values bottom up, then this ply's regret / strategy increments
+            const int n = nlegal_at(d), w = level_width(d), off = level_offset(d), p = d & 1;
+            for (int j = tid; j < w; j += nt) {
+                const int r = s_inf[off + j];
+                double v = 0.0;
+                for (int a = 0; a < n; a++) v += s_sig[r * 4 + a] * s_val[level_offset(d + 1) + j * n + a];
+                s_val[off + j] = v;
+            }
+            __syncthreads();
+            const double sgn = p == 0 ? 1.0 : -1.0;
+            for (int cell = tid; cell < I * 4; cell += nt) {
+                const int r = cell >> 2, a = cell & 3;
+                if ((int)(g_key[r] & 1) != p || (int)((g_key[r] >> 1) & 7) != n || a >= n) continue;
+                double dR = 0.0, dS = 0.0;
+                const double sg = s_sig[cell];
+                for (int j = 0; j < w; j++) {
+                    if (s_inf[off + j] != r) continue;
+                    const double reach = p == 0 ? s_r0[off + j] : s_r1[off + j], opp = p == 0 ? s_r1[off + j] : s_r0[off + j];
+                    dR += opp * (sgn * (s_val[level_offset(d + 1) + j * n + a] - s_val[off + j]));
+                    dS += reach * sg;
+                }
+                s_R[cell] += dR;   // sigma is already frozen in s_sig, so the tables can be updated in place
+                s_S[cell] += dS;
+            }
+            __syncthreads();
+        }
+    }
+    for (int i = tid; i < I * 4; i += nt) { g_regret[i] = s_R[i]; g_strat[i] = s_S[i]; }
+    for (int r = tid; r < I; r += nt) if (n_iters > 0 && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
+    if (tid == 0) { g_counters[0] += (unsigned long long)kDecision * n_iters; g_counters[1] += (unsigned long long)kTerminal * n_iters; }
+    (void)g_meta;
+}
+
+// =====================================================================================================================
+// Batched evaluation of a TABULAR policy against uniform random (evaluate_agent, vanilla_cfr.py:157-216 /
+// mc_cfr.py:146-206): n episodes of the context's deal in lockstep.  Each lane keeps the packed state (advanced
+// with the same device step as everything else) and its tree index, so the trained seat's policy row is one table lookup.
+__global__ void __launch_bounds__(256)
+k_eval_tabular_step(scopa_state *__restrict__ states, int32_t *__restrict__ node_idx, long long n, int ply,
+                    const uint16_t *__restrict__ g_infoset, const double *__restrict__ policy /*[I][4]*/,
+                    const int32_t *__restrict__ trained_seat, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    scopa_state s = states[i];
+    if (is_terminal(s)) return;
+    const int p = s.step & 1, nl = s.nh[p];
+    const int idx = node_idx[i];
+    const philox_out x = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)ply, stream, seed_lo, seed_hi);
+    const double u = u53(x.x0, x.x1);
+    int k = nl - 1;
+    if (p == trained_seat[i]) {  // np.random.choice(actions, p=probs): cumsum, normalise, searchsorted right
+        const double *row = policy + (size_t)g_infoset[level_offset(ply) + idx] * 4;
+        double c = 0.0, cdf[4];
+        for (int q = 0; q < nl; q++) { c = q ? c + row[q] : row[0]; cdf[q] = c; }
+        const double last = cdf[nl - 1];
+        int a = 0;
+        for (int q = 0; q < nl; q++) if (cdf[q] / last <= u) a = q + 1;
+        k = a < nl - 1 ? a : nl - 1;
+    } else {  // uniform opponent
+        const int a = (int)(u * (double)nl);
+        k = a < nl - 1 ? a : nl - 1;
+    }
+    step(s, nib(s.hand[p], k));
+    states[i] = s;
+    node_idx[i] = idx * nl + k;
+}
+
+extern "C" {
+
+int32_t scopa_cfr_sync_iterate(scopa_ctx *ctx, int32_t n_iters) {
+    if (!ctx || n_iters < 0 || n_iters > (1 << 24)) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_cfr_sync_iterate: no deal set");
+    if (n_iters == 0) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 3 + sizeof(double) * kNodes * 3 + 1656 * 2;
+    SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_cfr_sync_iterate: tables do not fit in LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cfr_sync), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(k_cfr_sync, dim3(1), dim3(1024), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_regret,
+                       ctx->d_strat, ctx->n_infosets, (int)n_iters, ctx->d_counters, ctx->d_visit, ctx->d_meta);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sigcdf_valid = false;
+    return SCOPA_OK;
+}
+
+int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *d_node_idx, int64_t n, int32_t ply,
+                                const double *d_policy, const int32_t *d_trained_seat, uint32_t stream_id) {
+    if (!ctx || n < 0 || ply < 0 || ply >= kPlies || (n && (!d_states || !d_node_idx || !d_policy || !d_trained_seat))) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_eval_tabular_step: no deal set");
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_eval_tabular_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, d_node_idx,
+                       (long long)n, (int)ply, ctx->d_infoset, d_policy, d_trained_seat, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), stream_id);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+}  // extern "C"
