@@ -184,8 +184,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][8]: sigma[4] | normalised cdf[4]
     double *s_dR = s_sigcdf + (size_t)I * 8;                                     // [I][4]
-    WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [16]
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + 16);         // [I] traverser visits
+    WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup]
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));  // [I] traverser visits
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));  // [1653] (+pad)
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);                    // [576]
     uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);            // [I]
@@ -538,9 +538,9 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-static size_t traverse_lds_bytes(int n_infosets) {
+static size_t traverse_lds_bytes(int n_infosets, int waves) {
     size_t b = (size_t)n_infosets * (8 + 4) * sizeof(double);  // sigma|cdf rows, delta table
-    b += 16 * sizeof(WaveScratch);                             // per-wavefront records
+    b += (size_t)waves * sizeof(WaveScratch);                  // per-wavefront records
     b += (((size_t)n_infosets * 4 + 15) & ~(size_t)15);        // visit counts
     b += 1656 * 2 + 576;                                       // node -> infoset, leaf payoffs
     b += (size_t)n_infosets;                                   // seen flags
@@ -548,8 +548,12 @@ static size_t traverse_lds_bytes(int n_infosets) {
 }
 
 static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb, bool fuse_apply = false) {
-    const int threads = 1024, waves = threads / 64;
-    const size_t lds = traverse_lds_bytes(ctx->n_infosets);
+    // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~870 infosets), fewer for deals
+    // with more infosets (the tables alone fit up to 1653, the maximum)
+    int waves = 16;
+    while (waves > 1 && traverse_lds_bytes(ctx->n_infosets, waves) + 64 > (size_t)ctx->lds_limit) waves -= 2;
+    const int threads = waves * 64;
+    const size_t lds = traverse_lds_bytes(ctx->n_infosets, waves);
     SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
     static bool attr_set = false;
     if (!attr_set) {

@@ -197,3 +197,27 @@ def test_profiling_counts_launches(ctx, sl):
     n, ms = ctx.prof_read()
     assert n == 5 and ms > 0
     ctx.prof_enable(False)
+
+
+@pytest.mark.parametrize("seed,n_inf", [(282, 251), (129, 1144)])
+def test_mccfr_batched_extreme_infoset_counts(ctx, sl, oracle, seed, n_inf):
+    """Deals with the fewest / most infosets among seeds 0..399: the traversal kernel sizes its workgroup to what the
+    LDS holds (1144 infosets leave room for fewer wave scratch areas) and still matches the oracle."""
+    t = oracle.Tree(seed=seed)
+    assert t.n_infosets == n_inf == ctx.set_deal(sl.deal_py_seed(seed))
+    ctx.mccfr_seed(11)
+    ctx.mccfr_iterate(300, 3)
+    R, S, _ = ctx.tables_get()
+    Ro, So, _ = t.tables()
+    t.mccfr_batched(Ro, So, 11, 0, 3, 300)
+    np.testing.assert_allclose(R, Ro, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(S, So, rtol=1e-10, atol=1e-10)
+    assert ctx.counters() == (463 * 300 * 3, 240 * 300 * 3)
+    # the exact-semantics solver and exploitability on the same deal
+    ctx.tables_reset()
+    ctx.cfr_exact_iterate(2)
+    Ro, So, Lo = t.tables()
+    t.cfr_exact(Ro, So, Lo, 2)
+    Rg, Sg, Lg = ctx.tables_get()
+    assert np.array_equal(Rg, Ro) and np.array_equal(Sg, So) and np.array_equal(Lg, Lo)
+    assert ctx.exploitability()["exploitability"] == t.exploitability(t.average_policy(So))[0]
