@@ -202,6 +202,26 @@ int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *
  * receives the policy that was evaluated. */
 int32_t scopa_exploitability(scopa_ctx *ctx, const double *h_policy, double *h_out4, double *h_policy_out);
 
+/* ---- many deals at once ("replicas": one workgroup per independent solve) -------------------------------------------------
+ * The reference solves one deal (seed 42) but its env takes a seed (MiniScopaEnv(seed=...), mini_scopa_game.py:120-132).
+ * A scopa_multi keeps n deals resident in HBM and runs the per-deal kernels with one workgroup per deal.
+ *   deal_py_seeds : MiniDeck(seed) for every deal ON DEVICE (CPython seed + shuffle, one lane per deal)
+ *   build         : game trees + zeroed tables; h_n_infosets[n] (optional) receives the infoset counts
+ *   cfr_exact / cfr_sync_iterate, exploitability (h_out4[n][4]) : as the single-deal entry points, per deal
+ *   tables_get    : [n_infosets(deal)][4] tables and keys of one deal */
+typedef struct scopa_multi scopa_multi;
+int32_t scopa_multi_create(scopa_ctx *ctx, int32_t n_deals, scopa_multi **out);
+int32_t scopa_multi_destroy(scopa_multi *m);
+int32_t scopa_multi_deal_py_seeds(scopa_multi *m, const int64_t *h_seeds);
+int32_t scopa_multi_set_perms(scopa_multi *m, const uint8_t *h_perms /*[n][16]*/);
+int32_t scopa_multi_perms_get(scopa_multi *m, uint8_t *h_perms);
+int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets);
+int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters);
+int32_t scopa_multi_cfr_sync_iterate(scopa_multi *m, int32_t n_iters);
+int32_t scopa_multi_exploitability(scopa_multi *m, double *h_out4);
+int32_t scopa_multi_tables_get(scopa_multi *m, int32_t deal, double *h_regret, double *h_strategy, double *h_local, uint64_t *h_keys);
+int32_t scopa_multi_counters(scopa_multi *m, uint64_t *decision_visits, uint64_t *terminal_visits);
+
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);

@@ -25,7 +25,9 @@ SYMBOLS = [
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_features_from_states",
-    "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
+    "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
+    "scopa_multi_cfr_sync_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -122,6 +124,17 @@ def lib():
         "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
         "scopa_eval_tabular_step": (i32, [vp, vp, vp, i64, i32, vp, vp, u32]),
         "scopa_cfr_sync_iterate": (i32, [vp, i32]),
+        "scopa_multi_create": (i32, [vp, i32, C.POINTER(vp)]),
+        "scopa_multi_destroy": (i32, [vp]),
+        "scopa_multi_deal_py_seeds": (i32, [vp, vp]),
+        "scopa_multi_set_perms": (i32, [vp, vp]),
+        "scopa_multi_perms_get": (i32, [vp, vp]),
+        "scopa_multi_build": (i32, [vp, vp]),
+        "scopa_multi_cfr_exact_iterate": (i32, [vp, i32]),
+        "scopa_multi_cfr_sync_iterate": (i32, [vp, i32]),
+        "scopa_multi_exploitability": (i32, [vp, vp]),
+        "scopa_multi_tables_get": (i32, [vp, i32, vp, vp, vp, vp]),
+        "scopa_multi_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
@@ -168,9 +181,14 @@ class Context:
             raise ScopaError(rc, "scopa_ctx_create", "a GPU is required: the solver path has no CPU fallback")
         self.device = device
         self.n_infosets = 0
+        self._children = []  # weakrefs of objects that hold device memory through this context (MultiDeal)
 
     def close(self):
         if getattr(self, "_h", None):
+            for ref in getattr(self, "_children", []):
+                child = ref()
+                if child is not None:
+                    child.close()
             self._L.scopa_ctx_destroy(self._h)
             self._h = None
 
@@ -369,3 +387,70 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self._ck(self._L.scopa_prof_read(self._h, C.byref(n), C.byref(ms)), "scopa_prof_read")
         return n.value, ms.value
+
+
+class MultiDeal:
+    """n independent deals resident on one device, one workgroup per deal (scopa_multi_* in include/scopa.h)."""
+
+    def __init__(self, ctx, n_deals):
+        self.ctx, self.n = ctx, int(n_deals)
+        self._L = lib()
+        self._h = C.c_void_p()
+        ctx._ck(self._L.scopa_multi_create(ctx._h, self.n, C.byref(self._h)), "scopa_multi_create")
+        self.n_infosets = None
+        import weakref
+        ctx._children.append(weakref.ref(self))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            self._L.scopa_multi_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def deal_py_seeds(self, seeds):
+        s = np.ascontiguousarray(seeds, np.int64)
+        assert s.size == self.n
+        self.ctx._ck(self._L.scopa_multi_deal_py_seeds(self._h, _ptr(s)), "scopa_multi_deal_py_seeds")
+
+    def set_perms(self, perms):
+        p = np.ascontiguousarray(perms, np.uint8)
+        assert p.shape == (self.n, 16)
+        self.ctx._ck(self._L.scopa_multi_set_perms(self._h, _ptr(p)), "scopa_multi_set_perms")
+
+    def perms(self):
+        p = np.zeros((self.n, 16), np.uint8)
+        self.ctx._ck(self._L.scopa_multi_perms_get(self._h, _ptr(p)), "scopa_multi_perms_get")
+        return p
+
+    def build(self):
+        ninf = np.zeros(self.n, np.int32)
+        self.ctx._ck(self._L.scopa_multi_build(self._h, _ptr(ninf)), "scopa_multi_build")
+        self.n_infosets = ninf
+        return ninf
+
+    def cfr_exact_iterate(self, n_iters):
+        self.ctx._ck(self._L.scopa_multi_cfr_exact_iterate(self._h, int(n_iters)), "scopa_multi_cfr_exact_iterate")
+
+    def cfr_sync_iterate(self, n_iters):
+        self.ctx._ck(self._L.scopa_multi_cfr_sync_iterate(self._h, int(n_iters)), "scopa_multi_cfr_sync_iterate")
+
+    def exploitability(self):
+        out = np.zeros((self.n, 4))
+        self.ctx._ck(self._L.scopa_multi_exploitability(self._h, _ptr(out)), "scopa_multi_exploitability")
+        return out
+
+    def tables_get(self, deal):
+        I = int(self.n_infosets[deal])
+        R, S, Lc, K = np.zeros((I, 4)), np.zeros((I, 4)), np.zeros((I, 4)), np.zeros(I, np.uint64)
+        self.ctx._ck(self._L.scopa_multi_tables_get(self._h, int(deal), _ptr(R), _ptr(S), _ptr(Lc), _ptr(K)), "scopa_multi_tables_get")
+        return R, S, Lc, K
+
+    def counters(self):
+        a, b = C.c_uint64(), C.c_uint64()
+        self.ctx._ck(self._L.scopa_multi_counters(self._h, C.byref(a), C.byref(b)), "scopa_multi_counters")
+        return a.value, b.value

@@ -32,7 +32,7 @@ __device__ __forceinline__ void regret_match(const double *R, int n, double *out
 
 __global__ void __launch_bounds__(256)
 k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, double *__restrict__ g_regret,
-            double *__restrict__ g_strat, double *__restrict__ g_local, int n_infosets, int n_traversals, int first_traverser,
+            double *__restrict__ g_strat, double *__restrict__ g_local, int n_infosets /* <= 0: multi-deal */, int n_traversals, int first_traverser,
             double *__restrict__ root_values, unsigned long long *__restrict__ g_counters, int use_lds,
             uint32_t *__restrict__ g_visit, int32_t *__restrict__ g_meta, int start_depth, int start_idx, double start_r0,
             double start_r1) {
@@ -40,6 +40,14 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
     __shared__ uint16_t s_inf[1656];
     __shared__ int8_t s_pay[kTerminal];
     __shared__ CfrFrame fr[kPlies + 1];
+    if (n_infosets <= 0) {  // multi-deal mode: one workgroup per deal, shapes from the deal's meta block
+        const size_t deal = blockIdx.x;
+        g_infoset += deal * kDecision; g_payoff += deal * kTerminal;
+        g_regret += deal * kDecision * 4; g_strat += deal * kDecision * 4; g_local += deal * kDecision * 4;
+        g_visit += deal * kDecision; g_meta += deal * 8; g_counters += deal * 8;
+        if (root_values) root_values += deal * (size_t)n_traversals;
+        n_infosets = g_meta[0];
+    }
     const int tid = threadIdx.x, cells = n_infosets * 4;
     double *R = g_regret, *S = g_strat, *L = g_local;
     if (use_lds) {

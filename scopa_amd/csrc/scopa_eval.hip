@@ -16,8 +16,18 @@ using namespace scopa;
 __global__ void __launch_bounds__(1024)
 k_exploitability(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
                  const double *__restrict__ g_strat, const double *__restrict__ g_policy_in, int n_infosets,
-                 double *__restrict__ out4, double *__restrict__ g_policy_out) {
+                 double *__restrict__ out4, double *__restrict__ g_policy_out, const int32_t *__restrict__ multi_meta) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (n_infosets <= 0) {  // multi-deal mode: one workgroup per deal; meta[0] of the deal = its infoset count
+        const size_t deal = blockIdx.x;
+        n_infosets = -n_infosets;  // the caller passes -max(n_infosets) so that LDS carving below is the same for all deals
+        g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision;
+        g_strat += deal * kDecision * 4; out4 += deal * 4;
+        if (g_policy_in) g_policy_in += deal * kDecision * 4;
+        if (g_policy_out) g_policy_out += deal * kDecision * 4;
+        // rows beyond this deal's own count are never referenced: every loop below is bounded by the deal's keys
+        n_infosets = multi_meta ? multi_meta[deal * 8] : n_infosets;
+    }
     const int I = n_infosets, tid = threadIdx.x, nt = blockDim.x;
     double *s_pol = reinterpret_cast<double *>(smem);   // [I][4]
     double *s_q = s_pol + (size_t)I * 4;                // [I][4]
@@ -119,7 +129,7 @@ extern "C" int32_t scopa_exploitability(scopa_ctx *ctx, const double *h_policy, 
         attr_set = true;
     }
     hipLaunchKernelGGL(k_exploitability, dim3(1), dim3(1024), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key,
-                       ctx->d_strat, h_policy ? d_pin : nullptr, I, d_out, h_policy_out ? d_pout : nullptr);
+                       ctx->d_strat, h_policy ? d_pin : nullptr, I, d_out, h_policy_out ? d_pout : nullptr, (const int32_t *)nullptr);
     SC_HIP(ctx, hipGetLastError());
     SC_HIP(ctx, hipMemcpyAsync(h_out4, d_out, 4 * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
     if (h_policy_out) SC_HIP(ctx, hipMemcpyAsync(h_policy_out, d_pout, pol_bytes, hipMemcpyDeviceToHost, ctx->stream));
@@ -133,21 +143,28 @@ extern "C" int32_t scopa_exploitability(scopa_ctx *ctx, const double *h_policy, 
 // NOT the reference's algorithm (whose tables depend on DFS visit order, vanilla_cfr.py:97); it is the textbook
 // simultaneous-update CFR, defined by oracle/scopa_oracle.c og_cfr_sync and matched bit-for-bit: every float64 sum
 // runs in the oracle's order (children left to right; an infoset's nodes in ply order).
-// One workgroup, everything in LDS (regret, strategy, sigma 3 x 23.6 KB, reach x2 + value 53 KB), n_iters per launch.
+// One workgroup per deal; regret and sigma (2 x 23.6 KB at 738 infosets), reach x2 + value (53 KB) in LDS -- fits every
+// deal up to the 1653-infoset maximum -- n_iters per launch.
 __global__ void __launch_bounds__(1024)
 k_cfr_sync(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
            double *__restrict__ g_regret, double *__restrict__ g_strat, int n_infosets, int n_iters,
            unsigned long long *__restrict__ g_counters, uint32_t *__restrict__ g_visit, int32_t *__restrict__ g_meta) {
     extern __shared__ __align__(16) unsigned char smem[];
+    if (n_infosets <= 0) {  // multi-deal mode: one workgroup per deal
+        const size_t deal = blockIdx.x;
+        g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision;
+        g_regret += deal * kDecision * 4; g_strat += deal * kDecision * 4;
+        g_visit += deal * kDecision; g_meta += deal * 8; g_counters += deal * 8;
+        n_infosets = g_meta[0];
+    }
     const int I = n_infosets, tid = threadIdx.x, nt = blockDim.x;
     double *s_R = reinterpret_cast<double *>(smem);   // [I][4]
-    double *s_S = s_R + (size_t)I * 4;                // [I][4]
-    double *s_sig = s_S + (size_t)I * 4;              // [I][4]
+    double *s_sig = s_R + (size_t)I * 4;              // [I][4]   (strategy sums stay in HBM: one RMW per cell per iteration)
     double *s_r0 = s_sig + (size_t)I * 4;             // [kNodes] reach of player 0 (BFS order)
     double *s_r1 = s_r0 + kNodes;                     // [kNodes]
     double *s_val = s_r1 + kNodes;                    // [kNodes] value for player 0
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(s_val + kNodes);  // [1653]
-    for (int i = tid; i < I * 4; i += nt) { s_R[i] = g_regret[i]; s_S[i] = g_strat[i]; }
+    for (int i = tid; i < I * 4; i += nt) s_R[i] = g_regret[i];
     for (int i = tid; i < kDecision; i += nt) s_inf[i] = g_infoset[i];
     __syncthreads();
     for (int it = 0; it < n_iters; it++) {
@@ -196,12 +213,12 @@ k_cfr_sync(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_
                     dS += reach * sg;
                 }
                 s_R[cell] += dR;   // sigma is already frozen in s_sig, so the tables can be updated in place
-                s_S[cell] += dS;
+                g_strat[cell] += dS;
             }
             __syncthreads();
         }
     }
-    for (int i = tid; i < I * 4; i += nt) { g_regret[i] = s_R[i]; g_strat[i] = s_S[i]; }
+    for (int i = tid; i < I * 4; i += nt) g_regret[i] = s_R[i];
     for (int r = tid; r < I; r += nt) if (n_iters > 0 && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
     if (tid == 0) { g_counters[0] += (unsigned long long)kDecision * n_iters; g_counters[1] += (unsigned long long)kTerminal * n_iters; }
     (void)g_meta;
@@ -248,7 +265,7 @@ int32_t scopa_cfr_sync_iterate(scopa_ctx *ctx, int32_t n_iters) {
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_cfr_sync_iterate: no deal set");
     if (n_iters == 0) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 3 + sizeof(double) * kNodes * 3 + 1656 * 2;
+    const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 2 + sizeof(double) * kNodes * 3 + 1656 * 2;
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_cfr_sync_iterate: tables do not fit in LDS");
     static bool attr_set = false;
     if (!attr_set) {

@@ -1,0 +1,257 @@
+// scopa_multi.hip -- many independent deals at once: "replicas" parallelism for the exact-semantics solvers.
+//
+// The reference always solves ONE deal (seed 42, src/envs/mini_scopa_game.py:25-28,131-132) although its API takes a
+// seed (MiniScopaEnv(seed=...), :120-132).  Its vanilla CFR is inherently sequential per solve (DESIGN.md §4,
+// SURVEY H1), so the way to use a 256-CU GPU for it is one solve per workgroup.  A scopa_multi holds n deals
+// resident in HBM -- per deal 35.7 KB of packed states, the node->infoset map, leaf payoffs, infoset keys and three
+// [1653][4] float64 tables (~200 KB) -- and runs, one WORKGROUP PER DEAL:
+//   k_deal_py_seed   the deal itself: CPython's random.seed(int) + random.shuffle on a per-lane MT19937
+//   k_tree_build     level-synchronous expansion with the device step function
+//   k_cfr_exact      the reference's sequential vanilla CFR, bit-exact per deal
+//   k_cfr_sync       synchronous CFR
+//   k_exploitability best responses and policy value
+#include <vector>
+
+#include "scopa_kernels.h"
+
+using namespace scopa;
+
+struct scopa_multi {
+    scopa_ctx *ctx = nullptr;
+    int n = 0;
+    bool built = false;
+    int max_infosets = 0;
+    uint8_t *d_perm = nullptr;       // [n][16]
+    scopa_state *d_states = nullptr; // [n][2229]
+    uint16_t *d_infoset = nullptr;   // [n][1653]
+    int8_t *d_payoff = nullptr;      // [n][576]
+    uint64_t *d_key = nullptr;       // [n][1653]
+    int32_t *d_meta = nullptr;       // [n][8]
+    double *d_regret = nullptr, *d_strat = nullptr, *d_local = nullptr;  // [n][1653][4]
+    uint32_t *d_visit = nullptr;     // [n][1653]
+    unsigned long long *d_counters = nullptr;  // [n][8]
+    double *d_out = nullptr;         // [n][4] exploitability outputs
+    int64_t *d_seeds = nullptr;      // [n]
+};
+
+// ---- CPython random.seed(int) + random.shuffle(16 cards), one lane per deal (MiniDeck.__init__, mini_scopa_game.py:25-28) --------
+// MT19937 init_by_array on |seed|'s 32-bit words, then Random._randbelow_with_getrandbits for i = 15..1.  The 624-word state
+// lives in per-lane scratch; outputs are produced by twisting word k on demand, in order, which is the reference generator.
+__global__ void __launch_bounds__(64) k_deal_py_seed(const int64_t *__restrict__ seeds, uint8_t *__restrict__ perms, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t mt[624];
+    const int64_t sd = seeds[i];
+    const uint64_t a = sd < 0 ? (uint64_t)0 - (uint64_t)sd : (uint64_t)sd;
+    const uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+    const int klen = key[1] ? 2 : 1;
+    mt[0] = 19650218u;
+    for (int k = 1; k < 624; k++) mt[k] = 1812433253u * (mt[k - 1] ^ (mt[k - 1] >> 30)) + (uint32_t)k;
+    {
+        int p = 1, j = 0;
+        for (int k = 624; k > 0; k--) {
+            mt[p] = (mt[p] ^ ((mt[p - 1] ^ (mt[p - 1] >> 30)) * 1664525u)) + key[j] + (uint32_t)j;
+            if (++p >= 624) { mt[0] = mt[623]; p = 1; }
+            if (++j >= klen) j = 0;
+        }
+        for (int k = 623; k > 0; k--) {
+            mt[p] = (mt[p] ^ ((mt[p - 1] ^ (mt[p - 1] >> 30)) * 1566083941u)) - (uint32_t)p;
+            if (++p >= 624) { mt[0] = mt[623]; p = 1; }
+        }
+        mt[0] = 0x80000000u;
+    }
+    int at = 0;  // next word to twist + temper
+    uint8_t perm[16];
+    for (int c = 0; c < 16; c++) perm[c] = (uint8_t)c;
+    for (int hi = 15; hi >= 1; hi--) {
+        const uint32_t nn = (uint32_t)hi + 1u;
+        const int bits = 32 - __clz(nn);
+        uint32_t r;
+        do {
+            const int k = at % 624;
+            const uint32_t y0 = (mt[k] & 0x80000000u) | (mt[(k + 1) % 624] & 0x7fffffffu);
+            mt[k] = mt[(k + 397) % 624] ^ (y0 >> 1) ^ ((y0 & 1u) ? 0x9908b0dfu : 0u);
+            uint32_t y = mt[k];
+            at++;
+            y ^= y >> 11; y ^= (y << 7) & 0x9d2c5680u; y ^= (y << 15) & 0xefc60000u; y ^= y >> 18;
+            r = y >> (32 - bits);
+        } while (r >= nn);
+        const uint8_t t = perm[hi]; perm[hi] = perm[r]; perm[r] = t;
+    }
+    for (int c = 0; c < 16; c++) perms[(size_t)i * 16 + c] = perm[c];
+}
+
+extern "C" {
+
+int32_t scopa_multi_destroy(scopa_multi *m);
+
+int32_t scopa_multi_create(scopa_ctx *ctx, int32_t n_deals, scopa_multi **out) {
+    if (!ctx || !out || n_deals <= 0 || n_deals > (1 << 20)) return SCOPA_EINVAL;
+    *out = nullptr;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    scopa_multi *m = new (std::nothrow) scopa_multi();
+    if (!m) return SCOPA_ENOMEM;
+    m->ctx = ctx;
+    m->n = n_deals;
+    const size_t n = (size_t)n_deals;
+    bool ok = hipMalloc(&m->d_perm, n * 16) == hipSuccess && hipMalloc(&m->d_states, n * kNodes * sizeof(scopa_state)) == hipSuccess &&
+              hipMalloc(&m->d_infoset, n * kDecision * 2) == hipSuccess && hipMalloc(&m->d_payoff, n * kTerminal) == hipSuccess &&
+              hipMalloc(&m->d_key, n * kDecision * 8) == hipSuccess && hipMalloc(&m->d_meta, n * 8 * 4) == hipSuccess &&
+              hipMalloc(&m->d_regret, n * kDecision * 32) == hipSuccess && hipMalloc(&m->d_strat, n * kDecision * 32) == hipSuccess &&
+              hipMalloc(&m->d_local, n * kDecision * 32) == hipSuccess && hipMalloc(&m->d_visit, n * kDecision * 4) == hipSuccess &&
+              hipMalloc(&m->d_counters, n * 8 * 8) == hipSuccess && hipMalloc(&m->d_out, n * 4 * 8) == hipSuccess &&
+              hipMalloc(&m->d_seeds, n * 8) == hipSuccess;
+    if (ok) ok = hipMemsetAsync(m->d_counters, 0, n * 64, ctx->stream) == hipSuccess && hipMemsetAsync(m->d_meta, 0, n * 32, ctx->stream) == hipSuccess;
+    if (!ok) { scopa_multi_destroy(m); return fail(ctx, SCOPA_ENOMEM, "scopa_multi_create: device allocation failed"); }
+    *out = m;
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_destroy(scopa_multi *m) {
+    if (!m) return SCOPA_EINVAL;
+    (void)hipSetDevice(m->ctx->device);
+    (void)hipStreamSynchronize(m->ctx->stream);
+    void *bufs[] = {m->d_perm, m->d_states, m->d_infoset, m->d_payoff, m->d_key, m->d_meta, m->d_regret, m->d_strat, m->d_local,
+                    m->d_visit, m->d_counters, m->d_out, m->d_seeds};
+    for (void *b : bufs) if (b) (void)hipFree(b);
+    delete m;
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_deal_py_seeds(scopa_multi *m, const int64_t *h_seeds) {
+    if (!m || !h_seeds) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    SC_HIP(ctx, hipMemcpyAsync(m->d_seeds, h_seeds, (size_t)m->n * 8, hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_deal_py_seed, dim3((m->n + 63) / 64), dim3(64), 0, ctx->stream, m->d_seeds, m->d_perm, m->n);
+    SC_HIP(ctx, hipGetLastError());
+    m->built = false;
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_set_perms(scopa_multi *m, const uint8_t *h_perms) {
+    if (!m || !h_perms) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    for (int d = 0; d < m->n; d++) {
+        uint32_t seen = 0;
+        for (int c = 0; c < 16; c++) { if (h_perms[d * 16 + c] > 15) return fail(ctx, SCOPA_EINVAL, "scopa_multi_set_perms: card id > 15"); seen |= 1u << h_perms[d * 16 + c]; }
+        SC_REQUIRE(ctx, seen == 0xFFFFu, SCOPA_EINVAL, "scopa_multi_set_perms: a row is not a permutation of the 16 cards");
+    }
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    SC_HIP(ctx, hipMemcpyAsync(m->d_perm, h_perms, (size_t)m->n * 16, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->built = false;
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_perms_get(scopa_multi *m, uint8_t *h_perms) {
+    if (!m || !h_perms) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_HIP(ctx, hipMemcpyAsync(h_perms, m->d_perm, (size_t)m->n * 16, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets) {
+    if (!m) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_tree_build, dim3(m->n), dim3(1024), 0, ctx->stream, m->d_perm, m->d_states, m->d_infoset, m->d_payoff, m->d_key, m->d_meta);
+    SC_HIP(ctx, hipGetLastError());
+    hipLaunchKernelGGL(k_tables_reset, dim3(8, m->n), dim3(1024), 0, ctx->stream, m->d_regret, m->d_strat, m->d_local, m->d_key, m->d_meta);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipMemsetAsync(m->d_visit, 0, (size_t)m->n * kDecision * 4, ctx->stream));
+    std::vector<int32_t> meta((size_t)m->n * 8);
+    SC_HIP(ctx, hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    m->max_infosets = 0;
+    for (int d = 0; d < m->n; d++) {
+        const int I = meta[(size_t)d * 8];
+        SC_REQUIRE(ctx, I > 0 && I <= kDecision, SCOPA_EHIP, "scopa_multi_build: a tree build produced a bad infoset count");
+        if (I > m->max_infosets) m->max_infosets = I;
+        if (h_n_infosets) h_n_infosets[d] = I;
+    }
+    m->built = true;
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters) {
+    if (!m || n_iters < 0 || n_iters > (1 << 20)) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_exact_iterate: call scopa_multi_build first");
+    if (!n_iters) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t lds = (size_t)m->max_infosets * 4 * 8 * 3;
+    const size_t static_lds = 1656 * 2 + kTerminal + 9 * 80 + 256;
+    const int use_lds = lds + static_lds <= (size_t)ctx->lds_limit ? 1 : 0;
+    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cfr_exact), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    ctx->lds_limit - (int)static_lds));
+    hipLaunchKernelGGL(k_cfr_exact, dim3(m->n), dim3(256), use_lds ? lds : 0, ctx->stream, m->d_infoset, m->d_payoff, m->d_regret, m->d_strat,
+                       m->d_local, 0 /* multi-deal */, n_iters * 2, 0, (double *)nullptr, m->d_counters, use_lds, m->d_visit, m->d_meta, 0, 0, 1.0, 1.0);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_cfr_sync_iterate(scopa_multi *m, int32_t n_iters) {
+    if (!m || n_iters < 0 || n_iters > (1 << 20)) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_sync_iterate: call scopa_multi_build first");
+    if (!n_iters) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t lds = (size_t)m->max_infosets * 4 * 8 * 2 + sizeof(double) * kNodes * 3 + 1656 * 2;
+    SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_multi_cfr_sync_iterate: a deal's tables do not fit in LDS");
+    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cfr_sync), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+    hipLaunchKernelGGL(k_cfr_sync, dim3(m->n), dim3(1024), lds, ctx->stream, m->d_infoset, m->d_payoff, m->d_key, m->d_regret, m->d_strat,
+                       0 /* multi-deal */, (int)n_iters, m->d_counters, m->d_visit, m->d_meta);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_exploitability(scopa_multi *m, double *h_out4) {
+    if (!m || !h_out4) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_exploitability: call scopa_multi_build first");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t lds = (size_t)m->max_infosets * 4 * 8 * 2 + sizeof(double) * kNodes * 2 + sizeof(int) * (size_t)m->max_infosets + 1656 * 2;
+    SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_multi_exploitability: tables do not fit in LDS");
+    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_exploitability), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+    hipLaunchKernelGGL(k_exploitability, dim3(m->n), dim3(1024), lds, ctx->stream, m->d_infoset, m->d_payoff, m->d_key, m->d_strat,
+                       (const double *)nullptr, -m->max_infosets, m->d_out, (double *)nullptr, m->d_meta);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipMemcpyAsync(h_out4, m->d_out, (size_t)m->n * 32, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_tables_get(scopa_multi *m, int32_t deal, double *h_regret, double *h_strategy, double *h_local, uint64_t *h_keys) {
+    if (!m || deal < 0 || deal >= m->n) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_tables_get: call scopa_multi_build first");
+    int32_t I = 0;
+    SC_HIP(ctx, hipMemcpyAsync(&I, m->d_meta + (size_t)deal * 8, 4, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t off = (size_t)deal * kDecision * 4, bytes = (size_t)I * 32;
+    if (h_regret) SC_HIP(ctx, hipMemcpyAsync(h_regret, m->d_regret + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_strategy) SC_HIP(ctx, hipMemcpyAsync(h_strategy, m->d_strat + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_local) SC_HIP(ctx, hipMemcpyAsync(h_local, m->d_local + off, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    if (h_keys) SC_HIP(ctx, hipMemcpyAsync(h_keys, m->d_key + (size_t)deal * kDecision, (size_t)I * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_counters(scopa_multi *m, uint64_t *decision_visits, uint64_t *terminal_visits) {
+    if (!m) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    std::vector<unsigned long long> h((size_t)m->n * 8);
+    SC_HIP(ctx, hipMemcpyAsync(h.data(), m->d_counters, h.size() * 8, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    unsigned long long a = 0, b = 0;
+    for (int d = 0; d < m->n; d++) { a += h[(size_t)d * 8]; b += h[(size_t)d * 8 + 1]; }
+    if (decision_visits) *decision_visits = a;
+    if (terminal_visits) *terminal_visits = b;
+    return SCOPA_OK;
+}
+
+}  // extern "C"

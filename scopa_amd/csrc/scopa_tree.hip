@@ -49,6 +49,11 @@ __global__ void __launch_bounds__(1024) k_tree_build(const uint8_t *__restrict__
     __shared__ int s_first[kDecision];         // per decision node (BFS): DFS index of the first node sharing its key
     __shared__ int s_scan[kNodes + 1];         // indexed by DFS index: 1 where an infoset is first visited -> prefix sum
     const int tid = threadIdx.x, nt = blockDim.x;
+    {   // one workgroup per deal (multi-deal mode launches a grid of them; a single context uses deal 0)
+        const size_t deal = blockIdx.x;
+        perm16 += deal * 16; states += deal * kNodes; infoset_of += deal * kDecision; payoff += deal * kTerminal;
+        key_of_infoset += deal * kDecision; meta += deal * 8;
+    }
 
     for (int i = tid; i <= kNodes; i += nt) s_scan[i] = 0;
     if (tid == 0) {
@@ -127,7 +132,12 @@ __global__ void __launch_bounds__(1024) k_tree_build(const uint8_t *__restrict__
 
 __global__ void k_tables_reset(double *regret, double *strat, double *local, const uint64_t *key_of_infoset,
                                const int32_t *meta) {
-    // InfoNode.__post_init__ (vanilla_cfr.py:15-21): zeros, local_strategy = ones(n)/n
+    // InfoNode.__post_init__ (vanilla_cfr.py:15-21): zeros, local_strategy = ones(n)/n.  blockIdx.y = deal.
+    {
+        const size_t deal = blockIdx.y;
+        regret += deal * kDecision * 4; strat += deal * kDecision * 4; local += deal * kDecision * 4;
+        key_of_infoset += deal * kDecision; meta += deal * 8;
+    }
     const int I = meta[0];
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < kDecision * 4; i += gridDim.x * blockDim.x) {
         const int row = i >> 2, col = i & 3;

@@ -1,0 +1,68 @@
+"""Multi-deal mode: n independent deals, one workgroup per deal -- deal on device, tree build, exact and synchronous
+CFR, exploitability -- each deal checked against the oracle / the reference fixtures."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def test_device_deal_matches_cpython_shuffle(ctx, sl, golden):
+    deals = golden.json("deals.json")
+    seeds = [int(s) for s in deals]
+    m = sl.MultiDeal(ctx, len(seeds))
+    m.deal_py_seeds(seeds)
+    perms = m.perms()
+    for i, s in enumerate(seeds):
+        assert list(perms[i]) == deals[str(s)], s
+    m.close()
+
+
+def test_multi_deal_solvers_match_oracle_per_deal(ctx, sl, oracle, golden):
+    seeds = [42, 0, 1, 7, 123, 282, 129, 5, 6, 8, 9, 10]
+    m = sl.MultiDeal(ctx, len(seeds))
+    m.deal_py_seeds(seeds)
+    ninf = m.build()
+    trees = [oracle.Tree(seed=s) for s in seeds]
+    assert list(ninf) == [t.n_infosets for t in trees]
+    m.cfr_exact_iterate(3)
+    expl = m.exploitability()
+    for i, t in enumerate(trees):
+        R, S, L = t.tables()
+        t.cfr_exact(R, S, L, 3)
+        Rg, Sg, Lg, K = m.tables_get(i)
+        assert np.array_equal(Rg, R) and np.array_equal(Sg, S) and np.array_equal(Lg, L), seeds[i]
+        assert [sl.key_to_string(k) for k in K] == t.infoset_strings
+        e, br = t.exploitability(t.average_policy(S))
+        assert (expl[i, 0], expl[i, 1], expl[i, 2], expl[i, 3]) == (e, br[0], br[1], t.policy_value(t.average_policy(S)))
+    assert m.counters() == (3306 * 3 * len(seeds), 1152 * 3 * len(seeds))
+    # deal 0 is the reference's deal: its tables are the reference's (golden fixture), too
+    g = golden.npz("vanilla_cfr.npz")
+    m2 = sl.MultiDeal(ctx, 3)
+    m2.deal_py_seeds([42, 42, 42])
+    m2.build()
+    m2.cfr_exact_iterate(5)
+    for i in range(3):
+        R, S, L, _ = m2.tables_get(i)
+        assert np.array_equal(R, g["it5_regret"]) and np.array_equal(S, g["it5_strategy"]) and np.array_equal(L, g["it5_local"])
+    m.close(); m2.close()
+
+
+def test_multi_deal_sync_cfr_many_deals(ctx, sl, oracle):
+    n = 600                                   # more deals than CUs: the grid wraps
+    rng = np.random.RandomState(2)
+    perms = np.array([rng.permutation(16) for _ in range(n)], np.uint8)
+    m = sl.MultiDeal(ctx, n)
+    m.set_perms(perms)
+    ninf = m.build()
+    m.cfr_sync_iterate(20)
+    expl = m.exploitability()
+    assert (expl[:, 0] >= 0).all() and (expl[:, 0] < 1.5).all()
+    for i in (0, 17, 599):
+        t = oracle.Tree(perm=perms[i])
+        assert ninf[i] == t.n_infosets
+        R, S, _ = t.tables()
+        t.cfr_sync(R, S, 20)
+        Rg, Sg, _, _ = m.tables_get(i)
+        assert np.array_equal(Rg, R) and np.array_equal(Sg, S)
+        assert expl[i, 0] == t.exploitability(t.average_policy(S))[0]
+    m.close()
