@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--graph", action="store_true", help="replay the optimiser step as a HIP graph")
     args = ap.parse_args()
     import torch
     import torch.distributed as dist
@@ -31,7 +32,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.manual_seed(0)
-    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=args.batch, rank=rank, world=world)
+    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=args.batch, rank=rank, world=world, graph_training=args.graph)
     ctx = d._engine.ctx
 
     def one_iter(train=True):

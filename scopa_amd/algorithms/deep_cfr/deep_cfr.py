@@ -58,8 +58,10 @@ class DeviceMemory:
 class AdvantageNetwork:
     """Advantage net + Adam + memory for one player (deep_cfr.py:24-116)."""
 
-    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4, memory_size=100000):
+    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4, memory_size=100000, use_graph=False):
         self.device = device
+        self.use_graph = use_graph   # replay the optimiser step as one HIP graph (same ops, ~10x less launch overhead)
+        self._graphs = {}            # batch_size -> (graph, static index tensor, static loss tensor)
         self.num_actions = num_actions
         self.net = FlexibleNet(mode="mlp", input_shape=(input_dim,), output_dim=num_actions, mlp_hidden=HIDDEN,
                                mlp_act="relu", mlp_norm="none", mlp_dropout=0.0).to(device)
@@ -67,7 +69,7 @@ class AdvantageNetwork:
             if isinstance(layer, nn.Linear):
                 nn.init.xavier_uniform_(layer.weight)
                 nn.init.constant_(layer.bias, 0.1)
-        self.optimizer = optim.Adam(self.net.parameters(), lr=lr)
+        self.optimizer = optim.Adam(self.net.parameters(), lr=lr, capturable=bool(use_graph))
         self.criterion = nn.MSELoss()
         self.buffer = DeviceMemory(memory_size, input_dim, device)
         self._rng = random.Random()
@@ -96,20 +98,64 @@ class AdvantageNetwork:
                 return 0.0
         self._rng.seed(42)
         self._rng.shuffle(list(range(16)))
+        if self.use_graph and self.grad_sync is None:
+            return self._train_graphed(n, batch_size, epochs)
         total_loss = 0.0
         for _ in range(epochs):
             idx = torch.tensor(self.sample_indices(n, batch_size), device=self.device)
-            states, target_adv, masks = self.buffer.rows(idx)
-            self.optimizer.zero_grad()
-            pred_adv = self.net(states)
-            loss = self.criterion(pred_adv * masks, target_adv * masks)
-            loss.backward()
-            if self.grad_sync is not None:
-                self.grad_sync(self.net.parameters())
-            torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm=1.0)
-            self.optimizer.step()
-            total_loss += loss.item()
+            total_loss += self._step(self.buffer.logical_to_physical(idx)).item()
         return total_loss / epochs
+
+    def _step(self, rows):
+        """One optimiser step on the ring rows `rows` (deep_cfr.py:99-112); returns the loss tensor."""
+        states, target_adv, masks = self.buffer.feat[rows], self.buffer.regret[rows], self.buffer.mask[rows]
+        self.optimizer.zero_grad(set_to_none=False)
+        pred_adv = self.net(states)
+        loss = self.criterion(pred_adv * masks, target_adv * masks)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.net.parameters())
+        torch.nn.utils.clip_grad_norm_(self.net.parameters(), max_norm=1.0)
+        self.optimizer.step()
+        return loss
+
+    def _train_graphed(self, n, batch_size, epochs):
+        """The same step, captured once per batch size into a HIP graph and replayed with fresh row indices."""
+        if batch_size not in self._graphs:
+            rows = torch.zeros(batch_size, dtype=torch.long, device=self.device)
+            side = torch.cuda.Stream(device=self.device)
+            side.wait_stream(torch.cuda.current_stream())
+            # warm-up + capture run real optimiser steps: snapshot parameters and Adam state BY VALUE first and restore
+            # them IN PLACE afterwards (the graph keeps pointing at these very tensors), so capturing changes nothing
+            params = list(self.net.parameters())
+            saved_p = [p.detach().clone() for p in params]
+            saved_s = {i: {k: v.clone() for k, v in self.optimizer.state[p].items() if torch.is_tensor(v)}
+                       for i, p in enumerate(params) if p in self.optimizer.state}
+            with torch.cuda.stream(side):
+                for _ in range(3):
+                    self._step(rows)
+            torch.cuda.current_stream().wait_stream(side)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                loss = self._step(rows)
+            with torch.no_grad():
+                for i, p in enumerate(params):
+                    p.copy_(saved_p[i])
+                    for k, v in self.optimizer.state[p].items():
+                        if torch.is_tensor(v):
+                            if i in saved_s and k in saved_s[i]:
+                                v.copy_(saved_s[i][k])
+                            else:
+                                v.zero_()   # a fresh optimiser: moments and step count start at zero
+            self._graphs[batch_size] = (g, rows, loss)
+        g, rows, loss = self._graphs[batch_size]
+        losses = []
+        for _ in range(epochs):
+            idx = torch.tensor(self.sample_indices(n, batch_size), device=self.device)
+            rows.copy_(self.buffer.logical_to_physical(idx))
+            g.replay()
+            losses.append(loss.clone())
+        return float(torch.stack(losses).sum().item()) / epochs
 
 
 class StrategyBuffer:
@@ -158,7 +204,7 @@ class DeepCFR:
     """`DeepCFR(game, num_players=2, device="cuda").train(iterations, advantage_epochs, eval_freq)`."""
 
     def __init__(self, game, num_players=2, device="cuda", batch=1, seed=0x5C09A, stream=None, rank=0, world=1,
-                 memory_size=None):
+                 memory_size=None, graph_training=False):
         """rank/world: data parallelism over torch.distributed (one process per GPU).  Each rank traverses `batch`
         traversals with global ids [rank*batch, (rank+1)*batch) into its own memory ring and the advantage-net
         gradients are averaged with one all-reduce per optimiser step (55 104 B), so every replica's nets stay equal."""
@@ -181,7 +227,8 @@ class DeepCFR:
                 memory_size = max(100000, 8 * ROWS_PER_TRAVERSAL * self.batch)
             if memory_size < ROWS_PER_TRAVERSAL * self.batch:
                 raise ValueError("memory_size must hold at least one batch of traversals (41 rows each)")
-            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device, memory_size=memory_size) for _ in range(num_players)]
+            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device, memory_size=memory_size, use_graph=graph_training)
+                                   for _ in range(num_players)]
         self.strategy_buffers = [StrategyBuffer() for _ in range(num_players)]
         self.training_history = {"losses": [[] for _ in range(num_players)], "values": [[] for _ in range(num_players)],
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}
