@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--epochs", type=int, default=5)
+    ap.add_argument("--ply-by-ply", action="store_true", help="use the level-synchronous multi-launch traversal instead of the fused kernel")
     ap.add_argument("--graph", action="store_true", help="replay the optimiser step as a HIP graph")
     args = ap.parse_args()
     import torch
@@ -32,7 +33,7 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
     torch.manual_seed(0)
-    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=args.batch, rank=rank, world=world, graph_training=args.graph)
+    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=args.batch, rank=rank, world=world, graph_training=args.graph, fused_traversal=not args.ply_by_ply)
     ctx = d._engine.ctx
 
     def one_iter(train=True):

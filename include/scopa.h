@@ -182,6 +182,13 @@ int32_t scopa_sdcfr_backward(scopa_ctx *ctx, int32_t ply, int32_t traverser, int
                              const float *d_child_val, float *d_val, const float *d_feats, const float *d_mask, float *d_mem_feat,
                              float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base);
 int32_t scopa_sdcfr_visits(scopa_ctx *ctx, uint64_t *decision_visits);
+/* The same traversal as ONE launch: one wavefront per traversal, both players' advantage MLPs (34-128-64-16 float32) resident
+ * in LDS and evaluated in-kernel.  d_weights[2][13776]: per player W1^T[34][128] | b1[128] | W2^T[128][64] | b2[64] |
+ * W3^T[64][16] | b3[16].  d_uniforms (optional, tests): [batch][8][24] float64 draws indexed (traversal, ply, slot).
+ * Samples the same actions as the ply-by-ply path (same Philox keying); float32 sums run in a different order. */
+int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_weights, float *d_mem_feat,
+                                   float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
+                                   float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0);
 /* features / masks of arbitrary device-resident states for the player to move (DeepCFR.get_policy, :497-504) */
 int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask);
 /* batched evaluation episodes (evaluate_vs_random :367-429; evaluate_agent vanilla_cfr.py:157-216): n copies of the deal's

@@ -24,7 +24,7 @@ SYMBOLS = [
     "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
-    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_features_from_states",
+    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
     "scopa_multi_cfr_sync_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
@@ -119,6 +119,7 @@ def lib():
         "scopa_sdcfr_terminal_values": (i32, [vp, i32, i64, vp, vp]),
         "scopa_sdcfr_backward": (i32, [vp, i32, i32, i64, vp, vp, vp, vp, vp, vp, vp, vp, vp, i64, i64]),
         "scopa_sdcfr_visits": (i32, [vp, C.POINTER(u64)]),
+        "scopa_sdcfr_traverse_fused": (i32, [vp, i32, i32, vp, vp, vp, vp, i64, i64, vp, vp, u32, u32]),
         "scopa_features_from_states": (i32, [vp, vp, i64, vp, vp]),
         "scopa_eval_init_states": (i32, [vp, vp, i64]),
         "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
@@ -351,6 +352,13 @@ class Context:
         self._ck(self._L.scopa_sdcfr_backward(self._h, ply, traverser, n, vp(idx_ptr), vp(pol_ptr), vp(child_val_ptr), vp(val_ptr), vp(feats_ptr),
                                               vp(mask_ptr), vp(mem_feat_ptr), vp(mem_regret_ptr), vp(mem_mask_ptr), capacity, write_base),
                  "scopa_sdcfr_backward")
+
+    def sdcfr_traverse_fused(self, traverser, batch, weights_ptr, mem_feat_ptr, mem_regret_ptr, mem_mask_ptr, capacity, write_base,
+                             root_values_ptr, uniforms_ptr, iteration, b0):
+        self._ck(self._L.scopa_sdcfr_traverse_fused(self._h, traverser, batch, C.c_void_p(weights_ptr), C.c_void_p(mem_feat_ptr),
+                                                    C.c_void_p(mem_regret_ptr), C.c_void_p(mem_mask_ptr), capacity, write_base,
+                                                    C.c_void_p(root_values_ptr), C.c_void_p(uniforms_ptr) if uniforms_ptr else None,
+                                                    iteration, b0), "scopa_sdcfr_traverse_fused")
 
     def sdcfr_visits(self):
         v = C.c_uint64()

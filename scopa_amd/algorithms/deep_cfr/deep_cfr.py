@@ -204,7 +204,7 @@ class DeepCFR:
     """`DeepCFR(game, num_players=2, device="cuda").train(iterations, advantage_epochs, eval_freq)`."""
 
     def __init__(self, game, num_players=2, device="cuda", batch=1, seed=0x5C09A, stream=None, rank=0, world=1,
-                 memory_size=None, graph_training=False):
+                 memory_size=None, graph_training=False, fused_traversal=None):
         """rank/world: data parallelism over torch.distributed (one process per GPU).  Each rank traverses `batch`
         traversals with global ids [rank*batch, (rank+1)*batch) into its own memory ring and the advantage-net
         gradients are averaged with one all-reduce per optimiser step (55 104 B), so every replica's nets stay equal."""
@@ -234,6 +234,9 @@ class DeepCFR:
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}
         self._iteration = 0
         self._eval_calls = 0
+        # None = automatic: the one-launch kernel wins while the ply-by-ply path is launch-bound (measured crossover ~8k
+        # traversals per batch on MI355X: beyond it rocBLAS GEMMs beat the LDS-bound in-kernel MLP)
+        self.fused_traversal = (self.batch <= 8192) if fused_traversal is None else bool(fused_traversal)
         self.rank, self.world = int(rank), int(world)
         if self.world > 1:
             import torch.distributed as dist
@@ -274,10 +277,44 @@ class DeepCFR:
         return mask
 
     # ---- the traversal ----------------------------------------------------------------------------------------------
-    def _traverse_batch(self, player, batch, uniforms=None, advantage_fn=None):
+    def _packed_weights(self):
+        """Both players' nets as the fused kernel wants them: per net W1^T | b1 | W2^T | b2 | W3^T | b3 (float32)."""
+        parts = []
+        for a in self.advantage_nets:
+            sd = a.net.state_dict()
+            for w, b in (("backbone.0.fc.weight", "backbone.0.fc.bias"), ("backbone.1.fc.weight", "backbone.1.fc.bias"),
+                         ("head.weight", "head.bias")):
+                parts += [sd[w].t().reshape(-1), sd[b].reshape(-1)]
+        return torch.cat(parts).to(torch.float32).contiguous()
+
+    def _traverse_batch_fused(self, player, batch, uniforms=None):
+        """One launch: k_sdcfr_traverse (one wavefront per traversal, both MLPs in LDS)."""
+        ctx, dev = self._engine.ctx, self.device
+        mem = self.advantage_nets[player].buffer
+        with torch.cuda.stream(self._stream), torch.no_grad():
+            w = self._packed_weights()
+            vals = torch.empty(batch, dtype=torch.float32, device=dev)
+            u = None
+            if uniforms is not None:   # {ply: [batch * width]} -> [batch][8][24]
+                u = torch.zeros((batch, 8, 24), dtype=torch.float64, device=dev)
+                for ply, t in uniforms.items():
+                    wd = t.numel() // batch
+                    u[:, ply, :wd] = t.view(batch, wd)
+            ctx.sdcfr_traverse_fused(player, batch, w.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), mem.mask.data_ptr(),
+                                     mem.capacity, mem.write_base, vals.data_ptr(), u.data_ptr() if u is not None else 0,
+                                     self._iteration, self.rank * batch)
+            mem.advance(batch * ROWS_PER_TRAVERSAL)
+        self._stream.synchronize()
+        return vals
+
+    def _traverse_batch(self, player, batch, uniforms=None, advantage_fn=None, fused=None):
         """`batch` external-sampling traversals for `player` from the root; returns the root values [batch] (float32).
         uniforms: optional {ply: float64 tensor [n]} of draws for the opponent plies (replay / tests);
-        advantage_fn(cur_player, feats, mask) -> raw advantages, default the current nets."""
+        advantage_fn(cur_player, feats, mask) -> raw advantages, default the current nets (forces the ply-by-ply path)."""
+        if fused is None:
+            fused = self.fused_traversal
+        if fused and advantage_fn is None:
+            return self._traverse_batch_fused(player, batch, uniforms)
         ctx, dev = self._engine.ctx, self.device
         mem = self.advantage_nets[player].buffer
         with torch.cuda.stream(self._stream), torch.no_grad():

@@ -290,3 +290,243 @@ int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const 
 }
 
 }  // extern "C"
+
+// =====================================================================================================================
+// Fused traversal: ONE launch per traversal batch instead of ~65 (8 plies x {features, 3 GEMMs + activations, expand} +
+// 8 backward steps).  One WAVEFRONT walks one traversal level-synchronously; both players' advantage MLPs
+// (34-128-64-16, float32, 13 776 parameters = 55 KB each) sit in LDS for the whole launch and the forward pass of the
+// <= 24 frontier nodes of a ply runs inside the wave, four nodes at a time:
+//   layer 1  sparse: the input is one-hot/multi-hot (<= 4 hand cards, <= 8 table cards, one constant), so a hidden unit is
+//            b1 + a handful of weight columns -- no multiplies;  each lane owns hidden units lane and lane+64
+//   layer 2  each lane owns one of the 64 units for the four nodes: 128 x (one weight read + one float4 broadcast read + 4 FMA)
+//   layer 3  lane = node*16 + output;  regret matching needs sum(relu(adv)*mask) over a node's 16 lanes: 4 shuffles
+// then expand / sample exactly as k_sdcfr_expand does (same Philox keying, so the two paths sample identical actions), and
+// after ply 7 the values flow back up inside the wave with the memory rows written straight to the caller's ring.
+// Weights per net, as one float32 buffer: W1^T [34][128] | b1 [128] | W2^T [128][64] | b2 [64] | W3^T [64][16] | b3 [16].
+namespace {
+constexpr int kNetFloats = 34 * 128 + 128 + 128 * 64 + 64 + 64 * 16 + 16;  // 13 776
+constexpr int kW1 = 0, kB1 = 34 * 128, kW2 = kB1 + 128, kB2 = kW2 + 128 * 64, kW3 = kB2 + 64, kB3 = kW3 + 64 * 16;
+
+struct SdWave {               // per-wavefront scratch
+    float h1[128][4];         // hidden layer 1 of the four nodes in flight
+    float h2[64][4];
+    float pol_trav[41][4];    // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
+    float val[2][24];
+    float polcur[4][4];
+    scopa_state st[4];        // packed states of the four nodes in flight
+    uint16_t idx[9][24];      // tree index of every frontier node, per ply (ply 8 = leaves)
+    uint16_t pad[8];
+};
+static_assert(sizeof(SdWave) % 16 == 0, "SdWave alignment");
+
+__device__ __forceinline__ void sd_sync() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+}  // namespace
+
+__global__ void __launch_bounds__(640)
+k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_weights,
+                 int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
+                 long long capacity, long long write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
+                 uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                           // [2][kNetFloats]
+    SdWave *s_wave = reinterpret_cast<SdWave *>(s_w + 2 * kNetFloats);      // [wavefronts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    for (int i = tid; i < 2 * kNetFloats / 4; i += blockDim.x)
+        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_weights)[i];
+    __syncthreads();
+    SdWave &ws = s_wave[wave];
+
+    for (int tb = blockIdx.x * n_waves + wave; tb < batch; tb += gridDim.x * n_waves) {
+        if (lane == 0) ws.idx[0][0] = 0;
+        sd_sync();
+        int width = 1;
+        // ---- forward: plies 0..7 ----------------------------------------------------------------------------------------
+#pragma unroll 1
+        for (int d = 0; d < kPlies; d++) {
+            const int p = d & 1, nl = 4 - (d >> 1);
+            const bool trav_ply = p == traverser;
+            const float *W = s_w + p * kNetFloats;
+            const int m = (d - traverser) >> 1;                       // traverser-ply index when trav_ply
+            const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
+            for (int g0 = 0; g0 < width; g0 += 4) {
+                // the group's four packed states: one global load per node, then LDS broadcasts for every phase below
+                if (lane < 4 && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[d][g0 + lane]];
+                sd_sync();
+                // layer 1 (sparse): hidden units lane, lane + 64 for up to four nodes.  Static, predicated loops: all
+                // weight-column reads of a node are independent and can be in flight together.
+                float a0[4], a1[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) {
+                    const bool liveq = g0 + q < width;
+                    const scopa_state s = ws.st[q];
+                    const int nh = liveq ? s.nh[p] : 0, nt = liveq ? s.nt : 0;
+                    float x0 = W[kB1 + lane] + W[kW1 + 32 * 128 + lane];           // bias + feature 32 (1.0); feature 33 is 0.0
+                    float x1 = W[kB1 + 64 + lane] + W[kW1 + 32 * 128 + 64 + lane];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int c = nib(s.hand[p], k) & 15;
+                        const float w0 = W[kW1 + c * 128 + lane], w1 = W[kW1 + c * 128 + 64 + lane];
+                        if (k < nh) { x0 += w0; x1 += w1; }
+                    }
+#pragma unroll
+                    for (int k = 0; k < 8; k++) {
+                        const int c = 16 + (nib(s.table, k) & 15);
+                        const float w0 = W[kW1 + c * 128 + lane], w1 = W[kW1 + c * 128 + 64 + lane];
+                        if (k < nt) { x0 += w0; x1 += w1; }
+                    }
+                    a0[q] = x0; a1[q] = x1;
+                }
+                *reinterpret_cast<float4 *>(ws.h1[lane]) = make_float4(fmaxf(a0[0], 0.0f), fmaxf(a0[1], 0.0f), fmaxf(a0[2], 0.0f), fmaxf(a0[3], 0.0f));
+                *reinterpret_cast<float4 *>(ws.h1[lane + 64]) = make_float4(fmaxf(a1[0], 0.0f), fmaxf(a1[1], 0.0f), fmaxf(a1[2], 0.0f), fmaxf(a1[3], 0.0f));
+                sd_sync();
+                // layer 2: hidden unit `lane` for the four nodes
+                float4 acc = make_float4(W[kB2 + lane], W[kB2 + lane], W[kB2 + lane], W[kB2 + lane]);
+#pragma unroll 8
+                for (int i = 0; i < 128; i++) {
+                    const float w = W[kW2 + i * 64 + lane];
+                    const float4 h = *reinterpret_cast<const float4 *>(ws.h1[i]);
+                    acc.x = fmaf(w, h.x, acc.x); acc.y = fmaf(w, h.y, acc.y); acc.z = fmaf(w, h.z, acc.z); acc.w = fmaf(w, h.w, acc.w);
+                }
+                *reinterpret_cast<float4 *>(ws.h2[lane]) = make_float4(fmaxf(acc.x, 0.0f), fmaxf(acc.y, 0.0f), fmaxf(acc.z, 0.0f), fmaxf(acc.w, 0.0f));
+                sd_sync();
+                // layer 3: lane = node q * 16 + output o
+                const int q = lane >> 4, o = lane & 15;
+                float adv = W[kB3 + o];
+#pragma unroll 8
+                for (int i = 0; i < 64; i++) adv = fmaf(W[kW3 + i * 16 + o], ws.h2[i][q], adv);
+                // positive_regret_policy over the node's 16 outputs (nets.py:93-101)
+                const bool live = g0 + q < width;
+                const scopa_state s = ws.st[q];
+                uint32_t hand_bits = 0;
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (live && k < nl) hand_bits |= 1u << nib(s.hand[p], k);
+                const float pos = (live && ((hand_bits >> o) & 1u) && adv > 0.0f) ? adv : 0.0f;
+                float z = pos;
+                z += __shfl_xor(z, 8); z += __shfl_xor(z, 4); z += __shfl_xor(z, 2); z += __shfl_xor(z, 1);
+                const float prob = pos / (z > 1e-8f ? z : 1e-8f);
+#pragma unroll
+                for (int k = 0; k < 4; k++) if (live && k < nl && nib(s.hand[p], k) == o) ws.polcur[q][k] = prob;
+                sd_sync();
+                // expand / sample: one lane per node of the group
+                if (lane < 4 && g0 + lane < width) {
+                    const int j = g0 + lane, idx = ws.idx[d][j];
+                    float pk[4];
+                    for (int k = 0; k < 4; k++) pk[k] = k < nl ? ws.polcur[lane][k] : 0.0f;
+                    if (trav_ply) {
+                        for (int k = 0; k < nl; k++) ws.idx[d + 1][j * nl + k] = (uint16_t)(idx * nl + k);
+                        for (int k = 0; k < 4; k++) ws.pol_trav[moff + j][k] = pk[k];
+                    } else {
+                        float sum = pk[0];
+                        for (int k = 1; k < nl; k++) sum += pk[k];
+                        double u;
+                        if (uniforms) u = uniforms[((size_t)tb * kPlies + d) * 24 + j];
+                        else {
+                            const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)tb, iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
+                            u = u53(x.x0, x.x1);
+                        }
+                        int a;
+                        if (sum == 0.0f) { a = (int)(u * (double)nl); a = a < nl - 1 ? a : nl - 1; }
+                        else {
+                            double c = 0.0, cdf[4];
+                            for (int k = 0; k < nl; k++) { const double pq = (double)(pk[k] / sum); c = k ? c + pq : pq; cdf[k] = c; }
+                            const double last = cdf[nl - 1];
+                            a = 0;
+                            for (int k = 0; k < nl; k++) if (cdf[k] / last <= u) a = k + 1;
+                            a = a < nl - 1 ? a : nl - 1;
+                        }
+                        ws.idx[d + 1][j] = (uint16_t)(idx * nl + a);
+                    }
+                }
+                sd_sync();
+            }
+            if (trav_ply) width *= nl;
+        }
+        // ---- leaves, then backward ---------------------------------------------------------------------------------------
+        if (lane < width) { const int p0 = g_payoff[ws.idx[8][lane]]; ws.val[0][lane] = 0.5f * (float)(traverser == 0 ? p0 : -p0); }
+        sd_sync();
+        int cur = 0;
+#pragma unroll 1
+        for (int d = kPlies - 1; d >= 0; d--) {
+            const int p = d & 1, nl = 4 - (d >> 1);
+            const bool trav_ply = p == traverser;
+            if (trav_ply) width /= nl;
+            const int m = (d - traverser) >> 1;
+            const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
+            if (lane < width) {
+                const int j = lane;
+                if (!trav_ply) ws.val[cur ^ 1][j] = ws.val[cur][j];
+                else {
+                    const scopa_state s = g_states[level_offset(d) + ws.idx[d][j]];
+                    float value = 0.0f, cfv[16];
+                    for (int c = 0; c < 16; c++) cfv[c] = 0.0f;
+                    uint32_t hand_bits = 0, table_bits = 0;
+                    for (int k = 0; k < nl; k++) {
+                        const float av = ws.val[cur][j * nl + k];
+                        value += ws.pol_trav[moff + j][k] * av;
+                        const int c = nib(s.hand[p], k);
+                        hand_bits |= 1u << c;
+#pragma unroll
+                        for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
+                    }
+                    for (int k = 0; k < s.nt; k++) table_bits |= 1u << nib(s.table, k);
+                    ws.val[cur ^ 1][j] = value;
+                    float mx = 0.0f, reg[16];
+#pragma unroll
+                    for (int c = 0; c < 16; c++) { reg[c] = cfv[c] - value; const float a = fabsf(reg[c]); mx = a > mx ? a : mx; }
+                    const float den = mx + 1e-8f;
+                    const int T[4] = {41, 10, 3, 1};
+                    int jj = j, rank = T[m] - 1;
+                    for (int qd = m - 1; qd >= 0; qd--) { const int radix = 4 - qd; rank += (jj % radix) * T[qd + 1]; jj /= radix; }
+                    const long long row = (write_base + (long long)tb * 41 + rank) % capacity;
+#pragma unroll
+                    for (int c = 0; c < 16; c++) {
+                        const float h = (float)((hand_bits >> c) & 1u);
+                        mem_feat[row * 34 + c] = h;
+                        mem_feat[row * 34 + 16 + c] = (float)((table_bits >> c) & 1u);
+                        mem_mask[row * 16 + c] = h;
+                        mem_regret[row * 16 + c] = mx > 0.0f ? reg[c] / den : reg[c];
+                    }
+                    mem_feat[row * 34 + 32] = 1.0f;
+                    mem_feat[row * 34 + 33] = 0.0f;
+                }
+            }
+            cur ^= 1;
+            sd_sync();
+        }
+        if (lane == 0) root_values[tb] = ws.val[cur][0];
+        sd_sync();
+    }
+}
+
+extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_weights, float *d_mem_feat,
+                                              float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
+                                              float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0) {
+    if (!ctx || traverser < 0 || traverser > 1 || batch < 0 || (batch && (!d_weights || !d_mem_feat || !d_mem_regret || !d_mem_mask || !d_root_values)))
+        return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_traverse_fused: no deal set");
+    SC_REQUIRE(ctx, capacity >= 41 && (int64_t)batch * 41 <= capacity && write_base >= 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: memory ring too small for the batch");
+    SC_REQUIRE(ctx, ((uintptr_t)d_weights & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: weights must be 16-byte aligned");
+    if (!batch) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const int waves = 10, threads = waves * 64;  // 110 KB of weights + 10 x 4.5 KB of wave scratch
+    const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
+    SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
+    static bool attr_set = false;
+    if (!attr_set) {
+        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sdcfr_traverse), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
+        attr_set = true;
+    }
+    const int passes = (batch + waves - 1) / waves;
+    const int grid = passes < ctx->n_cus ? passes : ctx->n_cus;
+    hipLaunchKernelGGL(k_sdcfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_states, ctx->d_payoff, d_weights, (int)traverser,
+                       (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, d_root_values, d_uniforms,
+                       (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
+    SC_HIP(ctx, hipGetLastError());
+    ctx->sdcfr_visits += (uint64_t)batch * (traverser == 0 ? 105 : 82);
+    return SCOPA_OK;
+}

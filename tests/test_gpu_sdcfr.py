@@ -194,3 +194,48 @@ def test_graphed_training_step_matches_eager(ctx, golden):
     assert abs(loss - float(g["train_loss_p0_epochs2"][0])) < 1e-5
     for k, v in d.advantage_nets[0].net.state_dict().items():
         np.testing.assert_allclose(v.cpu().numpy(), g[f"net0_after__{k}"], atol=2e-5, rtol=0)
+
+
+@pytest.mark.parametrize("trav", [0, 1])
+def test_fused_traversal_matches_ply_by_ply_path(dcfr, trav):
+    """k_sdcfr_traverse (one launch, MLP in LDS) vs the ply-by-ply path (PyTorch MLP): same Philox draws -> the same
+    sampled actions, identical features/masks/row order, float32 values within 2e-5."""
+    import torch
+    d, _ = dcfr
+    B = 300
+    v_ref = d._traverse_batch(trav, B, fused=False)
+    mem = d.advantage_nets[trav].buffer
+    fa, ra, ma = (t.clone() for t in mem.rows(torch.arange(B * 41, device="cuda:0")))
+    mem.total = 0
+    v0 = d._engine.ctx.sdcfr_visits()
+    v_fused = d._traverse_batch(trav, B, fused=True)
+    assert d._engine.ctx.sdcfr_visits() - v0 == (105, 82)[trav] * B
+    fb, rb, mb = mem.rows(torch.arange(B * 41, device="cuda:0"))
+    assert torch.equal(fa, fb) and torch.equal(ma, mb)
+    np.testing.assert_allclose(rb.cpu().numpy(), ra.cpu().numpy(), atol=ATOL, rtol=0)
+    np.testing.assert_allclose(v_fused.cpu().numpy(), v_ref.cpu().numpy(), atol=ATOL, rtol=0)
+
+
+@pytest.mark.parametrize("trav", [0, 1])
+def test_fused_traversal_replay_matches_reference(dcfr, trav):
+    """The reference's own traversal (fixture) through the fused kernel, its np.random draws supplied as uniforms."""
+    import torch
+    d, g = dcfr
+    order = _opponent_draw_order(trav)
+    u = np.random.RandomState(100 + trav).random_sample(len(order))
+    uni = {}
+    for ply in range(8):
+        if (ply & 1) != trav:
+            width = max(s for p, s in order if p == ply) + 1
+            arr = np.zeros(width)
+            for k, (p, s) in enumerate(order):
+                if p == ply:
+                    arr[s] = u[k]
+            uni[ply] = torch.from_numpy(arr).to("cuda:0")
+    val = d._traverse_batch(trav, 1, uniforms=uni, fused=True)
+    assert abs(float(val[0]) - float(g[f"trav{trav}_value"][0])) < ATOL
+    mem = d.advantage_nets[trav].buffer
+    f, r, m = mem.rows(torch.arange(41, device="cuda:0"))
+    assert np.array_equal(f.cpu().numpy(), g[f"trav{trav}_row_feat"])
+    assert np.array_equal(m.cpu().numpy(), g[f"trav{trav}_row_mask"])
+    np.testing.assert_allclose(r.cpu().numpy(), g[f"trav{trav}_row_regret"], atol=ATOL, rtol=0)
