@@ -1,10 +1,12 @@
 #!/usr/bin/env python3
-"""Many deals at once (one workgroup per deal): deal on device, build trees, exact and synchronous CFR, exploitability.
-    python benchmarks/multi_deal_bench.py --deals 4096
+"""TEST-SIDE TOOL (times the oracle beside the GPU, hence it lives under tests/).
+
+Many deals at once (one workgroup per deal): deal on device, build trees, exact and synchronous CFR, exploitability.
+    python tests/tools/multi_deal_bench.py --deals 4096
 """
 import argparse, json, os, sys, time
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 
 
