@@ -229,6 +229,35 @@ int32_t scopa_multi_exploitability(scopa_multi *m, double *h_out4);
 int32_t scopa_multi_tables_get(scopa_multi *m, int32_t deal, double *h_regret, double *h_strategy, double *h_local, uint64_t *h_keys);
 int32_t scopa_multi_counters(scopa_multi *m, uint64_t *decision_visits, uint64_t *terminal_visits);
 
+/* ---- FullScopa: the 40-card game (src/envs/full_scopa_game.py, src/envs/openspiel_full_scopa.py) -- state engine -------------
+ * No reference solver uses it; provided: deal, the state protocol, and the batched device step.
+ * Card id = action id = suit_idx*10 + rank-1 (denari, coppe, spade, bastoni).  A state refers to its deck (the deal order,
+ * needed for the re-deals) by index `game` into a caller-supplied array of 40-byte decks. */
+typedef struct scopa_full_state {   /* 64 bytes */
+    uint64_t table[2];     /* ordered table, 20 six-bit slots (10 per word)                                   */
+    uint64_t cap[2];       /* captured cards per player, 40-bit masks                                          */
+    uint32_t hand[2];      /* ordered hands, 3 six-bit slots                                                   */
+    uint32_t game;         /* deck index                                                                       */
+    uint8_t  nh[2], nt, deck_pos, round, last_capture /* 0xFF = none */, scopas[2];
+    uint16_t step;
+    uint8_t  terminal;
+    int8_t   r2_p0;        /* rewards x2 of player 0 once terminal (player 1 = negation)                       */
+    uint8_t  flags;        /* bit 0: table capacity (20) exceeded                                              */
+    uint8_t  pad[7];
+} scopa_full_state;
+int32_t scopa_full_deal_py_seed(int64_t seed, uint8_t perm40[40]);                              /* FullDeck.__init__ :29-32 */
+int32_t scopa_full_state_init(const uint8_t deck40[40], uint32_t game, scopa_full_state *out);  /* FullScopaGame.reset :60-75 */
+int32_t scopa_full_state_step(scopa_full_state *s, const uint8_t deck40[40], int32_t action);   /* FullScopaEnv.step :252-297 */
+int32_t scopa_full_state_legal(const scopa_full_state *s, int32_t player, int32_t out[3], int32_t *n);
+int32_t scopa_full_state_infoset_string(const scopa_full_state *s, int32_t player, char *buf, int32_t cap);
+/* d_states[i] <- step(d_states[i], d_decks[d_states[i].game], d_actions[i]) */
+int32_t scopa_full_step_batch(scopa_ctx *ctx, scopa_full_state *d_states, const uint8_t *d_actions, const uint8_t *d_decks, int64_t n);
+int32_t scopa_full_step_batch_host(scopa_ctx *ctx, scopa_full_state *h_states, const uint8_t *h_actions, const uint8_t *h_decks,
+                                   int64_t n_decks, int64_t n);
+/* n_games uniform-random playouts to the end, one lane per game, decks dealt ON DEVICE from seeds[i] (CPython shuffle);
+ * h_r2_p0[n] = rewards x2 of player 0, h_plies[n] = game length.  Philox stream (ctx seed, game, ply). */
+int32_t scopa_full_random_playouts(scopa_ctx *ctx, const int64_t *h_seeds, int64_t n_games, int8_t *h_r2_p0, int16_t *h_plies);
+
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);

@@ -400,7 +400,49 @@ def gen_sdcfr(ns):
     np.savez_compressed(os.path.join(OUT, "sdcfr.npz"), **out)
 
 
-ALL = dict(deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+def gen_full(ns):
+    """FullScopa (40 cards): deals and random playouts through the reference's FullScopaEnv / FullScopaState
+    (src/envs/full_scopa_game.py, src/envs/openspiel_full_scopa.py).  Card id = action id = suit_idx*10 + rank-1."""
+    import importlib
+    fg = importlib.import_module("envs.full_scopa_game")
+    fs = importlib.import_module("envs.openspiel_full_scopa")
+    import pyspiel
+    game = pyspiel.load_game("full_scopa")
+    FS = fg.FullDeck.suits
+
+    def fid(c):
+        return FS.index(c.suit) * 10 + (c.rank - 1)
+
+    deals = {str(s): [fid(c) for c in fg.FullDeck(s).cards] for s in [42, 0, 1, 2, 3, 7, 123, 2024, 2**32 + 5]}
+    rng = np.random.RandomState(40)
+    cases = []
+    for seed in [42, 0, 1, 2, 3, 7, 123, 2024]:
+        for k in range(6):
+            env = fg.FullScopaEnv(seed=seed)
+            st = fs.FullScopaState(game, env=env, skip_reset=True)
+            acts, trail = [], []
+            while not st.is_terminal():
+                legal = st.legal_actions()
+                a = int(legal[rng.randint(len(legal))]) if (k < 4 or rng.rand() < 0.7) else int(rng.randint(40))
+                acts.append(a)
+                st.apply_action(a)
+                g = st.env.game
+                trail.append(dict(hands=[[fid(c) for c in p.hand] for p in g.players], table=[fid(c) for c in g.table],
+                                  caps=[sorted(fid(c) for c in p.captures) for p in g.players], scopas=[p.scopas for p in g.players],
+                                  round=g.round_number, step=st.env.step_count, deck_remaining=g.deck.cards_remaining(),
+                                  last=(g.players.index(g.last_capture) if g.last_capture else -1), term=bool(st.is_terminal()),
+                                  cur=int(st.current_player()) if not st.is_terminal() else -4,
+                                  legal=[int(x) for x in st.legal_actions()],
+                                  info0=st.information_state_string(0), info1=st.information_state_string(1)))
+            cases.append(dict(seed=seed, actions=acts, trail=trail[::3] + trail[-2:], trail_idx=list(range(0, len(trail), 3)) + [len(trail) - 2, len(trail) - 1],
+                              rewards=[float(r) for r in st.rewards()], hist=st.history_str()))
+    with open(os.path.join(OUT, "full_scopa.json"), "w") as f:
+        json.dump(dict(deals=deals, playouts=cases), f)
+    print("full scopa: deals", len(deals), "playouts", len(cases), "plies", sorted({len(c["actions"]) for c in cases}),
+          "max table", max(len(t["table"]) for c in cases for t in c["trail"]))
+
+
+ALL = dict(full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

@@ -217,3 +217,53 @@ class Tree:
         br = np.zeros(2)
         e = lib().og_exploitability(self.h, _p(np.ascontiguousarray(P)), _p(br))
         return e, br
+
+
+# ---- FullScopa (40 cards) ---------------------------------------------------------------------------------------------
+class _FullState(C.Structure):
+    _fields_ = [("deck", C.c_uint8 * 40), ("deck_pos", C.c_int8), ("hand", (C.c_int8 * 3) * 2), ("nh", C.c_int8 * 2),
+                ("table", C.c_int8 * 40), ("nt", C.c_int8), ("cap", (C.c_uint8 * 40) * 2), ("ncap", C.c_int8 * 2),
+                ("scopas", C.c_int8 * 2), ("round_number", C.c_int8), ("last_capture", C.c_int8), ("step", C.c_int16),
+                ("terminal", C.c_int8), ("r2", C.c_int * 2)]
+
+
+def full_deal_py_seed(seed):
+    perm = np.zeros(40, np.uint8)
+    lib().og_deal_py_seed  # ensure loaded
+    lib().ogf_deal_py_seed(C.c_int64(int(seed)), _p(perm))
+    return perm
+
+
+class FullState:
+    def __init__(self, perm=None, seed=42):
+        self.s = _FullState()
+        self.perm = np.ascontiguousarray(full_deal_py_seed(seed) if perm is None else perm, np.uint8)
+        lib().ogf_reset(C.byref(self.s), _p(self.perm))
+
+    def legal(self, player=-1):
+        out = (C.c_int * 3)()
+        n = lib().ogf_legal(C.byref(self.s), int(player), out)
+        return [out[i] for i in range(n)]
+
+    def step(self, a):
+        lib().ogf_step(C.byref(self.s), int(a))
+
+    def is_terminal(self):
+        return bool(self.s.terminal)
+
+    def current_player(self):
+        return -4 if self.s.terminal else (self.s.step & 1)
+
+    def rewards(self):
+        return [self.s.r2[0] / 2.0, self.s.r2[1] / 2.0] if self.s.terminal else [0, 0]
+
+    def infoset_string(self, player):
+        buf = C.create_string_buffer(256)
+        lib().ogf_infoset_string(C.byref(self.s), int(player), buf)
+        return buf.value.decode()
+
+    def snapshot(self):
+        s = self.s
+        return dict(hands=[[int(s.hand[p][i]) for i in range(s.nh[p])] for p in range(2)], table=[int(s.table[i]) for i in range(s.nt)],
+                    caps=[sorted(int(s.cap[p][i]) for i in range(s.ncap[p])) for p in range(2)], scopas=[int(s.scopas[0]), int(s.scopas[1])],
+                    round=int(s.round_number), step=int(s.step), deck_remaining=40 - int(s.deck_pos), last=int(s.last_capture))

@@ -681,3 +681,141 @@ double og_exploitability(const og_tree *t, const double *policy, double *br_valu
     if (br_values) { br_values[0] = b0; br_values[1] = b1; }
     return 0.5 * (b0 + b1); /* NashConv/2; v0(pi)+v1(pi)=0 */
 }
+
+/* ===================================================================================================================
+ * FullScopa (40-card deck): src/envs/full_scopa_game.py, src/envs/openspiel_full_scopa.py.  Literal restatement. */
+static const char *FSUIT_NAME[4] = {"denari", "coppe", "spade", "bastoni"}; /* FullDeck.suits (:20) */
+static int f_rank(int c) { return c % 10 + 1; }
+static int f_suit(int c) { return c / 10; }
+
+void ogf_deal_py_seed(int64_t seed, uint8_t perm[40]) {
+    /* FullDeck.__init__ (:29-32): 40 cards suit-major, random.seed(seed), random.shuffle */
+    uint64_t a = seed < 0 ? (uint64_t)(-seed) : (uint64_t)seed;
+    uint32_t key[2] = {(uint32_t)a, (uint32_t)(a >> 32)};
+    mt_t m;
+    mt_init_by_array(&m, key, key[1] ? 2 : 1);
+    for (int i = 0; i < 40; i++) perm[i] = (uint8_t)i;
+    for (int i = 39; i >= 1; i--) {
+        uint32_t j = py_randbelow(&m, (uint32_t)i + 1);
+        uint8_t t = perm[i]; perm[i] = perm[j]; perm[j] = t;
+    }
+}
+
+void ogf_reset(ogf_state *s, const uint8_t perm[40]) {
+    /* FullScopaGame.reset (:60-75): 4 cards to the table, then 3 to each player */
+    memset(s, 0, sizeof *s);
+    memcpy(s->deck, perm, 40);
+    for (int i = 0; i < 4; i++) s->table[s->nt++] = (int8_t)perm[s->deck_pos++];
+    for (int p = 0; p < 2; p++) { for (int i = 0; i < 3; i++) s->hand[p][i] = (int8_t)perm[s->deck_pos++]; s->nh[p] = 3; }
+    s->last_capture = -1;
+}
+
+int ogf_legal(const ogf_state *s, int player, int out[3]) {
+    /* FullScopaState.legal_actions (openspiel_full_scopa.py:22-42) */
+    if (s->terminal) return 0;
+    if (player < 0) player = s->step & 1;
+    int n = 0;
+    for (int i = 0; i < s->nh[player]; i++) out[n++] = s->hand[player][i];
+    if (!n) { out[0] = 0; n = 1; }
+    return n;
+}
+
+static void f_evaluate(ogf_state *s) {
+    /* FullScopaGame.evaluate_game (:166-228) */
+    int scores[2] = {0, 0};
+    if (s->nt > 0 && s->last_capture >= 0) { /* remaining table cards to the last capturer */
+        int p = s->last_capture;
+        for (int i = 0; i < s->nt; i++) s->cap[p][s->ncap[p]++] = (uint8_t)s->table[i];
+    }
+    int cards[2] = {s->ncap[0], s->ncap[1]};
+    if (cards[0] != cards[1]) scores[cards[0] > cards[1] ? 0 : 1] += 1;            /* carte */
+    int den[2] = {0, 0};
+    for (int p = 0; p < 2; p++) for (int i = 0; i < s->ncap[p]; i++) if (f_suit(s->cap[p][i]) == 0) den[p]++;
+    if (den[0] != den[1]) scores[den[0] > den[1] ? 0 : 1] += 1;                    /* denari */
+    for (int p = 0; p < 2; p++) {                                                  /* sette bello: first holder */
+        int has = 0;
+        for (int i = 0; i < s->ncap[p]; i++) if (s->cap[p][i] == 6) has = 1;
+        if (has) { scores[p] += 1; break; }
+    }
+    static const int PV[11] = {0, 16, 12, 13, 14, 15, 18, 21, 10, 10, 10};         /* primiera_values (:24-27) */
+    int prim[2];
+    for (int p = 0; p < 2; p++) {
+        int best[4] = {0, 0, 0, 0}, have[4] = {0, 0, 0, 0};
+        for (int i = 0; i < s->ncap[p]; i++) {
+            int c = s->cap[p][i], v = PV[f_rank(c)], su = f_suit(c);
+            if (!have[su] || v > best[su]) { best[su] = v; have[su] = 1; }
+        }
+        prim[p] = (have[0] && have[1] && have[2] && have[3]) ? best[0] + best[1] + best[2] + best[3] : 0;
+    }
+    if (prim[0] > 0 || prim[1] > 0) {
+        int mx = prim[0] > prim[1] ? prim[0] : prim[1];
+        int w0 = prim[0] == mx && prim[0] > 0, w1 = prim[1] == mx && prim[1] > 0;
+        if (w0 + w1 == 1) scores[w0 ? 0 : 1] += 1;
+    }
+    scores[0] += s->scopas[0]; scores[1] += s->scopas[1];
+    int total = scores[0] + scores[1];
+    if (total == 0) { s->r2[0] = s->r2[1] = 0; }
+    else { s->r2[0] = 2 * scores[0] - total; s->r2[1] = 2 * scores[1] - total; }
+    s->terminal = 1;
+}
+
+void ogf_step(ogf_state *s, int action) {
+    /* FullScopaEnv.step (:252-297) */
+    if (s->terminal) return;
+    int p = s->step & 1, pos = -1;
+    for (int i = 0; i < s->nh[p]; i++) if (s->hand[p][i] == action) { pos = i; break; }
+    if (pos >= 0) { /* play_card (:120-150) with capture_choice None */
+        int card = action, target = f_rank(card), capmask = 0;
+        for (int i = 0; i < s->nt; i++) if (f_rank(s->table[i]) == target) { capmask = 1 << i; break; }   /* exact match first */
+        if (!capmask && s->nt > 0)
+            for (int mask = 1; mask < (1 << s->nt); mask++) {   /* find_capture_combinations (:104-118): first subset, masks ascending */
+                int sum = 0;
+                for (int i = 0; i < s->nt; i++) if (mask & (1 << i)) sum += f_rank(s->table[i]);
+                if (sum == target) { capmask = mask; break; }
+            }
+        if (capmask) {
+            int8_t keep[40]; int nk = 0;
+            for (int i = 0; i < s->nt; i++) {
+                if (capmask & (1 << i)) s->cap[p][s->ncap[p]++] = (uint8_t)s->table[i];
+                else keep[nk++] = s->table[i];
+            }
+            s->cap[p][s->ncap[p]++] = (uint8_t)card;
+            memcpy(s->table, keep, (size_t)nk); s->nt = (int8_t)nk;
+            s->last_capture = (int8_t)p;
+            if (s->nt == 0) s->scopas[p]++;
+        } else s->table[s->nt++] = (int8_t)card;
+        for (int i = pos; i + 1 < s->nh[p]; i++) s->hand[p][i] = s->hand[p][i + 1];
+        s->nh[p]--;
+    }
+    s->step++;
+    if (s->nh[0] == 0 && s->nh[1] == 0) {
+        if (40 - s->deck_pos >= 6) { /* deal_new_round (:81-88) */
+            for (int q = 0; q < 2; q++) { for (int i = 0; i < 3; i++) s->hand[q][i] = (int8_t)s->deck[s->deck_pos++]; s->nh[q] = 3; }
+            s->round_number++;
+        } else f_evaluate(s);
+    }
+    if (!s->terminal && s->step >= 200) f_evaluate(s);
+}
+
+static int f_cmp_cards(const void *a, const void *b) {
+    /* sorted([(rank, suit_name)]) */
+    int x = *(const int *)a, y = *(const int *)b;
+    if (f_rank(x) != f_rank(y)) return f_rank(x) - f_rank(y);
+    return strcmp(FSUIT_NAME[f_suit(x)], FSUIT_NAME[f_suit(y)]);
+}
+
+int ogf_infoset_string(const ogf_state *s, int player, char *buf) {
+    /* FullScopaState.information_state_string (openspiel_full_scopa.py:79-94) */
+    int h[3], t[40];
+    for (int i = 0; i < s->nh[player]; i++) h[i] = s->hand[player][i];
+    for (int i = 0; i < s->nt; i++) t[i] = s->table[i];
+    qsort(h, (size_t)s->nh[player], sizeof(int), f_cmp_cards);
+    qsort(t, (size_t)s->nt, sizeof(int), f_cmp_cards);
+    char *w = buf;
+    w += sprintf(w, "P%d:R%d:H[", player, s->round_number);
+    for (int i = 0; i < s->nh[player]; i++) w += sprintf(w, "%s%d%c", i ? "-" : "", f_rank(h[i]), FSUIT_NAME[f_suit(h[i])][0]);
+    w += sprintf(w, "]:T[");
+    for (int i = 0; i < s->nt; i++) w += sprintf(w, "%s%d%c", i ? "-" : "", f_rank(t[i]), FSUIT_NAME[f_suit(t[i])][0]);
+    w += sprintf(w, "]:C[%d,%d]:S[%d,%d]", s->ncap[0], s->ncap[1], s->scopas[0], s->scopas[1]);
+    return (int)(w - buf);
+}

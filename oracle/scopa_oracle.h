@@ -125,3 +125,28 @@ double og_exploitability(const og_tree *t, const double *policy, double *br_valu
 }
 #endif
 #endif
+
+/* ==== FullScopa (40 cards), test-side restatement of src/envs/full_scopa_game.py + openspiel_full_scopa.py ========== */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct {
+    uint8_t deck[40];        /* FullDeck(seed).cards as card ids (suit_idx*10 + rank-1), deal order */
+    int8_t deck_pos;         /* cards dealt so far */
+    int8_t hand[2][3]; int8_t nh[2];
+    int8_t table[40]; int8_t nt;
+    uint8_t cap[2][40]; int8_t ncap[2];   /* captures as lists (order irrelevant for scoring) */
+    int8_t scopas[2];
+    int8_t round_number, last_capture /* -1 none */;
+    int16_t step;
+    int8_t terminal;
+    int r2[2];               /* rewards x2 once terminal */
+} ogf_state;
+void ogf_deal_py_seed(int64_t seed, uint8_t perm[40]);
+void ogf_reset(ogf_state *s, const uint8_t perm[40]);
+int  ogf_legal(const ogf_state *s, int player, int out[3]);
+void ogf_step(ogf_state *s, int action);
+int  ogf_infoset_string(const ogf_state *s, int player, char *buf);
+#ifdef __cplusplus
+}
+#endif

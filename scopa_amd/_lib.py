@@ -27,7 +27,9 @@ SYMBOLS = [
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
-    "scopa_multi_cfr_sync_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_multi_cfr_sync_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
+    "scopa_full_state_init", "scopa_full_state_step", "scopa_full_state_legal", "scopa_full_state_infoset_string",
+    "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -136,6 +138,14 @@ def lib():
         "scopa_multi_exploitability": (i32, [vp, vp]),
         "scopa_multi_tables_get": (i32, [vp, i32, vp, vp, vp, vp]),
         "scopa_multi_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
+        "scopa_full_deal_py_seed": (i32, [i64, vp]),
+        "scopa_full_state_init": (i32, [vp, u32, vp]),
+        "scopa_full_state_step": (i32, [vp, vp, i32]),
+        "scopa_full_state_legal": (i32, [vp, i32, C.POINTER(i32 * 3), C.POINTER(i32)]),
+        "scopa_full_state_infoset_string": (i32, [vp, i32, C.c_char_p, i32]),
+        "scopa_full_step_batch": (i32, [vp, vp, vp, vp, i64]),
+        "scopa_full_step_batch_host": (i32, [vp, vp, vp, vp, i64, i64]),
+        "scopa_full_random_playouts": (i32, [vp, vp, i64, vp, vp]),
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
@@ -382,6 +392,20 @@ class Context:
     def cfr_sync_iterate(self, n_iters):
         self._ck(self._L.scopa_cfr_sync_iterate(self._h, int(n_iters)), "scopa_cfr_sync_iterate")
 
+    def full_step_batch_host(self, states, actions, decks):
+        assert states.dtype == FULL_STATE_DTYPE
+        actions = np.ascontiguousarray(actions, np.uint8)
+        decks = np.ascontiguousarray(decks, np.uint8).reshape(-1, 40)
+        self._ck(self._L.scopa_full_step_batch_host(self._h, _ptr(states), _ptr(actions), _ptr(decks), decks.shape[0], states.size),
+                 "scopa_full_step_batch_host")
+        return states
+
+    def full_random_playouts(self, seeds):
+        seeds = np.ascontiguousarray(seeds, np.int64)
+        r2, plies = np.zeros(seeds.size, np.int8), np.zeros(seeds.size, np.int16)
+        self._ck(self._L.scopa_full_random_playouts(self._h, _ptr(seeds), seeds.size, _ptr(r2), _ptr(plies)), "scopa_full_random_playouts")
+        return r2, plies
+
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(self._L.scopa_counters(self._h, C.byref(a), C.byref(b)), "scopa_counters")
@@ -395,6 +419,69 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self._ck(self._L.scopa_prof_read(self._h, C.byref(n), C.byref(ms)), "scopa_prof_read")
         return n.value, ms.value
+
+
+FULL_STATE_DTYPE = np.dtype([("table", "<u8", (2,)), ("cap", "<u8", (2,)), ("hand", "<u4", (2,)), ("game", "<u4"), ("nh", "u1", (2,)),
+                             ("nt", "u1"), ("deck_pos", "u1"), ("round", "u1"), ("last_capture", "u1"), ("scopas", "u1", (2,)),
+                             ("step", "<u2"), ("terminal", "u1"), ("r2_p0", "i1"), ("flags", "u1"), ("pad", "u1", (7,))])
+assert FULL_STATE_DTYPE.itemsize == 64
+
+
+def full_deal_py_seed(seed):
+    """40-card FullDeck(seed).cards as card ids (full_scopa_game.py:29-32)."""
+    perm = np.zeros(40, np.uint8)
+    rc = lib().scopa_full_deal_py_seed(int(seed), _ptr(perm))
+    if rc:
+        raise ScopaError(rc, "scopa_full_deal_py_seed")
+    return perm
+
+
+class FullState:
+    """One packed FullScopa state driven through the host-side protocol (scopa_full_state_*)."""
+
+    def __init__(self, seed=42, deck=None, game=0):
+        self.deck = np.ascontiguousarray(full_deal_py_seed(seed) if deck is None else deck, np.uint8)
+        self.s = np.zeros(1, FULL_STATE_DTYPE)
+        rc = lib().scopa_full_state_init(_ptr(self.deck), int(game), _ptr(self.s))
+        if rc:
+            raise ScopaError(rc, "scopa_full_state_init")
+
+    def step(self, action):
+        rc = lib().scopa_full_state_step(_ptr(self.s), _ptr(self.deck), int(action))
+        if rc:
+            raise ScopaError(rc, "scopa_full_state_step")
+
+    def legal(self, player=-1):
+        out, n = (C.c_int32 * 3)(), C.c_int32()
+        lib().scopa_full_state_legal(_ptr(self.s), int(player), C.byref(out), C.byref(n))
+        return [out[i] for i in range(n.value)]
+
+    def is_terminal(self):
+        return bool(self.s[0]["terminal"])
+
+    def current_player(self):
+        return -4 if self.is_terminal() else int(self.s[0]["step"]) & 1
+
+    def rewards(self):
+        r = int(self.s[0]["r2_p0"])
+        return [r / 2.0, -r / 2.0] if self.is_terminal() else [0, 0]
+
+    def infoset_string(self, player):
+        buf = C.create_string_buffer(256)
+        lib().scopa_full_state_infoset_string(_ptr(self.s), int(player), buf, 256)
+        return buf.value.decode()
+
+    def snapshot(self):
+        return unpack_full_state(self.s[0])
+
+
+def unpack_full_state(s):
+    tab = [int((int(s["table"][i // 10]) >> (6 * (i % 10))) & 63) for i in range(int(s["nt"]))]
+    hands = [[int((int(s["hand"][p]) >> (6 * i)) & 63) for i in range(int(s["nh"][p]))] for p in range(2)]
+    caps = [[c for c in range(40) if (int(s["cap"][p]) >> c) & 1] for p in range(2)]
+    last = int(s["last_capture"])
+    return dict(hands=hands, table=tab, caps=caps, scopas=[int(s["scopas"][0]), int(s["scopas"][1])], round=int(s["round"]),
+                step=int(s["step"]), deck_remaining=40 - int(s["deck_pos"]), last=-1 if last == 255 else last)
 
 
 class MultiDeal:

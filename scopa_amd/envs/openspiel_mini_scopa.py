@@ -146,7 +146,12 @@ class MiniScopaGame:
                               num_players=self._num_players, skip_reset=True)
 
 
-_REGISTRY = {"mini_scopa": lambda params=None: MiniScopaGame()}
+def _full_scopa(params=None):
+    from .openspiel_full_scopa import FullScopaGame
+    return FullScopaGame()
+
+
+_REGISTRY = {"mini_scopa": lambda params=None: MiniScopaGame(), "full_scopa": _full_scopa}
 
 
 def load_game(short_name, params=None):
