@@ -225,6 +225,10 @@ int32_t scopa_multi_perms_get(scopa_multi *m, uint8_t *h_perms);
 int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets);
 int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters);
 int32_t scopa_multi_cfr_sync_iterate(scopa_multi *m, int32_t n_iters);
+/* batched MCCFR on every deal at once, persistent: one workgroup per deal keeps the deal's regret table in LDS and runs all
+ * n_iters iterations of `batch` traversal pairs without leaving the kernel; same definition (frozen tables per iteration,
+ * Philox keyed by seed / traversal id / iteration) as scopa_mccfr_iterate on that deal */
+int32_t scopa_multi_mccfr_iterate(scopa_multi *m, uint32_t batch, uint32_t n_iters, uint64_t seed);
 int32_t scopa_multi_exploitability(scopa_multi *m, double *h_out4);
 int32_t scopa_multi_tables_get(scopa_multi *m, int32_t deal, double *h_regret, double *h_strategy, double *h_local, uint64_t *h_keys);
 int32_t scopa_multi_counters(scopa_multi *m, uint64_t *decision_visits, uint64_t *terminal_visits);

@@ -18,3 +18,9 @@ __global__ void k_exploitability(const uint16_t *__restrict__ g_infoset, const i
                                  const uint64_t *__restrict__ g_key, const double *__restrict__ g_strat,
                                  const double *__restrict__ g_policy_in, int n_infosets, double *__restrict__ out4,
                                  double *__restrict__ g_policy_out, const int32_t *__restrict__ multi_meta);
+
+namespace scopa {
+int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const uint16_t *d_infoset, const int8_t *d_payoff,
+                           const uint64_t *d_key, double *d_regret, double *d_strat, const int32_t *d_meta, uint32_t *d_visit,
+                           unsigned long long *d_counters, uint64_t seed, uint32_t iter0, uint32_t n_iters, uint32_t batch);
+}

@@ -174,6 +174,64 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
     return visited;
 }
 
+// One traversal pair (both traversers of global traversal id b) on one wavefront: plies 0..5 level by level, plies 6-7, then the
+// regret update.  Regret increments go to `s_dR` with LDS float64 atomics, traverser visits to `s_cnt`.
+__device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
+                                          const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
+                                          unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
+                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis) {
+    // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time)
+    my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts
+    for (int t = lane; t < 2 * 60; t += 64) {
+        const int trav = t < 60 ? 0 : 1;
+        const int j = trav ? t - 60 : t;
+        // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
+        int pj = j, k = 0;
+        if (trav == 1) { pj = j / 3; k = j - pj * 3; }
+        const NodeRec pr = ws.recB[(trav ? 60 : 0) + pj];
+        const int act = (trav == 1 && k > 0) ? k - 1 : pr.a;
+        const int idx6 = pr.idx * 2 + act;                 // = index of the ply-7 node and of the leaf as well
+        const int I6 = s_inf[level_offset(6) + idx6], I7 = s_inf[level_offset(7) + idx6];
+        s_seen[I6] = 1;
+        s_seen[I7] = 1;
+        atomicAdd(&s_cnt[trav == 0 ? I6 : I7], 1u);       // the traverser's single-action node: strategy_sum += [1.0]
+        const int p0 = s_pay[idx6];
+        ws.p6[t] = (int8_t)(trav == 0 ? p0 : -p0);
+        my_dvis += trav == 0 ? 3 : 2;                       // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
+        my_tvis += 2;
+    }
+    wave_lds_sync();
+    // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84)
+    if (lane < 2 * kUpd) {
+        const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
+        const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
+        const int j = x - (m == 0 ? 0 : m == 1 ? 1 : 6);
+        const int nX = 4 - m;
+        const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
+        const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
+        const int IX = ws.updI[lane];
+        const double rX = ws.updr[lane], sX = ws.upds[lane];
+        const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
+        const int8_t *p6 = ws.p6 + trav * 60;
+        double cfv[4], v = 0.0;
+        for (int i = 0; i < nX; i++) {
+            cfv[i] = 0.5 * (double)p6[base + (i + 1) * stride];
+            v = fma(s_sigcdf[IX * 8 + i], cfv[i], v);      // np.dot on this numpy build: an fma chain (see oracle)
+        }
+        for (int i = 0; i < nX; i++) {
+            const double delta = w * (cfv[i] - v);
+            if (delta != 0.0) atomicAdd(&s_dR[IX * 4 + i], delta);
+        }
+    }
+    wave_lds_sync();  // the next pair overwrites this wave's scratch
+}
+
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_slabs,
@@ -206,57 +264,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        const uint32_t b = b0 + pg;
-        // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time)
-        my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-        my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-        my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-        my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-        my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-        my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-        // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts
-        for (int t = lane; t < 2 * 60; t += 64) {
-            const int trav = t < 60 ? 0 : 1;
-            const int j = trav ? t - 60 : t;
-            // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
-            int pj = j, k = 0;
-            if (trav == 1) { pj = j / 3; k = j - pj * 3; }
-            const NodeRec pr = ws.recB[(trav ? 60 : 0) + pj];
-            const int act = (trav == 1 && k > 0) ? k - 1 : pr.a;
-            const int idx6 = pr.idx * 2 + act;                 // = index of the ply-7 node and of the leaf as well
-            const int I6 = s_inf[level_offset(6) + idx6], I7 = s_inf[level_offset(7) + idx6];
-            s_seen[I6] = 1;
-            s_seen[I7] = 1;
-            atomicAdd(&s_cnt[trav == 0 ? I6 : I7], 1u);       // the traverser's single-action node: strategy_sum += [1.0]
-            const int p0 = s_pay[idx6];
-            ws.p6[t] = (int8_t)(trav == 0 ? p0 : -p0);
-            my_dvis += trav == 0 ? 3 : 2;                       // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
-            my_tvis += 2;
-        }
-        wave_lds_sync();
-        // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84)
-        if (lane < 2 * kUpd) {
-            const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
-            const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
-            const int j = x - (m == 0 ? 0 : m == 1 ? 1 : 6);
-            const int nX = 4 - m;
-            const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
-            const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
-            const int IX = ws.updI[lane];
-            const double rX = ws.updr[lane], sX = ws.upds[lane];
-            const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
-            const int8_t *p6 = ws.p6 + trav * 60;
-            double cfv[4], v = 0.0;
-            for (int i = 0; i < nX; i++) {
-                cfv[i] = 0.5 * (double)p6[base + (i + 1) * stride];
-                v = fma(s_sigcdf[IX * 8 + i], cfv[i], v);      // np.dot on this numpy build: an fma chain (see oracle)
-            }
-            for (int i = 0; i < nX; i++) {
-                const double delta = w * (cfv[i] - v);
-                if (delta != 0.0) atomicAdd(&s_dR[IX * 4 + i], delta);
-            }
-        }
-        wave_lds_sync();  // the next pair overwrites this wave's scratch
+        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis);
     }
     __syncthreads();
 
@@ -278,6 +286,70 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
     __syncthreads();
     if (tid < 2) g_wg_counts[blockIdx.x * 2 + tid] = s_vis[tid];
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Multi-deal mode: ONE WORKGROUP PER DEAL runs n_iters whole iterations without leaving the kernel.  The deal's regret table
+// lives in LDS for the whole solve; each iteration freezes sigma|cdf rows from it, lets the 16 wavefronts walk `batch` traversal
+// pairs (LDS float64 atomics straight into the live regret table -- the frozen rows are what the walks read), then adds
+// count * sigma to the strategy sums in HBM and refreezes.  No slabs, no reduce kernel, no per-iteration launch.
+__global__ void __launch_bounds__(1024)
+k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
+              double *__restrict__ g_regret, double *__restrict__ g_strat, const int32_t *__restrict__ g_meta, uint32_t *__restrict__ g_visit,
+              unsigned long long *__restrict__ g_counters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t n_iters,
+              uint32_t batch) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ unsigned int s_vis[2];
+    {
+        const size_t deal = blockIdx.x;
+        g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision; g_regret += deal * kDecision * 4;
+        g_strat += deal * kDecision * 4; g_meta += deal * 8; g_visit += deal * kDecision; g_counters += deal * 8;
+    }
+    const int I = g_meta[0];
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][8] frozen rows
+    double *s_R = s_sigcdf + (size_t)I * 8;                                      // [I][4] live regret table
+    WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_R + (size_t)I * 4);
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));
+    uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));
+    int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);
+    uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    if (tid < 2) s_vis[tid] = 0u;
+    for (int i = tid; i < I * 4; i += blockDim.x) s_R[i] = g_regret[i];
+    for (int r = tid; r < I; r += blockDim.x) { s_cnt[r] = 0u; s_seen[r] = 0; }
+    for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
+    for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
+    __syncthreads();
+    WaveScratch &ws = s_wave[wave];
+    unsigned int my_dvis = 0, my_tvis = 0;
+    for (uint32_t it = 0; it < n_iters; it++) {
+        for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
+            const int n = (int)((g_key[r] >> 1) & 7);
+            double sg[4], cd[4];
+            mc_sigma(s_R + r * 4, n, sg);
+            choice_cdf(sg, n, cd);
+            for (int c = 0; c < 4; c++) { s_sigcdf[r * 8 + c] = sg[c]; s_sigcdf[r * 8 + 4 + c] = cd[c]; }
+        }
+        __syncthreads();
+        for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
+            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis);
+        __syncthreads();
+        for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
+            const unsigned int c = s_cnt[r];
+            if (c) {
+                const int n = (int)((g_key[r] >> 1) & 7);
+                for (int k = 0; k < n; k++) g_strat[r * 4 + k] += (double)c * s_sigcdf[r * 8 + k];
+                s_cnt[r] = 0u;
+            }
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < I * 4; i += blockDim.x) g_regret[i] = s_R[i];
+    for (int r = tid; r < I; r += blockDim.x) if (s_seen[r] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
+    for (int off = 32; off > 0; off >>= 1) { my_dvis += __shfl_down(my_dvis, off); my_tvis += __shfl_down(my_tvis, off); }
+    if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
+    __syncthreads();
+    if (tid < 2) g_counters[tid] += s_vis[tid];
 }
 
 // delta[c] += sum over slabs, in slab order (deterministic).  A workgroup owns 16 consecutive cells; thread
@@ -599,6 +671,26 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
+
+namespace scopa {
+int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const uint16_t *d_infoset, const int8_t *d_payoff,
+                           const uint64_t *d_key, double *d_regret, double *d_strat, const int32_t *d_meta, uint32_t *d_visit,
+                           unsigned long long *d_counters, uint64_t seed, uint32_t iter0, uint32_t n_iters, uint32_t batch) {
+    int waves = 16;
+    auto need = [&](int w) {
+        size_t b = (size_t)max_infosets * (8 + 4) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
+        b += (((size_t)max_infosets * 4 + 15) & ~(size_t)15) + 1656 * 2 + 576 + (size_t)max_infosets;
+        return (b + 15) & ~(size_t)15;
+    };
+    while (waves > 1 && need(waves) + 64 > (size_t)ctx->lds_limit) waves -= 2;
+    SC_REQUIRE(ctx, need(waves) + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
+    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_multi), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 64));
+    hipLaunchKernelGGL(k_mccfr_multi, dim3(n_deals), dim3(waves * 64), need(waves), ctx->stream, d_infoset, d_payoff, d_key, d_regret, d_strat,
+                       d_meta, d_visit, d_counters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, n_iters, batch);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+}  // namespace scopa
 
 extern "C" {
 

@@ -32,6 +32,7 @@ struct scopa_multi {
     unsigned long long *d_counters = nullptr;  // [n][8]
     double *d_out = nullptr;         // [n][4] exploitability outputs
     int64_t *d_seeds = nullptr;      // [n]
+    uint32_t mccfr_iteration = 0;
 };
 
 // ---- CPython random.seed(int) + random.shuffle(16 cards), one lane per deal (MiniDeck.__init__, mini_scopa_game.py:25-28) --------
@@ -172,6 +173,7 @@ int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets) {
         if (h_n_infosets) h_n_infosets[d] = I;
     }
     m->built = true;
+    m->mccfr_iteration = 0;
     return SCOPA_OK;
 }
 
@@ -205,6 +207,20 @@ int32_t scopa_multi_cfr_sync_iterate(scopa_multi *m, int32_t n_iters) {
     hipLaunchKernelGGL(k_cfr_sync, dim3(m->n), dim3(1024), lds, ctx->stream, m->d_infoset, m->d_payoff, m->d_key, m->d_regret, m->d_strat,
                        0 /* multi-deal */, (int)n_iters, m->d_counters, m->d_visit, m->d_meta);
     SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_mccfr_iterate(scopa_multi *m, uint32_t batch, uint32_t n_iters, uint64_t seed) {
+    if (!m || batch == 0 || batch > (1u << 24) || n_iters > (1u << 24)) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_mccfr_iterate: call scopa_multi_build first");
+    if (!n_iters) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    const int32_t rc = launch_mccfr_multi(ctx, m->n, m->max_infosets, m->d_infoset, m->d_payoff, m->d_key, m->d_regret, m->d_strat, m->d_meta,
+                                          m->d_visit, m->d_counters, seed, m->mccfr_iteration, n_iters, batch);
+    if (rc != SCOPA_OK) return rc;
+    m->mccfr_iteration += n_iters;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCOPA_OK;
 }

@@ -66,3 +66,31 @@ def test_multi_deal_sync_cfr_many_deals(ctx, sl, oracle):
         assert np.array_equal(Rg, R) and np.array_equal(Sg, S)
         assert expl[i, 0] == t.exploitability(t.average_policy(S))[0]
     m.close()
+
+
+def test_multi_deal_persistent_mccfr_matches_oracle(ctx, sl, oracle):
+    """One workgroup per deal runs all iterations in-kernel (regret table in LDS): same definition as the single-deal
+    batched path, so each deal matches the oracle's og_mccfr_batched and the single-deal API."""
+    seeds = [42, 0, 1, 129, 282, 7]
+    m = sl.MultiDeal(ctx, len(seeds))
+    m.deal_py_seeds(seeds)
+    m.build()
+    m.mccfr_iterate(batch=48, n_iters=5, seed=321)
+    for i, s in enumerate(seeds):
+        t = oracle.Tree(seed=s)
+        R, S, _ = t.tables()
+        t.mccfr_batched(R, S, 321, 0, 5, 48)
+        Rg, Sg, _, _ = m.tables_get(i)
+        np.testing.assert_allclose(Rg, R, rtol=1e-10, atol=1e-10)
+        np.testing.assert_allclose(Sg, S, rtol=1e-10, atol=1e-10)
+    assert m.counters() == (463 * 48 * 5 * len(seeds), 240 * 48 * 5 * len(seeds))
+    # continuing is the same as one longer run; and deal 0 equals the single-deal entry point
+    m.mccfr_iterate(batch=48, n_iters=3, seed=321)
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.mccfr_seed(321)
+    ctx.mccfr_iterate(48, 8)
+    R1, S1, _ = ctx.tables_get()
+    Rg, Sg, _, _ = m.tables_get(0)
+    np.testing.assert_allclose(Rg, R1, rtol=1e-10, atol=1e-10)
+    np.testing.assert_allclose(Sg, S1, rtol=1e-10, atol=1e-10)
+    m.close()
