@@ -44,14 +44,30 @@ __device__ __forceinline__ void mc_sigma(const double *R, int n, double *sigma) 
     for (int i = 0; i < 4; i++) sigma[i] = i < n ? (s == 0.0 ? 1.0 / (double)n : pos[i] / s) : 0.0;
 }
 
-// np.random.choice(legal, p=sigma): cdf = p.cumsum(); cdf /= cdf[-1]; index = cdf.searchsorted(u, 'right')
-__device__ __forceinline__ void choice_cdf(const double *sigma, int n, double *cdf) {
+// np.random.choice(legal, p=sigma): cdf = p.cumsum(); cdf /= cdf[-1]; index = cdf.searchsorted(u, 'right') = #{cdf_i <= u}.
+// Every u here is k * 2^-53 with an integer k < 2^53 (u53 of two Philox words), and cdf_i * 2^53 is exact in float64, so
+// cdf_i <= u  <=>  ceil(cdf_i * 2^53) <= k: the row stores those integer thresholds (bit patterns in the double slots) and the
+// walk compares integers -- the same answer bit for bit, without int->float64 conversions and float64 compares per draw.
+__device__ __forceinline__ void choice_cdf(const double *sigma, int n, double *cdf_bits) {
+    double cdf[4];
+    double c = sigma[0];
+    cdf[0] = c;
+    for (int i = 1; i < n; i++) { c += sigma[i]; cdf[i] = c; }
+    const double last = cdf[n - 1];
+    for (int i = 0; i < 4; i++) {
+        const unsigned long long t = i < n ? (unsigned long long)ceil((cdf[i] / last) * 9007199254740992.0) : ~0ull;  // padding never counts
+        cdf_bits[i] = __longlong_as_double((long long)t);
+    }
+}
+// the plain float64 form, for the replay kernel whose uniforms come from the host
+__device__ __forceinline__ void choice_cdf_f64(const double *sigma, int n, double *cdf) {
     double c = sigma[0];
     cdf[0] = c;
     for (int i = 1; i < n; i++) { c += sigma[i]; cdf[i] = c; }
     const double last = cdf[n - 1];
     for (int i = 0; i < 4; i++) cdf[i] = i < n ? cdf[i] / last : 2.0;  // 2.0 > any u: padding never counts
 }
+__device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) { return ((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6); }
 
 // traverser plies strictly above ply d, and nodes of ply d (d <= 6) in one task's recursion tree
 __host__ __device__ constexpr int ntl_at(int trav, int d) { return trav == 0 ? (d + 1) >> 1 : d >> 1; }
@@ -59,16 +75,16 @@ __host__ __device__ constexpr int task_nodes(int trav, int d) {
     return ntl_at(trav, d) == 0 ? 1 : ntl_at(trav, d) == 1 ? 5 : ntl_at(trav, d) == 2 ? 20 : 60;
 }
 
-struct NodeRec {      // 32 bytes, one per recursion-tree node of the ply being handed down
+struct NodeRec {      // 24 bytes, one per recursion-tree node of the ply being handed down
     double reach;     // product of the opponent's sigma on the path          (reach_probs[1 - traverser])
     double samp;      // product of the traverser's sigma on the path         (sampling_probs[traverser])
-    double u_next;    // words 2,3 of the Philox block, for the traverser node below an opponent node
     uint16_t idx;     // BFS index of the game-tree node within its ply
     uint16_t dig;     // branch digits so far, 3 bits per traverser ply
+    uint16_t inf;     // its infoset id
     uint8_t a;        // sampled action index (np.random.choice)
-    uint8_t pad[3];
+    uint8_t pad;
 };
-static_assert(sizeof(NodeRec) == 32, "NodeRec must be 32 bytes");
+static_assert(sizeof(NodeRec) == 24, "NodeRec must be 24 bytes");
 
 constexpr int kUpd = 26;  // traverser nodes with > 1 legal action per task: 1 + 5 + 20
 
@@ -96,6 +112,12 @@ struct WaveScratch {
     double upds[2 * kUpd];   // ... and own sampling probability at every traverser node with > 1 action
     uint16_t updI[2 * kUpd]; // ... and its infoset
     int8_t p6[2 * 60];       // resolved leaf payoffs x2 (traverser's sign) per task
+    // the pair's random draws, one Philox block per (traverser, ntl, branch prefix): 53-bit integers.  Only the halves that are
+    // consumed are kept: words 0,1 (kx) feed the opponent node, words 2,3 (ky) the traverser node below it.
+    unsigned long long kx0[86];  // traverser 0: opponent nodes of plies 1,3,5   (blocks 1..85; slot 0 unused)
+    unsigned long long ky0[26];  // traverser 0: traverser nodes of plies 0,2,4
+    unsigned long long kx1[26];  // traverser 1: opponent nodes of plies 0,2,4
+    unsigned long long ky1[26];  // traverser 1: traverser nodes of plies 1,3,5
 };
 static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch must keep 16-byte alignment");
 
@@ -108,12 +130,35 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// All random draws of one traversal pair in a dense pre-pass: 86 + 26 Philox blocks over 64 lanes (2 rounds = 40 64-bit
+// multiplies per wavefront instead of one Philox per ply round at 3-60 % lane use).  Block (traverser, ntl, j): j indexes the
+// branch prefix in the same mixed radix (5,4,3) as the node index of its ply; counter = (ntl + 16*digits, b, iteration, traverser).
+__device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const int item = r * 64 + lane;
+        if (item < 86 + 26) {
+            const int trav = item < 86 ? 0 : 1, blk = trav ? item - 86 : item;
+            const int ntl = blk == 0 ? 0 : blk < 6 ? 1 : blk < 26 ? 2 : 3;
+            const int j = blk - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26);
+            uint32_t dig;
+            if (ntl <= 1) dig = (uint32_t)j;
+            else if (ntl == 2) dig = (uint32_t)(j / 4) | ((uint32_t)(j % 4) << 3);
+            else dig = (uint32_t)(j / 12) | ((uint32_t)((j / 3) % 4) << 3) | ((uint32_t)(j % 3) << 6);
+            const philox_out x = philox4x32_10((uint32_t)ntl + 16u * dig, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
+            const unsigned long long kx = k53(x.x0, x.x1), ky = k53(x.x2, x.x3);
+            if (trav == 0) { ws.kx0[blk] = kx; if (blk < 26) ws.ky0[blk] = ky; }
+            else           { ws.kx1[blk] = kx; ws.ky1[blk] = ky; }
+        }
+    }
+    wave_lds_sync();
+}
+
 // One ply of one traversal pair: lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's.
 template <int D>
 __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf,
                                                  const double *__restrict__ s_sigcdf, uint8_t *__restrict__ s_seen,
-                                                 unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration,
-                                                 uint32_t seed_lo, uint32_t seed_hi) {
+                                                 unsigned int *__restrict__ s_cnt) {
     constexpr int n = 4 - (D >> 1);
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
     NodeRec *rec_out = (D & 1) ? ws.recB : ws.recA;
@@ -128,32 +173,26 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
             const bool is_trav = (D & 1) == trav;
             const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
             int idx = 0;
-            uint32_t dig = 0;
-            double reach = 1.0, samp = 1.0, u_in = 0.0;
+            double reach = 1.0, samp = 1.0;
             if (D > 0) {
                 constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
                 const bool p_trav = (pd & 1) == trav;
-                int pj = j, k = 0;
-                if (p_trav) { pj = j / (pn + 1); k = j - pj * (pn + 1); }
+                int pj = j, br = 0;
+                if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
                 const NodeRec pr = rec_in[(trav ? task_nodes(0, pd) : 0) + pj];
-                const int act = (p_trav && k > 0) ? k - 1 : pr.a;
-                const double sg = s_sigcdf[s_inf[level_offset(pd) + pr.idx] * 8 + act];
+                const int act = (p_trav && br > 0) ? br - 1 : pr.a;
+                const double sg = s_sigcdf[pr.inf * 8 + act];
                 idx = pr.idx * pn + act;
-                dig = pr.dig;
-                if (p_trav) { samp = pr.samp * sg; reach = pr.reach; dig |= (uint32_t)k << (3 * (trav == 0 ? (pd + 1) >> 1 : pd >> 1)); }
+                if (p_trav) { samp = pr.samp * sg; reach = pr.reach; }
                 else        { reach = pr.reach * sg; samp = pr.samp; }
-                u_in = pr.u_next;
             }
             const int In = s_inf[level_offset(D) + idx];
             s_seen[In] = 1;  // benign race: every writer stores 1
-            double u = u_in, u_next = 0.0;
-            if (!is_trav || D == 0) {  // opponent node (or traverser 0's root): this path prefix's Philox block
-                const philox_out x = philox4x32_10((uint32_t)ntl + 16u * dig, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
-                u_next = u53(x.x2, x.x3);
-                u = is_trav ? u_next : u53(x.x0, x.x1);
-            }
-            const double *row = s_sigcdf + In * 8;
-            int a = (row[4] <= u) + (row[5] <= u) + (row[6] <= u) + (row[7] <= u);
+            // this node's draw: block (ntl, j) of its traverser, prepared by draw_pair()
+            const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
+            const unsigned long long k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
+            const unsigned long long *thr = reinterpret_cast<const unsigned long long *>(s_sigcdf + In * 8 + 4);
+            int a = (thr[0] <= k) + (thr[1] <= k) + (thr[2] <= k) + (thr[3] <= k);
             a = a < n - 1 ? a : n - 1;
             if (is_trav) {  // what the update step needs (mc_cfr.py:81-82)
                 const int x = trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + j;
@@ -163,9 +202,8 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
                 atomicAdd(&s_cnt[In], 1u);
             }
             NodeRec out;
-            out.reach = reach; out.samp = samp; out.u_next = u_next;
-            out.idx = (uint16_t)idx; out.dig = (uint16_t)dig; out.a = (uint8_t)a;
-            out.pad[0] = out.pad[1] = out.pad[2] = 0;
+            out.reach = reach; out.samp = samp;
+            out.idx = (uint16_t)idx; out.dig = 0; out.inf = (uint16_t)In; out.a = (uint8_t)a; out.pad = 0;
             rec_out[t] = out;
             visited += 1;
         }
@@ -180,13 +218,14 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
                                           uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis) {
+    draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
     // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time)
-    my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-    my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-    my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-    my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-    my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
-    my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, b, iteration, seed_lo, seed_hi);
+    my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
+    my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
+    my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
+    my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
+    my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
+    my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
     // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts
     for (int t = lane; t < 2 * 60; t += 64) {
         const int trav = t < 60 ? 0 : 1;
@@ -563,7 +602,7 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
                     for (int c = 0; c < 4; c++) R[c] = g_regret[f.I * 4 + c];
                     mc_sigma(R, n, f.sigma);
                     double cdf[4];
-                    choice_cdf(f.sigma, n, cdf);
+                    choice_cdf_f64(f.sigma, n, cdf);
                     const double u = upos < n_uniforms ? uniforms[upos] : 0.0;
                     upos++;
                     int a = (cdf[0] <= u) + (cdf[1] <= u) + (cdf[2] <= u) + (cdf[3] <= u);
