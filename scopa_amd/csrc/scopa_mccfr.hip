@@ -86,6 +86,10 @@ struct NodeRec {      // 24 bytes, one per recursion-tree node of the ply being 
 };
 static_assert(sizeof(NodeRec) == 24, "NodeRec must be 24 bytes");
 
+constexpr int kRow = 7;   // doubles per frozen row in LDS: sigma[4] | 3 cdf thresholds.  The last threshold of a row is always >= 2^53
+                           // (cdf[n-1] = 1.0, padding = ~0) and never counts, so it is not kept; the 56-byte stride also spreads
+                           // random-row gathers over 32 bank alignments (64-byte rows could only start at 4 of them: every gather
+                           // was >= 4-way bank-conflicted, SQ_LDS_BANK_CONFLICT = 47 % of LDS cycles)
 constexpr int kUpd = 26;  // traverser nodes with > 1 legal action per task: 1 + 5 + 20
 
 }  // namespace
@@ -181,7 +185,7 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
                 if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
                 const NodeRec pr = rec_in[(trav ? task_nodes(0, pd) : 0) + pj];
                 const int act = (p_trav && br > 0) ? br - 1 : pr.a;
-                const double sg = s_sigcdf[pr.inf * 8 + act];
+                const double sg = s_sigcdf[pr.inf * kRow + act];
                 idx = pr.idx * pn + act;
                 if (p_trav) { samp = pr.samp * sg; reach = pr.reach; }
                 else        { reach = pr.reach * sg; samp = pr.samp; }
@@ -191,8 +195,8 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
             // this node's draw: block (ntl, j) of its traverser, prepared by draw_pair()
             const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
             const unsigned long long k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
-            const unsigned long long *thr = reinterpret_cast<const unsigned long long *>(s_sigcdf + In * 8 + 4);
-            int a = (thr[0] <= k) + (thr[1] <= k) + (thr[2] <= k) + (thr[3] <= k);
+            const unsigned long long *thr = reinterpret_cast<const unsigned long long *>(s_sigcdf + In * kRow + 4);
+            int a = (thr[0] <= k) + (thr[1] <= k) + (thr[2] <= k);  // thr[3] >= 2^53 > k always
             a = a < n - 1 ? a : n - 1;
             if (is_trav) {  // what the update step needs (mc_cfr.py:81-82)
                 const int x = trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + j;
@@ -261,7 +265,7 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         double cfv[4], v = 0.0;
         for (int i = 0; i < nX; i++) {
             cfv[i] = 0.5 * (double)p6[base + (i + 1) * stride];
-            v = fma(s_sigcdf[IX * 8 + i], cfv[i], v);      // np.dot on this numpy build: an fma chain (see oracle)
+            v = fma(s_sigcdf[IX * kRow + i], cfv[i], v);      // np.dot on this numpy build: an fma chain (see oracle)
         }
         for (int i = 0; i < nX; i++) {
             const double delta = w * (cfv[i] - v);
@@ -279,8 +283,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     const int I = n_infosets;
-    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][8]: sigma[4] | normalised cdf[4]
-    double *s_dR = s_sigcdf + (size_t)I * 8;                                     // [I][4]
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | cdf thresholds[4] | pad
+    double *s_dR = s_sigcdf + (size_t)I * kRow + (I & 1);                        // [I][4] (16-byte aligned)
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));  // [I] traverser visits
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));  // [1653] (+pad)
@@ -290,10 +294,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     if (tid < 2) s_vis[tid] = 0u;
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
-    for (int i = tid; i < I * 4; i += blockDim.x) {  // 16-byte copies of the prepared rows
-        reinterpret_cast<double2 *>(s_sigcdf)[i] = reinterpret_cast<const double2 *>(g_sigcdf)[i];
-        s_dR[i] = 0.0;
-    }
+    for (int i = tid; i < I * 8; i += blockDim.x) if ((i & 7) < kRow) s_sigcdf[(i >> 3) * kRow + (i & 7)] = g_sigcdf[i];  // prepared rows, re-strided
+    for (int i = tid; i < I * 4; i += blockDim.x) s_dR[i] = 0.0;
     for (int r = tid; r < I; r += blockDim.x) { s_cnt[r] = 0u; s_seen[r] = 0; }
     for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
@@ -345,8 +347,8 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         g_strat += deal * kDecision * 4; g_meta += deal * 8; g_visit += deal * kDecision; g_counters += deal * 8;
     }
     const int I = g_meta[0];
-    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][8] frozen rows
-    double *s_R = s_sigcdf + (size_t)I * 8;                                      // [I][4] live regret table
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow] frozen rows
+    double *s_R = s_sigcdf + (size_t)I * kRow + (I & 1);                         // [I][4] live regret table
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_R + (size_t)I * 4);
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));
@@ -367,7 +369,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
             double sg[4], cd[4];
             mc_sigma(s_R + r * 4, n, sg);
             choice_cdf(sg, n, cd);
-            for (int c = 0; c < 4; c++) { s_sigcdf[r * 8 + c] = sg[c]; s_sigcdf[r * 8 + 4 + c] = cd[c]; }
+            for (int c = 0; c < 4; c++) { s_sigcdf[r * kRow + c] = sg[c]; if (c < 3) s_sigcdf[r * kRow + 4 + c] = cd[c]; }
         }
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
@@ -377,7 +379,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
             const unsigned int c = s_cnt[r];
             if (c) {
                 const int n = (int)((g_key[r] >> 1) & 7);
-                for (int k = 0; k < n; k++) g_strat[r * 4 + k] += (double)c * s_sigcdf[r * 8 + k];
+                for (int k = 0; k < n; k++) g_strat[r * 4 + k] += (double)c * s_sigcdf[r * kRow + k];
                 s_cnt[r] = 0u;
             }
         }
@@ -650,7 +652,7 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 static size_t traverse_lds_bytes(int n_infosets, int waves) {
-    size_t b = (size_t)n_infosets * (8 + 4) * sizeof(double);  // sigma|cdf rows, delta table
+    size_t b = ((size_t)n_infosets * (kRow + 4) + (n_infosets & 1)) * sizeof(double);  // sigma|cdf rows (padded), delta table
     b += (size_t)waves * sizeof(WaveScratch);                  // per-wavefront records
     b += (((size_t)n_infosets * 4 + 15) & ~(size_t)15);        // visit counts
     b += 1656 * 2 + 576;                                       // node -> infoset, leaf payoffs
@@ -717,7 +719,7 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
                            unsigned long long *d_counters, uint64_t seed, uint32_t iter0, uint32_t n_iters, uint32_t batch) {
     int waves = 16;
     auto need = [&](int w) {
-        size_t b = (size_t)max_infosets * (8 + 4) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
+        size_t b = ((size_t)max_infosets * (kRow + 4) + 1) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
         b += (((size_t)max_infosets * 4 + 15) & ~(size_t)15) + 1656 * 2 + 576 + (size_t)max_infosets;
         return (b + 15) & ~(size_t)15;
     };
