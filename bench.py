@@ -47,6 +47,36 @@ def cpu_baseline(batch, target_s=12.0):
             "reference_python_note": "rug-marl-group2/scopa MCCFRTrainer on 1 Xeon core, measured in the survey container (BASELINE.md); the reference cannot run on the GPU box"}
 
 
+def _cpu_worker(args):
+    """One oracle replica on one core (spawned process: no GPU state is inherited)."""
+    batch, target_s, salt = args
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    t = O.Tree(seed=42)
+    R, S, _ = t.tables()
+    visits, iters, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_s:
+        visits += t.mccfr_batched(R, S, 0x5C09A + salt, iters, 1, batch)
+        iters += 1
+    return visits, time.perf_counter() - t0
+
+
+def cpu_baseline_all_cores(batch, target_s=6.0):
+    """The same oracle workload as independent replicas on every host core: the reference is
+    single-threaded, so 'all cores' can only mean replicas."""
+    import multiprocessing as mp
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    n = max(1, min(avail, 16))  # a 1-GPU box's CPU share is 16 cores
+    with mp.get_context("spawn").Pool(n) as pool:
+        res = pool.map(_cpu_worker, [(min(batch, 1024), target_s, i) for i in range(n)])
+    rate = sum(v / dt for v, dt in res)
+    return {"value": rate, "unit": "infoset-traversals/s", "cores": n, "kind": "port",
+            "sample": f"{n} independent oracle replicas x {target_s:.0f} s of the same MCCFR workload"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -152,8 +182,26 @@ def main():
                                  "(tables, tree) is LDS-resident by design, so HBM traffic is far below the algorithmic bytes"},
             "decision_visits": visits,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
+            try:
+                out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(args.batch)
+            except Exception as e:  # a baseline, never a reason to lose the GPU line
+                out["cpu_baseline_all_cores"] = {"error": repr(e)}
+            out["gpu_over_cpu_1core"] = out["value"] / out["cpu_baseline"]["value"]
+            # the same engine at a large batch (not the headline: BASELINE configs[1] is B=4096), for the throughput ceiling
+            try:
+                big = 65536
+                ctx.mccfr_iterate(big, 20)
+                torch.cuda.synchronize()
+                c0, _ = ctx.counters()
+                tb = time.perf_counter()
+                ctx.mccfr_iterate(big, 200)
+                torch.cuda.synchronize()
+                dtb = time.perf_counter() - tb
+                out["large_batch"] = {"batch_per_gpu": big, "value": (ctx.counters()[0] - c0) / dtb, "ms_per_step": 1e3 * dtb / 200}
+            except Exception as e:
+                out["large_batch"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()
