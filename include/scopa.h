@@ -224,6 +224,9 @@ int32_t scopa_multi_set_perms(scopa_multi *m, const uint8_t *h_perms /*[n][16]*/
 int32_t scopa_multi_perms_get(scopa_multi *m, uint8_t *h_perms);
 int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets);
 int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters);
+/* the same exact solve with one LANE per deal (64 deals share an instruction stream: the tree shape is deal-independent),
+ * tables gathered from HBM: the throughput form for thousands of deals; bit-identical results */
+int32_t scopa_multi_cfr_exact_iterate_lanes(scopa_multi *m, int32_t n_iters);
 int32_t scopa_multi_cfr_sync_iterate(scopa_multi *m, int32_t n_iters);
 /* batched MCCFR on every deal at once, persistent: one workgroup per deal keeps the deal's regret table in LDS and runs all
  * n_iters iterations of `batch` traversal pairs without leaving the kernel; same definition (frozen tables per iteration,

@@ -27,7 +27,7 @@ SYMBOLS = [
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
-    "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
+    "scopa_multi_cfr_exact_iterate_lanes", "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
     "scopa_full_state_init", "scopa_full_state_step", "scopa_full_state_legal", "scopa_full_state_infoset_string",
     "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
@@ -135,6 +135,7 @@ def lib():
         "scopa_multi_build": (i32, [vp, vp]),
         "scopa_multi_cfr_exact_iterate": (i32, [vp, i32]),
         "scopa_multi_cfr_sync_iterate": (i32, [vp, i32]),
+        "scopa_multi_cfr_exact_iterate_lanes": (i32, [vp, i32]),
         "scopa_multi_exploitability": (i32, [vp, vp]),
         "scopa_multi_mccfr_iterate": (i32, [vp, u32, u32, u64]),
         "scopa_multi_tables_get": (i32, [vp, i32, vp, vp, vp, vp]),
@@ -531,6 +532,9 @@ class MultiDeal:
 
     def cfr_exact_iterate(self, n_iters):
         self.ctx._ck(self._L.scopa_multi_cfr_exact_iterate(self._h, int(n_iters)), "scopa_multi_cfr_exact_iterate")
+
+    def cfr_exact_iterate_lanes(self, n_iters):
+        self.ctx._ck(self._L.scopa_multi_cfr_exact_iterate_lanes(self._h, int(n_iters)), "scopa_multi_cfr_exact_iterate_lanes")
 
     def cfr_sync_iterate(self, n_iters):
         self.ctx._ck(self._L.scopa_multi_cfr_sync_iterate(self._h, int(n_iters)), "scopa_multi_cfr_sync_iterate")

@@ -32,6 +32,8 @@ struct scopa_multi {
     unsigned long long *d_counters = nullptr;  // [n][8]
     double *d_out = nullptr;         // [n][4] exploitability outputs
     int64_t *d_seeds = nullptr;      // [n]
+    uint16_t *d_infoset_T = nullptr; // [1653][n]  node-major copies for the lane-per-deal kernel (coalesced across deals)
+    int8_t *d_payoff_T = nullptr;    // [576][n]
     uint32_t mccfr_iteration = 0;
 };
 
@@ -82,6 +84,103 @@ __global__ void __launch_bounds__(64) k_deal_py_seed(const int64_t *__restrict__
     for (int c = 0; c < 16; c++) perms[(size_t)i * 16 + c] = perm[c];
 }
 
+// ---- lane-per-deal exact CFR: the HBM-bound way to run many sequential solves ----------------------------------------
+// The reference's vanilla CFR is one sequential DFS per solve (vanilla_cfr.py:56-99), but the tree SHAPE is the same for every
+// deal (legal counts 4,4,3,3,2,2,1,1), so 64 deals can share one instruction stream with no divergence: lane = deal, the DFS
+// position (ply, node index) is wave-uniform, only the infoset id at that position -- and therefore which table rows are
+// touched -- differs per lane.  Node -> infoset maps and payoffs are stored node-major ([node][deal]) so those reads are
+// coalesced across lanes; the three float64 tables of each deal (159 KB) stay in HBM and are gathered row by row.
+// With tens of thousands of deals resident (10+ GB) every SIMD has eight wavefronts of independent solves to hide the
+// gathers behind.  Arithmetic and visit order per deal are exactly k_cfr_exact's, hence bit-identical to the reference.
+namespace {
+struct LaneCtx {
+    const uint16_t *inf_T;   // [1653][n]
+    const int8_t *pay_T;     // [576][n]
+    double *R, *S, *L;       // this deal's tables
+    size_t n;                // deals (stride of the node-major maps)
+    size_t deal;
+    int trav;
+    unsigned long long dvis, tvis;
+};
+
+template <int D>
+__device__ __forceinline__ double lane_rec(LaneCtx &c, int idx, double r0, double r1) {
+    if constexpr (D == kPlies) {
+        c.tvis++;
+        const int p0 = c.pay_T[(size_t)idx * c.n + c.deal];
+        return 0.5 * (double)(c.trav == 0 ? p0 : -p0);
+    } else {
+        constexpr int n = 4 - (D >> 1), p = D & 1;
+        c.dvis++;
+        const int I = c.inf_T[(size_t)(level_offset(D) + idx) * c.n + c.deal];
+        double ls[4], au[4];
+        {   // one 32-byte gather; local_strategy of this infoset cannot change before this visit ends (its other nodes are on the same ply)
+            const double2 a = reinterpret_cast<const double2 *>(c.L + (size_t)I * 4)[0], b = reinterpret_cast<const double2 *>(c.L + (size_t)I * 4)[1];
+            ls[0] = a.x; ls[1] = a.y; ls[2] = b.x; ls[3] = b.y;
+        }
+#pragma unroll 1
+        for (int i = 0; i < n; i++)
+            au[i] = lane_rec<D + 1>(c, idx * n + i, p == 0 ? r0 * ls[i] : r0, p == 1 ? r1 * ls[i] : r1);
+        double v = ls[0] * au[0];
+        for (int i = 1; i < n; i++) v += ls[i] * au[i];
+        double Rr[4] = {0.0, 0.0, 0.0, 0.0};
+        {
+            const double2 a = reinterpret_cast<const double2 *>(c.R + (size_t)I * 4)[0], b = reinterpret_cast<const double2 *>(c.R + (size_t)I * 4)[1];
+            Rr[0] = a.x; Rr[1] = a.y; Rr[2] = b.x; Rr[3] = b.y;
+        }
+        if (p == c.trav) {
+            const double reach = c.trav == 0 ? r0 : r1, opp = c.trav == 0 ? r1 : r0;
+            double Sr[4];
+            {
+                const double2 a = reinterpret_cast<const double2 *>(c.S + (size_t)I * 4)[0], b = reinterpret_cast<const double2 *>(c.S + (size_t)I * 4)[1];
+                Sr[0] = a.x; Sr[1] = a.y; Sr[2] = b.x; Sr[3] = b.y;
+            }
+            for (int i = 0; i < n; i++) { Rr[i] += opp * (au[i] - v); Sr[i] += reach * ls[i]; }
+            reinterpret_cast<double2 *>(c.R + (size_t)I * 4)[0] = make_double2(Rr[0], Rr[1]);
+            reinterpret_cast<double2 *>(c.R + (size_t)I * 4)[1] = make_double2(Rr[2], Rr[3]);
+            reinterpret_cast<double2 *>(c.S + (size_t)I * 4)[0] = make_double2(Sr[0], Sr[1]);
+            reinterpret_cast<double2 *>(c.S + (size_t)I * 4)[1] = make_double2(Sr[2], Sr[3]);
+        }
+        double pos[4] = {0.0, 0.0, 0.0, 0.0};  // regret matching on the (possibly just updated) row: local_strategy refresh (:97)
+        for (int i = 0; i < n; i++) pos[i] = Rr[i] > 0.0 ? Rr[i] : 0.0;
+        double sm = pos[0];
+        for (int i = 1; i < n; i++) sm += pos[i];
+        double nl[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = 0; i < n; i++) nl[i] = sm > 0.0 ? pos[i] / sm : 1.0 / (double)n;
+        reinterpret_cast<double2 *>(c.L + (size_t)I * 4)[0] = make_double2(nl[0], nl[1]);
+        reinterpret_cast<double2 *>(c.L + (size_t)I * 4)[1] = make_double2(nl[2], nl[3]);
+        return v;
+    }
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_transpose_maps(const uint16_t *__restrict__ inf, const int8_t *__restrict__ pay,
+                                                        uint16_t *__restrict__ inf_T, int8_t *__restrict__ pay_T, long long n) {
+    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;  // over n * 1653
+    if (i < n * kDecision) { const long long d = i / kDecision, k = i - d * kDecision; inf_T[k * n + d] = inf[i]; }
+    if (i < n * kTerminal) { const long long d = i / kTerminal, k = i - d * kTerminal; pay_T[k * n + d] = pay[i]; }
+}
+
+__global__ void __launch_bounds__(64)
+k_cfr_exact_lanes(const uint16_t *__restrict__ inf_T, const int8_t *__restrict__ pay_T, double *__restrict__ g_regret, double *__restrict__ g_strat,
+                  double *__restrict__ g_local, const int32_t *__restrict__ g_meta, uint32_t *__restrict__ g_visit,
+                  unsigned long long *__restrict__ g_counters, long long n, int n_iters) {
+    const long long deal = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (deal >= n) return;  // the tail wavefront simply has fewer lanes
+    LaneCtx c;
+    c.inf_T = inf_T; c.pay_T = pay_T; c.n = (size_t)n; c.deal = (size_t)deal;
+    c.R = g_regret + (size_t)deal * kDecision * 4; c.S = g_strat + (size_t)deal * kDecision * 4; c.L = g_local + (size_t)deal * kDecision * 4;
+    c.dvis = 0; c.tvis = 0;
+    for (int it = 0; it < n_iters; it++)
+        for (int trav = 0; trav < 2; trav++) { c.trav = trav; lane_rec<0>(c, 0, 1.0, 1.0); }
+    g_counters[deal * 8] += c.dvis;
+    g_counters[deal * 8 + 1] += c.tvis;
+    if (n_iters > 0) {  // a full traversal visits every infoset, in id order (ids ARE the DFS first-visit order)
+        const int I = g_meta[deal * 8];
+        for (int r = 0; r < I; r++) if (g_visit[deal * kDecision + r] == 0u) g_visit[deal * kDecision + r] = (uint32_t)r + 1u;
+    }
+}
+
 extern "C" {
 
 int32_t scopa_multi_destroy(scopa_multi *m);
@@ -101,7 +200,8 @@ int32_t scopa_multi_create(scopa_ctx *ctx, int32_t n_deals, scopa_multi **out) {
               hipMalloc(&m->d_regret, n * kDecision * 32) == hipSuccess && hipMalloc(&m->d_strat, n * kDecision * 32) == hipSuccess &&
               hipMalloc(&m->d_local, n * kDecision * 32) == hipSuccess && hipMalloc(&m->d_visit, n * kDecision * 4) == hipSuccess &&
               hipMalloc(&m->d_counters, n * 8 * 8) == hipSuccess && hipMalloc(&m->d_out, n * 4 * 8) == hipSuccess &&
-              hipMalloc(&m->d_seeds, n * 8) == hipSuccess;
+              hipMalloc(&m->d_seeds, n * 8) == hipSuccess && hipMalloc(&m->d_infoset_T, n * kDecision * 2) == hipSuccess &&
+              hipMalloc(&m->d_payoff_T, n * kTerminal) == hipSuccess;
     if (ok) ok = hipMemsetAsync(m->d_counters, 0, n * 64, ctx->stream) == hipSuccess && hipMemsetAsync(m->d_meta, 0, n * 32, ctx->stream) == hipSuccess;
     if (!ok) { scopa_multi_destroy(m); return fail(ctx, SCOPA_ENOMEM, "scopa_multi_create: device allocation failed"); }
     *out = m;
@@ -113,7 +213,7 @@ int32_t scopa_multi_destroy(scopa_multi *m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     void *bufs[] = {m->d_perm, m->d_states, m->d_infoset, m->d_payoff, m->d_key, m->d_meta, m->d_regret, m->d_strat, m->d_local,
-                    m->d_visit, m->d_counters, m->d_out, m->d_seeds};
+                    m->d_visit, m->d_counters, m->d_out, m->d_seeds, m->d_infoset_T, m->d_payoff_T};
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete m;
     return SCOPA_OK;
@@ -162,6 +262,12 @@ int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets) {
     hipLaunchKernelGGL(k_tables_reset, dim3(8, m->n), dim3(1024), 0, ctx->stream, m->d_regret, m->d_strat, m->d_local, m->d_key, m->d_meta);
     SC_HIP(ctx, hipGetLastError());
     SC_HIP(ctx, hipMemsetAsync(m->d_visit, 0, (size_t)m->n * kDecision * 4, ctx->stream));
+    {
+        const long long total = (long long)m->n * kDecision;
+        hipLaunchKernelGGL(k_transpose_maps, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, m->d_infoset, m->d_payoff,
+                           m->d_infoset_T, m->d_payoff_T, (long long)m->n);
+        SC_HIP(ctx, hipGetLastError());
+    }
     std::vector<int32_t> meta((size_t)m->n * 8);
     SC_HIP(ctx, hipMemcpyAsync(meta.data(), m->d_meta, meta.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -190,6 +296,19 @@ int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters) {
                                     ctx->lds_limit - (int)static_lds));
     hipLaunchKernelGGL(k_cfr_exact, dim3(m->n), dim3(256), use_lds ? lds : 0, ctx->stream, m->d_infoset, m->d_payoff, m->d_regret, m->d_strat,
                        m->d_local, 0 /* multi-deal */, n_iters * 2, 0, (double *)nullptr, m->d_counters, use_lds, m->d_visit, m->d_meta, 0, 0, 1.0, 1.0);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return SCOPA_OK;
+}
+
+int32_t scopa_multi_cfr_exact_iterate_lanes(scopa_multi *m, int32_t n_iters) {
+    if (!m || n_iters < 0 || n_iters > (1 << 20)) return SCOPA_EINVAL;
+    scopa_ctx *ctx = m->ctx;
+    SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_exact_iterate_lanes: call scopa_multi_build first");
+    if (!n_iters) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_cfr_exact_lanes, dim3((m->n + 63) / 64), dim3(64), 0, ctx->stream, m->d_infoset_T, m->d_payoff_T, m->d_regret,
+                       m->d_strat, m->d_local, m->d_meta, m->d_visit, m->d_counters, (long long)m->n, (int)n_iters);
     SC_HIP(ctx, hipGetLastError());
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCOPA_OK;

@@ -94,3 +94,28 @@ def test_multi_deal_persistent_mccfr_matches_oracle(ctx, sl, oracle):
     np.testing.assert_allclose(Rg, R1, rtol=1e-10, atol=1e-10)
     np.testing.assert_allclose(Sg, S1, rtol=1e-10, atol=1e-10)
     m.close()
+
+
+def test_lane_per_deal_exact_cfr_is_bit_identical(ctx, sl, oracle, golden):
+    """scopa_multi_cfr_exact_iterate_lanes (64 deals per wavefront, tables gathered from HBM) against the workgroup-per-deal
+    kernel on every deal, against the oracle on a sample, and against the reference's own tables on the seed-42 deal."""
+    n = 200                                   # 3 full wavefronts + a ragged one
+    seeds = [42] + list(range(1, n))
+    a = sl.MultiDeal(ctx, n); b = sl.MultiDeal(ctx, n)
+    a.deal_py_seeds(seeds); b.deal_py_seeds(seeds)
+    ninf = a.build(); assert np.array_equal(ninf, b.build())
+    a.cfr_exact_iterate_lanes(2); a.cfr_exact_iterate_lanes(3)      # resumable: 2 + 3 == 5
+    b.cfr_exact_iterate(5)
+    for i in range(n):
+        Ra, Sa, La, Ka = a.tables_get(i); Rb, Sb, Lb, Kb = b.tables_get(i)
+        assert np.array_equal(Ra, Rb) and np.array_equal(Sa, Sb) and np.array_equal(La, Lb) and np.array_equal(Ka, Kb), seeds[i]
+    assert a.counters() == b.counters() == (3306 * 5 * n, 1152 * 5 * n)
+    assert np.array_equal(a.exploitability(), b.exploitability())
+    g = golden.npz("vanilla_cfr.npz")
+    R, S, L, _ = a.tables_get(0)
+    assert np.array_equal(R, g["it5_regret"]) and np.array_equal(S, g["it5_strategy"]) and np.array_equal(L, g["it5_local"])
+    for i in (1, 63, 64, 199):
+        t = oracle.Tree(seed=seeds[i]); R, S, L = t.tables(); t.cfr_exact(R, S, L, 5)
+        Rg, Sg, Lg, _ = a.tables_get(i)
+        assert np.array_equal(Rg, R) and np.array_equal(Sg, S) and np.array_equal(Lg, L), seeds[i]
+    a.close(); b.close()

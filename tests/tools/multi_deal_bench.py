@@ -15,6 +15,7 @@ def main():
     ap.add_argument("--deals", type=int, default=4096)
     ap.add_argument("--exact-iters", type=int, default=10)
     ap.add_argument("--sync-iters", type=int, default=100)
+    ap.add_argument("--lanes-deals", type=int, default=0, help="also time the lane-per-deal exact CFR kernel on this many deals")
     a = ap.parse_args()
     from scopa_amd import _lib
     import oracle as O
@@ -36,7 +37,21 @@ def main():
     for s in range(k):
         t = O.Tree(seed=s); R, S, L = t.tables(); t.cfr_sync(R, S, a.sync_iters)
     c_sync = (time.perf_counter() - t0) / k
+    lanes = None
+    if a.lanes_deals:
+        n = a.lanes_deals
+        m.close()
+        m = _lib.MultiDeal(ctx, n); m.deal_py_seeds(np.arange(n)); m.build()
+        m.cfr_exact_iterate_lanes(1)
+        t0 = time.perf_counter(); m.cfr_exact_iterate_lanes(a.exact_iters); t_l = time.perf_counter() - t0
+        # algorithmic bytes per deal-iteration: per decision visit one L row read + R row read + L row written (96 B) and, at the
+        # traverser's nodes (half of the visits per traversal), R and S written + S read (96 B more); maps 2 B / 1 B per visit
+        alg = 3306 * 96 + 1653 * 96 + 3306 * 2 + 1152
+        lanes = {"deals": n, "iterations": a.exact_iters, "seconds": t_l, "deal_iterations_per_s": n * a.exact_iters / t_l,
+                 "visits_per_s": n * a.exact_iters * 3306 / t_l, "tables_resident_GB": n * 1653 * 96 / 1e9,
+                 "algorithmic_GBps": n * a.exact_iters * alg / t_l / 1e9}
     print(json.dumps({
+        "lane_per_deal_exact_cfr": lanes,
         "deals": a.deals, "hbm_resident_MB": round(a.deals * (2229 * 16 + 1653 * (2 + 8 + 4 + 96) + 576) / 1e6, 1),
         "infosets_min_mean_max": [int(ninf.min()), float(ninf.mean()), int(ninf.max())],
         "deal_on_device_ms": 1e3 * t_deal, "tree_build_ms": 1e3 * t_build,
