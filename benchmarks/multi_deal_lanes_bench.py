@@ -8,10 +8,9 @@ import argparse, json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
-# algorithmic bytes per deal-iteration (two traversals, 3306 decision visits + 1152 leaves): every decision visit reads its
-# local_strategy row and regret row and writes local_strategy (3 x 32 B); the traverser's visits (1653 per iteration) also read
-# strategy_sum and write regret_sum and strategy_sum (3 x 32 B); node->infoset map 2 B per visit, payoff 1 B per leaf.
-ALG_BYTES = 3306 * 96 + 1653 * 96 + 3306 * 2 + 1152
+# algorithmic bytes: SURVEY.md 8(d) prices vanilla CFR at 192 B per decision visit (state 32 B, regret row 32 B, local_strategy
+# read + write 64 B, and at the traverser's half of the visits regret/strategy read-modify-write 128 B); 3306 visits per iteration.
+ALG_BYTES = 3306 * 192
 
 
 def main():
@@ -32,7 +31,7 @@ def main():
     e = m.exploitability()
     print(json.dumps({"workload": "vanilla CFR, %d deals x %d iterations, one deal per lane" % (a.deals, a.iters), "deals": a.deals,
                       "iterations": a.iters, "seconds": best, "deal_iterations_per_s": a.deals * a.iters / best,
-                      "visits_per_s": a.deals * a.iters * 3306 / best, "tables_resident_GB": a.deals * 1653 * 96 / 1e9,
+                      "visits_per_s": a.deals * a.iters * 3306 / best, "row_image_resident_GB": a.deals * 1653 * 64 / 1e9,
                       "tree_build_s": t_build, "algorithmic_bytes_per_deal_iteration": ALG_BYTES,
                       "algorithmic_GBps": a.deals * a.iters * ALG_BYTES / best / 1e9, "mean_exploitability": float(e[:, 0].mean())}))
     m.close()

@@ -34,6 +34,8 @@ struct scopa_multi {
     int64_t *d_seeds = nullptr;      // [n]
     uint16_t *d_infoset_T = nullptr; // [1653][n]  node-major copies for the lane-per-deal kernel (coalesced across deals)
     int8_t *d_payoff_T = nullptr;    // [576][n]
+    double *d_rows = nullptr;        // [n][1653][8]  lane-per-deal kernel's table image: one 64-byte row per infoset = regret[4] strategy[4]
+    bool rows_current = false;       // the tables live in d_rows (true) or in d_regret/d_strat/d_local (false)
     uint32_t mccfr_iteration = 0;
 };
 
@@ -87,68 +89,67 @@ __global__ void __launch_bounds__(64) k_deal_py_seed(const int64_t *__restrict__
 // ---- lane-per-deal exact CFR: the HBM-bound way to run many sequential solves ----------------------------------------
 // The reference's vanilla CFR is one sequential DFS per solve (vanilla_cfr.py:56-99), but the tree SHAPE is the same for every
 // deal (legal counts 4,4,3,3,2,2,1,1), so 64 deals can share one instruction stream with no divergence: lane = deal, the DFS
-// position (ply, node index) is wave-uniform, only the infoset id at that position -- and therefore which table rows are
+// position (ply, node index) is wave-uniform, only the infoset id at that position -- and therefore which table row is
 // touched -- differs per lane.  Node -> infoset maps and payoffs are stored node-major ([node][deal]) so those reads are
-// coalesced across lanes; the three float64 tables of each deal (159 KB) stay in HBM and are gathered row by row.
-// With tens of thousands of deals resident (10+ GB) every SIMD has eight wavefronts of independent solves to hide the
-// gathers behind.  Arithmetic and visit order per deal are exactly k_cfr_exact's, hence bit-identical to the reference.
+// coalesced across lanes; the tables stay in HBM and are gathered row by row.
+//
+// Table image: ONE 64-BYTE ROW PER INFOSET = regret_sum[4] | strategy_sum[4] (one DRAM burst), and no local_strategy at all:
+// the reference refreshes local_strategy = get_strategy() at the end of EVERY visit (vanilla_cfr.py:97) and regret_sum only
+// changes inside visits, so between visits local_strategy == regret_matching(regret_sum) holds identically (InfoNode starts
+// with zeros / uniform, which is the same statement).  The kernel therefore reads the regret row on entry, derives the
+// strategy, and only the traverser's nodes write anything (regret | strategy, one full 64-byte store).  Per decision visit
+// that is one 64-byte fetch and half a 64-byte store instead of the 3 reads + 1-3 writes of 32 bytes of the literal form.
+// k_rows_pack refuses tables for which the invariant does not hold (tables written by another solver).
+// Arithmetic and visit order per deal are exactly k_cfr_exact's, hence bit-identical to the reference.
 namespace {
 struct LaneCtx {
     const uint16_t *inf_T;   // [1653][n]
     const int8_t *pay_T;     // [576][n]
-    double *R, *S, *L;       // this deal's tables
+    double *rows;            // this deal's [1653][8] table image
     size_t n;                // deals (stride of the node-major maps)
     size_t deal;
-    int trav;
     unsigned long long dvis, tvis;
 };
 
-template <int D>
+template <int N>
+__device__ __forceinline__ void regret_match(const double (&R)[4], double (&out)[4]) {  // InfoNode.get_strategy, vanilla_cfr.py:23-30
+    double pos[4];
+    for (int i = 0; i < N; i++) pos[i] = R[i] > 0.0 ? R[i] : 0.0;
+    double sm = pos[0];
+    for (int i = 1; i < N; i++) sm += pos[i];
+    for (int i = 0; i < 4; i++) out[i] = i < N ? (sm > 0.0 ? pos[i] / sm : 1.0 / (double)N) : 0.0;
+}
+
+template <int D, int TRAV>
 __device__ __forceinline__ double lane_rec(LaneCtx &c, int idx, double r0, double r1) {
     if constexpr (D == kPlies) {
         c.tvis++;
         const int p0 = c.pay_T[(size_t)idx * c.n + c.deal];
-        return 0.5 * (double)(c.trav == 0 ? p0 : -p0);
+        return 0.5 * (double)(TRAV == 0 ? p0 : -p0);
     } else {
         constexpr int n = 4 - (D >> 1), p = D & 1;
         c.dvis++;
         const int I = c.inf_T[(size_t)(level_offset(D) + idx) * c.n + c.deal];
+        double2 *row = reinterpret_cast<double2 *>(c.rows + (size_t)I * 8);
         double ls[4], au[4];
-        {   // one 32-byte gather; local_strategy of this infoset cannot change before this visit ends (its other nodes are on the same ply)
-            const double2 a = reinterpret_cast<const double2 *>(c.L + (size_t)I * 4)[0], b = reinterpret_cast<const double2 *>(c.L + (size_t)I * 4)[1];
-            ls[0] = a.x; ls[1] = a.y; ls[2] = b.x; ls[3] = b.y;
+        {   // this infoset's regret row cannot change before this visit ends: its other nodes are on the same ply
+            const double2 a = row[0], b = row[1];
+            const double Rr[4] = {a.x, a.y, b.x, b.y};
+            regret_match<n>(Rr, ls);
         }
 #pragma unroll 1
         for (int i = 0; i < n; i++)
-            au[i] = lane_rec<D + 1>(c, idx * n + i, p == 0 ? r0 * ls[i] : r0, p == 1 ? r1 * ls[i] : r1);
+            au[i] = lane_rec<D + 1, TRAV>(c, idx * n + i, p == 0 ? r0 * ls[i] : r0, p == 1 ? r1 * ls[i] : r1);
         double v = ls[0] * au[0];
         for (int i = 1; i < n; i++) v += ls[i] * au[i];
-        double Rr[4] = {0.0, 0.0, 0.0, 0.0};
-        {
-            const double2 a = reinterpret_cast<const double2 *>(c.R + (size_t)I * 4)[0], b = reinterpret_cast<const double2 *>(c.R + (size_t)I * 4)[1];
-            Rr[0] = a.x; Rr[1] = a.y; Rr[2] = b.x; Rr[3] = b.y;
-        }
-        if (p == c.trav) {
-            const double reach = c.trav == 0 ? r0 : r1, opp = c.trav == 0 ? r1 : r0;
-            double Sr[4];
-            {
-                const double2 a = reinterpret_cast<const double2 *>(c.S + (size_t)I * 4)[0], b = reinterpret_cast<const double2 *>(c.S + (size_t)I * 4)[1];
-                Sr[0] = a.x; Sr[1] = a.y; Sr[2] = b.x; Sr[3] = b.y;
-            }
+        if constexpr (p == TRAV) {
+            const double reach = TRAV == 0 ? r0 : r1, opp = TRAV == 0 ? r1 : r0;
+            const double2 a = row[0], b = row[1], e = row[2], f = row[3];   // the row read on entry, usually still in L2
+            double Rr[4] = {a.x, a.y, b.x, b.y}, Sr[4] = {e.x, e.y, f.x, f.y};
             for (int i = 0; i < n; i++) { Rr[i] += opp * (au[i] - v); Sr[i] += reach * ls[i]; }
-            reinterpret_cast<double2 *>(c.R + (size_t)I * 4)[0] = make_double2(Rr[0], Rr[1]);
-            reinterpret_cast<double2 *>(c.R + (size_t)I * 4)[1] = make_double2(Rr[2], Rr[3]);
-            reinterpret_cast<double2 *>(c.S + (size_t)I * 4)[0] = make_double2(Sr[0], Sr[1]);
-            reinterpret_cast<double2 *>(c.S + (size_t)I * 4)[1] = make_double2(Sr[2], Sr[3]);
+            row[0] = make_double2(Rr[0], Rr[1]); row[1] = make_double2(Rr[2], Rr[3]);
+            row[2] = make_double2(Sr[0], Sr[1]); row[3] = make_double2(Sr[2], Sr[3]);
         }
-        double pos[4] = {0.0, 0.0, 0.0, 0.0};  // regret matching on the (possibly just updated) row: local_strategy refresh (:97)
-        for (int i = 0; i < n; i++) pos[i] = Rr[i] > 0.0 ? Rr[i] : 0.0;
-        double sm = pos[0];
-        for (int i = 1; i < n; i++) sm += pos[i];
-        double nl[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = 0; i < n; i++) nl[i] = sm > 0.0 ? pos[i] / sm : 1.0 / (double)n;
-        reinterpret_cast<double2 *>(c.L + (size_t)I * 4)[0] = make_double2(nl[0], nl[1]);
-        reinterpret_cast<double2 *>(c.L + (size_t)I * 4)[1] = make_double2(nl[2], nl[3]);
         return v;
     }
 }
@@ -161,18 +162,55 @@ __global__ void __launch_bounds__(256) k_transpose_maps(const uint16_t *__restri
     if (i < n * kTerminal) { const long long d = i / kTerminal, k = i - d * kTerminal; pay_T[k * n + d] = pay[i]; }
 }
 
+// tables <-> row image; one thread per infoset row.  pack: checks local_strategy == regret_matching(regret_sum) bit for bit and
+// counts violations in *bad; unpack: writes regret_sum, strategy_sum and the implied local_strategy (zero rows past the deal's
+// infoset count, as scopa_tables_reset leaves them).
+__global__ void __launch_bounds__(256) k_rows_pack(double *__restrict__ R, double *__restrict__ S, double *__restrict__ L, double *__restrict__ rows,
+                                                   const uint64_t *__restrict__ key, const int32_t *__restrict__ meta, long long n_rows, int unpack,
+                                                   unsigned int *__restrict__ bad) {
+    const long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_rows) return;
+    const long long deal = r / kDecision;
+    const int in_deal = (int)(r - deal * kDecision);
+    const bool live = in_deal < meta[deal * 8];
+    const int n = live ? (int)((key[r] >> 1) & 7) : 0;  // legal count = hand size
+    double2 *line = reinterpret_cast<double2 *>(rows + r * 8);
+    double Rr[4], ls[4] = {0.0, 0.0, 0.0, 0.0};
+    if (!unpack) {
+        const double2 a = reinterpret_cast<const double2 *>(R + r * 4)[0], b = reinterpret_cast<const double2 *>(R + r * 4)[1];
+        Rr[0] = a.x; Rr[1] = a.y; Rr[2] = b.x; Rr[3] = b.y;
+        line[0] = a; line[1] = b;
+        line[2] = reinterpret_cast<const double2 *>(S + r * 4)[0]; line[3] = reinterpret_cast<const double2 *>(S + r * 4)[1];
+    } else {
+        const double2 a = line[0], b = line[1];
+        Rr[0] = a.x; Rr[1] = a.y; Rr[2] = b.x; Rr[3] = b.y;
+        reinterpret_cast<double2 *>(R + r * 4)[0] = a; reinterpret_cast<double2 *>(R + r * 4)[1] = b;
+        reinterpret_cast<double2 *>(S + r * 4)[0] = line[2]; reinterpret_cast<double2 *>(S + r * 4)[1] = line[3];
+    }
+    if (n == 4) regret_match<4>(Rr, ls); else if (n == 3) regret_match<3>(Rr, ls); else if (n == 2) regret_match<2>(Rr, ls); else if (n == 1) regret_match<1>(Rr, ls);
+    if (!unpack) {
+        bool same = true;
+        for (int i = 0; i < 4; i++) same = same && __double_as_longlong(L[r * 4 + i]) == __double_as_longlong(ls[i]);
+        if (!same) atomicAdd(bad, 1u);
+    } else {
+        reinterpret_cast<double2 *>(L + r * 4)[0] = make_double2(ls[0], ls[1]); reinterpret_cast<double2 *>(L + r * 4)[1] = make_double2(ls[2], ls[3]);
+    }
+}
+
 __global__ void __launch_bounds__(64)
-k_cfr_exact_lanes(const uint16_t *__restrict__ inf_T, const int8_t *__restrict__ pay_T, double *__restrict__ g_regret, double *__restrict__ g_strat,
-                  double *__restrict__ g_local, const int32_t *__restrict__ g_meta, uint32_t *__restrict__ g_visit,
-                  unsigned long long *__restrict__ g_counters, long long n, int n_iters) {
+k_cfr_exact_lanes(const uint16_t *__restrict__ inf_T, const int8_t *__restrict__ pay_T, double *__restrict__ g_rows, const int32_t *__restrict__ g_meta,
+                  uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_counters, long long n, int n_iters) {
     const long long deal = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (deal >= n) return;  // the tail wavefront simply has fewer lanes
     LaneCtx c;
     c.inf_T = inf_T; c.pay_T = pay_T; c.n = (size_t)n; c.deal = (size_t)deal;
-    c.R = g_regret + (size_t)deal * kDecision * 4; c.S = g_strat + (size_t)deal * kDecision * 4; c.L = g_local + (size_t)deal * kDecision * 4;
+    c.rows = g_rows + (size_t)deal * kDecision * 8;
     c.dvis = 0; c.tvis = 0;
-    for (int it = 0; it < n_iters; it++)
-        for (int trav = 0; trav < 2; trav++) { c.trav = trav; lane_rec<0>(c, 0, 1.0, 1.0); }
+#pragma unroll 1
+    for (int it = 0; it < n_iters; it++) {
+        lane_rec<0, 0>(c, 0, 1.0, 1.0);
+        lane_rec<0, 1>(c, 0, 1.0, 1.0);
+    }
     g_counters[deal * 8] += c.dvis;
     g_counters[deal * 8 + 1] += c.tvis;
     if (n_iters > 0) {  // a full traversal visits every infoset, in id order (ids ARE the DFS first-visit order)
@@ -180,6 +218,33 @@ k_cfr_exact_lanes(const uint16_t *__restrict__ inf_T, const int8_t *__restrict__
         for (int r = 0; r < I; r++) if (g_visit[deal * kDecision + r] == 0u) g_visit[deal * kDecision + r] = (uint32_t)r + 1u;
     }
 }
+
+namespace {
+int32_t rows_convert(scopa_multi *m, bool to_rows) {
+    scopa_ctx *ctx = m->ctx;
+    if (m->rows_current == to_rows) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!m->d_rows) {
+        if (hipMalloc(&m->d_rows, (size_t)m->n * kDecision * 64 + 256) != hipSuccess)
+            return fail(ctx, SCOPA_ENOMEM, "scopa_multi: no device memory for the row-per-infoset table image");
+    }
+    unsigned int *d_bad = reinterpret_cast<unsigned int *>(m->d_rows + (size_t)m->n * kDecision * 8);
+    const long long n_rows = (long long)m->n * kDecision;
+    if (to_rows) SC_HIP(ctx, hipMemsetAsync(d_bad, 0, 4, ctx->stream));
+    hipLaunchKernelGGL(k_rows_pack, dim3((unsigned)((n_rows + 255) / 256)), dim3(256), 0, ctx->stream, m->d_regret, m->d_strat, m->d_local, m->d_rows,
+                       m->d_key, m->d_meta, n_rows, to_rows ? 0 : 1, d_bad);
+    SC_HIP(ctx, hipGetLastError());
+    if (to_rows) {
+        unsigned int bad = 0;
+        SC_HIP(ctx, hipMemcpyAsync(&bad, d_bad, 4, hipMemcpyDeviceToHost, ctx->stream));
+        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        SC_REQUIRE(ctx, bad == 0, SCOPA_ESTATE,
+                   "scopa_multi_cfr_exact_iterate_lanes: local_strategy is not regret-matching of regret_sum (tables written by another solver); use scopa_multi_cfr_exact_iterate");
+    }
+    m->rows_current = to_rows;
+    return SCOPA_OK;
+}
+}  // namespace
 
 extern "C" {
 
@@ -213,7 +278,7 @@ int32_t scopa_multi_destroy(scopa_multi *m) {
     (void)hipSetDevice(m->ctx->device);
     (void)hipStreamSynchronize(m->ctx->stream);
     void *bufs[] = {m->d_perm, m->d_states, m->d_infoset, m->d_payoff, m->d_key, m->d_meta, m->d_regret, m->d_strat, m->d_local,
-                    m->d_visit, m->d_counters, m->d_out, m->d_seeds, m->d_infoset_T, m->d_payoff_T};
+                    m->d_visit, m->d_counters, m->d_out, m->d_seeds, m->d_infoset_T, m->d_payoff_T, m->d_rows};
     for (void *b : bufs) if (b) (void)hipFree(b);
     delete m;
     return SCOPA_OK;
@@ -279,6 +344,7 @@ int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets) {
         if (h_n_infosets) h_n_infosets[d] = I;
     }
     m->built = true;
+    m->rows_current = false;
     m->mccfr_iteration = 0;
     return SCOPA_OK;
 }
@@ -287,6 +353,7 @@ int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters) {
     if (!m || n_iters < 0 || n_iters > (1 << 20)) return SCOPA_EINVAL;
     scopa_ctx *ctx = m->ctx;
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_exact_iterate: call scopa_multi_build first");
+    if (int32_t rc = rows_convert(m, false)) return rc;
     if (!n_iters) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = (size_t)m->max_infosets * 4 * 8 * 3;
@@ -307,8 +374,8 @@ int32_t scopa_multi_cfr_exact_iterate_lanes(scopa_multi *m, int32_t n_iters) {
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_exact_iterate_lanes: call scopa_multi_build first");
     if (!n_iters) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_cfr_exact_lanes, dim3((m->n + 63) / 64), dim3(64), 0, ctx->stream, m->d_infoset_T, m->d_payoff_T, m->d_regret,
-                       m->d_strat, m->d_local, m->d_meta, m->d_visit, m->d_counters, (long long)m->n, (int)n_iters);
+    if (int32_t rc = rows_convert(m, true)) return rc;
+    hipLaunchKernelGGL(k_cfr_exact_lanes, dim3((m->n + 63) / 64), dim3(64), 0, ctx->stream, m->d_infoset_T, m->d_payoff_T, m->d_rows, m->d_meta, m->d_visit, m->d_counters, (long long)m->n, (int)n_iters);
     SC_HIP(ctx, hipGetLastError());
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCOPA_OK;
@@ -318,6 +385,7 @@ int32_t scopa_multi_cfr_sync_iterate(scopa_multi *m, int32_t n_iters) {
     if (!m || n_iters < 0 || n_iters > (1 << 20)) return SCOPA_EINVAL;
     scopa_ctx *ctx = m->ctx;
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_sync_iterate: call scopa_multi_build first");
+    if (int32_t rc = rows_convert(m, false)) return rc;
     if (!n_iters) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = (size_t)m->max_infosets * 4 * 8 * 2 + sizeof(double) * kNodes * 3 + 1656 * 2;
@@ -334,6 +402,7 @@ int32_t scopa_multi_mccfr_iterate(scopa_multi *m, uint32_t batch, uint32_t n_ite
     if (!m || batch == 0 || batch > (1u << 24) || n_iters > (1u << 24)) return SCOPA_EINVAL;
     scopa_ctx *ctx = m->ctx;
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_mccfr_iterate: call scopa_multi_build first");
+    if (int32_t rc = rows_convert(m, false)) return rc;
     if (!n_iters) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const int32_t rc = launch_mccfr_multi(ctx, m->n, m->max_infosets, m->d_infoset, m->d_payoff, m->d_key, m->d_regret, m->d_strat, m->d_meta,
@@ -348,6 +417,7 @@ int32_t scopa_multi_exploitability(scopa_multi *m, double *h_out4) {
     if (!m || !h_out4) return SCOPA_EINVAL;
     scopa_ctx *ctx = m->ctx;
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_exploitability: call scopa_multi_build first");
+    if (int32_t rc = rows_convert(m, false)) return rc;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = (size_t)m->max_infosets * 4 * 8 * 2 + sizeof(double) * kNodes * 2 + sizeof(int) * (size_t)m->max_infosets + 1656 * 2;
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_multi_exploitability: tables do not fit in LDS");
@@ -364,6 +434,7 @@ int32_t scopa_multi_tables_get(scopa_multi *m, int32_t deal, double *h_regret, d
     if (!m || deal < 0 || deal >= m->n) return SCOPA_EINVAL;
     scopa_ctx *ctx = m->ctx;
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_tables_get: call scopa_multi_build first");
+    if (int32_t rc = rows_convert(m, false)) return rc;
     int32_t I = 0;
     SC_HIP(ctx, hipMemcpyAsync(&I, m->d_meta + (size_t)deal * 8, 4, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
