@@ -265,6 +265,31 @@ int32_t scopa_full_step_batch_host(scopa_ctx *ctx, scopa_full_state *h_states, c
  * h_r2_p0[n] = rewards x2 of player 0, h_plies[n] = game length.  Philox stream (ctx seed, game, ply). */
 int32_t scopa_full_random_playouts(scopa_ctx *ctx, const int64_t *h_seeds, int64_t n_games, int8_t *h_r2_p0, int16_t *h_plies);
 
+/* ---- Team MiniScopa TPI: 2 teams x 2 seats on the 16-card deck, 16 plies (src/envs/team_mini_scopa_game.py,
+ * src/envs/openspiel_team_mini_scopa.py) -- state engine ------------------------------------------------------------------
+ * No reference solver uses it; provided: the state protocol, the batched device step and device playouts.
+ * The "player" of the TPI game is the TEAM (coordinator) of the seat to move; seats 0,1 = team 0, seats 2,3 = team 1. */
+typedef struct scopa_team_state {   /* 40 bytes */
+    uint64_t history;      /* nibble i = action of ply i (TPIMiniScopaState.action_history)                    */
+    uint32_t table;        /* ordered table, nibble list (at most 8: table ranks are always distinct)          */
+    uint16_t hand[4];      /* ordered hands                                                                    */
+    uint16_t cap[4];       /* captured cards per seat, 16-bit masks                                            */
+    uint8_t  nh[4];
+    uint8_t  scopas[4];
+    uint8_t  nt, step, last_capture_team /* 0xFF = None */, flags /* bit 0 terminal, bit 1 table overflow */;
+} scopa_team_state;
+int32_t scopa_team_state_init(const uint8_t perm16[16], scopa_team_state *out);               /* TeamMiniScopaGame.reset :68-78 */
+int32_t scopa_team_state_step(scopa_team_state *s, int32_t action);                           /* apply_action / env.step :173-201 */
+int32_t scopa_team_state_legal(const scopa_team_state *s, int32_t out[4], int32_t *n);        /* legal_actions, openspiel_team…:52-86 */
+int32_t scopa_team_state_rewards_x2(const scopa_team_state *s, int32_t r2_seat[4]);           /* evaluate_game :125-155, x2 */
+int32_t scopa_team_state_infoset_string(const scopa_team_state *s, int32_t team, char *buf, int32_t cap); /* :119-146 */
+/* d_states[i] <- step(d_states[i], d_actions[i]) */
+int32_t scopa_team_step_batch(scopa_ctx *ctx, scopa_team_state *d_states, const uint8_t *d_actions, int64_t n);
+int32_t scopa_team_step_batch_host(scopa_ctx *ctx, scopa_team_state *h_states, const uint8_t *h_actions, int64_t n);
+/* n_games uniform-random playouts to the end, one lane per game, dealt ON DEVICE from seeds[i] (CPython shuffle);
+ * h_r2_team0[n] = reward x2 of team 0 (team 1 = negation), h_scopas[n][4] per seat.  Philox stream (ctx seed, game, ply). */
+int32_t scopa_team_random_playouts(scopa_ctx *ctx, const int64_t *h_seeds, int64_t n_games, int8_t *h_r2_team0, uint8_t *h_scopas);
+
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);

@@ -442,7 +442,58 @@ def gen_full(ns):
           "max table", max(len(t["table"]) for c in cases for t in c["trail"]))
 
 
-ALL = dict(full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+def gen_team(ns):
+    """Team MiniScopa TPI (4 seats, 16 plies): random playouts through the reference's TeamMiniScopaEnv / TPIMiniScopaState
+    (src/envs/team_mini_scopa_game.py, src/envs/openspiel_team_mini_scopa.py).  Card id = action id = suit_idx*4 + rank_idx."""
+    import importlib
+    tg = importlib.import_module("envs.team_mini_scopa_game")
+    ts = importlib.import_module("envs.openspiel_team_mini_scopa")
+    import pyspiel
+    game = pyspiel.load_game("team_mini_scopa_tpi")
+    SU = tg.MiniDeck.suits
+
+    def cid(c):
+        return SU.index(c.suit) * 4 + tg.MiniDeck.ranks[c.suit].index(c.rank)
+
+    def snap(st):
+        g = st.env.game
+        return dict(hands=[[cid(c) for c in p.hand] for p in g.players], table=[cid(c) for c in g.table],
+                    caps=[sorted(cid(c) for c in p.captures) for p in g.players], scopas=[p.scopas for p in g.players],
+                    last=-1 if g.last_capture_team is None else int(g.last_capture_team), step=st.env.step_count,
+                    seat=st.env.agent_name_mapping[st.env.agent_selection], term=bool(st.is_terminal()),
+                    cur=-4 if st.is_terminal() else int(st.current_player()), legal=[int(x) for x in st.legal_actions()],
+                    info0=st.information_state_string(0), info1=st.information_state_string(1), hist=st.history_str(),
+                    rewards=[float(r) for r in st.rewards()])
+
+    rng = np.random.RandomState(16)
+    cases = []
+    for seed in [42, 0, 1, 2, 3, 7, 123, 2024]:
+        for k in range(8):
+            env = tg.TeamMiniScopaEnv(seed=seed) if seed else tg.TeamMiniScopaEnv(seed=0)
+            if seed == 0:
+                env.game.reset(0)      # `seed or self.seed` (team_mini_scopa_game.py:160) turns an explicit 0 into the default
+            st = ts.TPIMiniScopaState(game, env=env, skip_reset=True)
+            init = snap(st)
+            acts, trail = [], []
+            while not st.is_terminal():
+                legal = st.legal_actions()
+                a = int(legal[rng.randint(len(legal))]) if (k < 6 or rng.rand() < 0.75) else int(rng.randint(16))
+                acts.append(a)
+                if k == 7 and len(acts) == 5:
+                    st = st.clone()                      # clone mid-game must not disturb anything
+                st.apply_action(a)
+                trail.append(snap(st))
+            cases.append(dict(seed=seed, actions=acts, init=init, trail=trail, player_rewards=[float(st.env.rewards[f"player_{i}"]) for i in range(4)]))
+    # default construction path of the reference: TPIMiniScopaState(game) -> TeamMiniScopaEnv() -> reset() -> seed 42
+    st = game.new_initial_state()
+    default = snap(st)
+    with open(os.path.join(OUT, "team_mini_scopa.json"), "w") as f:
+        json.dump(dict(playouts=cases, default_initial=default), f)
+    print("team mini scopa: playouts", len(cases), "plies", sorted({len(c["actions"]) for c in cases}),
+          "max table", max(len(t["table"]) for c in cases for t in c["trail"]))
+
+
+ALL = dict(team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

@@ -267,3 +267,58 @@ class FullState:
         return dict(hands=[[int(s.hand[p][i]) for i in range(s.nh[p])] for p in range(2)], table=[int(s.table[i]) for i in range(s.nt)],
                     caps=[sorted(int(s.cap[p][i]) for i in range(s.ncap[p])) for p in range(2)], scopas=[int(s.scopas[0]), int(s.scopas[1])],
                     round=int(s.round_number), step=int(s.step), deck_remaining=40 - int(s.deck_pos), last=int(s.last_capture))
+
+
+# ---- Team MiniScopa TPI (4 seats, 16 plies) ---------------------------------------------------------------------------
+class _TeamState(C.Structure):
+    _fields_ = [("hand", (C.c_int8 * 4) * 4), ("nh", C.c_int8 * 4), ("table", C.c_int8 * 16), ("nt", C.c_int8),
+                ("cap", (C.c_int8 * 16) * 4), ("ncap", C.c_int8 * 4), ("scopas", C.c_int8 * 4), ("last_capture_team", C.c_int8),
+                ("step", C.c_int8), ("terminal", C.c_int8), ("history", C.c_int8 * 16), ("nhist", C.c_int8), ("r2", C.c_int * 4)]
+
+
+class TeamState:
+    def __init__(self, perm=None, seed=42):
+        self.s = _TeamState()
+        self.perm = np.ascontiguousarray(deal_py_seed(seed) if perm is None else perm, np.uint8)
+        lib().ogt_reset(C.byref(self.s), _p(self.perm))
+
+    def legal(self):
+        out = (C.c_int * 4)()
+        n = lib().ogt_legal(C.byref(self.s), out)
+        return [out[i] for i in range(n)]
+
+    def step(self, a):
+        lib().ogt_step(C.byref(self.s), int(a))
+
+    def is_terminal(self):
+        return bool(self.s.terminal)
+
+    def current_player(self):
+        return lib().ogt_current_player(C.byref(self.s))
+
+    def rewards(self):
+        """TPIMiniScopaState.rewards (openspiel_team_mini_scopa.py:106-116): per TEAM"""
+        return [self.s.r2[0] / 2.0, self.s.r2[2] / 2.0] if self.s.terminal else [0, 0]
+
+    def player_rewards(self):
+        return [self.s.r2[i] / 2.0 for i in range(4)]
+
+    def infoset_string(self, team):
+        buf = C.create_string_buffer(256)
+        lib().ogt_infoset_string(C.byref(self.s), int(team), buf)
+        return buf.value.decode()
+
+    def history_str(self):
+        h = "-".join(str(int(self.s.history[i])) for i in range(self.s.nhist))
+        if self.s.terminal:
+            return f"TERMINAL:{h}:" + ",".join(f"{r:.2f}" for r in self.rewards())
+        return f"H:{h}:T{self.current_player()}"
+
+    def snapshot(self):
+        s = self.s
+        return dict(hands=[[int(s.hand[p][i]) for i in range(s.nh[p])] for p in range(4)], table=[int(s.table[i]) for i in range(s.nt)],
+                    caps=[sorted(int(s.cap[p][i]) for i in range(s.ncap[p])) for p in range(4)], scopas=[int(x) for x in s.scopas],
+                    last=int(s.last_capture_team), step=int(s.step), seat=int(s.step) % 4, term=bool(s.terminal),
+                    cur=self.current_player(), legal=self.legal(), info0=self.infoset_string(0), info1=self.infoset_string(1),
+                    hist=self.history_str(), rewards=[float(r) for r in self.rewards()])
+

@@ -819,3 +819,118 @@ int ogf_infoset_string(const ogf_state *s, int player, char *buf) {
     w += sprintf(w, "]:C[%d,%d]:S[%d,%d]", s->ncap[0], s->ncap[1], s->scopas[0], s->scopas[1]);
     return (int)(w - buf);
 }
+
+/* ==== Team MiniScopa TPI ============================================================================================ */
+void ogt_reset(ogt_state *s, const uint8_t perm[16]) {
+    /* TeamMiniScopaGame.reset (team_mini_scopa_game.py:68-78): 4 cards to each of the 4 players, table empty */
+    memset(s, 0, sizeof *s);
+    for (int p = 0; p < 4; p++) { for (int i = 0; i < 4; i++) s->hand[p][i] = (int8_t)perm[p * 4 + i]; s->nh[p] = 4; }
+    s->last_capture_team = -1;
+}
+
+int ogt_current_player(const ogt_state *s) {
+    /* TPIMiniScopaState.current_player (openspiel_team_mini_scopa.py:23-29): the TEAM of the seat to move */
+    return s->terminal ? -4 : ((s->step % 4) / 2);
+}
+
+int ogt_legal(const ogt_state *s, int out[4]) {
+    /* legal_actions (:52-86): the hand of the seat to move, in hand order, whatever `player` says; [0] fallback; [] at terminal */
+    if (s->terminal) return 0;
+    int seat = s->step % 4, n = 0;
+    for (int i = 0; i < s->nh[seat]; i++) out[n++] = s->hand[seat][i];
+    if (!n) { out[0] = 0; n = 1; }
+    return n;
+}
+
+static int t_capture(const ogt_state *s, int card, int cap_idx[16]) {
+    /* TeamMiniScopaGame.card_in_table (:84-109): same rule as MiniScopa's */
+    int target = RANK_OF[card];
+    if (target <= 0 || s->nt == 0) return 0;
+    for (int i = 0; i < s->nt; i++) if (RANK_OF[s->table[i]] == target) { cap_idx[0] = i; return 1; }
+    int have[11], len[11], comb[11][16];
+    memset(have, 0, sizeof have);
+    have[0] = 1; len[0] = 0;
+    for (int idx = 0; idx < s->nt; idx++) {
+        int r = RANK_OF[s->table[idx]];
+        for (int sum = target; sum >= r; sum--)
+            if (!have[sum] && have[sum - r]) {
+                have[sum] = 1; len[sum] = len[sum - r] + 1;
+                memcpy(comb[sum], comb[sum - r], sizeof(int) * (size_t)len[sum - r]);
+                comb[sum][len[sum] - 1] = idx;
+            }
+    }
+    if (!have[target]) return 0;
+    for (int i = 0; i < len[target]; i++) cap_idx[i] = comb[target][i];
+    return len[target];
+}
+
+static void t_evaluate(ogt_state *s) {
+    /* evaluate_game (:125-155): leftover table cards go to the FIRST player of the last capturing team (the table itself is
+     * left as it is); team score = sum of len(captures) + 2*scopas; zero-sum around the mean */
+    if (s->nt > 0 && s->last_capture_team >= 0) {
+        int p = s->last_capture_team * 2;
+        for (int i = 0; i < s->nt; i++) s->cap[p][s->ncap[p]++] = s->table[i];
+    }
+    int score[2] = {0, 0};
+    for (int p = 0; p < 4; p++) score[p / 2] += s->ncap[p] + 2 * s->scopas[p];
+    int total = score[0] + score[1];
+    for (int p = 0; p < 4; p++) s->r2[p] = total == 0 ? 0 : 2 * score[p / 2] - total;
+}
+
+void ogt_step(ogt_state *s, int action) {
+    /* TPIMiniScopaState.apply_action (:88-92) + TeamMiniScopaEnv.step (:173-201) + play_card (:111-123) */
+    if (s->nhist < 16) s->history[s->nhist++] = (int8_t)action;   /* action_history grows even on a dead step */
+    if (s->terminal) return;                                        /* _was_dead_step */
+    int seat = s->step % 4, pos = -1;
+    for (int i = 0; i < s->nh[seat]; i++) if (s->hand[seat][i] == action) { pos = i; break; }
+    if (pos >= 0) {
+        int cap[16];
+        int nc = t_capture(s, action, cap);
+        if (nc > 0) {
+            int8_t keep[16]; int nk = 0;
+            for (int i = 0; i < s->nt; i++) {
+                int taken = 0;
+                for (int j = 0; j < nc; j++) if (cap[j] == i) taken = 1;
+                if (taken) s->cap[seat][s->ncap[seat]++] = s->table[i]; else keep[nk++] = s->table[i];
+            }
+            s->cap[seat][s->ncap[seat]++] = (int8_t)action;
+            memcpy(s->table, keep, (size_t)nk); s->nt = (int8_t)nk;
+            s->last_capture_team = (int8_t)(seat / 2);
+            if (nk == 0) s->scopas[seat]++;
+        } else s->table[s->nt++] = (int8_t)action;
+        for (int i = pos; i + 1 < s->nh[seat]; i++) s->hand[seat][i] = s->hand[seat][i + 1];
+        s->nh[seat]--;
+    }
+    s->step++;
+    if ((s->nh[0] | s->nh[1] | s->nh[2] | s->nh[3]) == 0 || s->step >= 16) { s->terminal = 1; t_evaluate(s); }
+}
+
+static const char *TSUIT_NAME[4] = {"cuori", "fiori", "picche", "bello"};
+static int t_cmp_cards(const void *a, const void *b) {
+    /* sorted([(rank, suit_name)]) (:135-139) */
+    int x = *(const int *)a, y = *(const int *)b;
+    if (RANK_OF[x] != RANK_OF[y]) return RANK_OF[x] - RANK_OF[y];
+    return strcmp(TSUIT_NAME[x / 4], TSUIT_NAME[y / 4]);
+}
+
+int ogt_infoset_string(const ogt_state *s, int team, char *buf) {
+    /* information_state_string (:119-146): the seat to move if it belongs to `team`, else the team's first seat; hand and
+     * table SORTED by (rank, suit name); the whole action history is part of the key */
+    int seat = s->step % 4;
+    if (seat / 2 != team) seat = team * 2;
+    int h[4], t[16];
+    for (int i = 0; i < s->nh[seat]; i++) h[i] = s->hand[seat][i];
+    for (int i = 0; i < s->nt; i++) t[i] = s->table[i];
+    qsort(h, (size_t)s->nh[seat], sizeof(int), t_cmp_cards);
+    qsort(t, (size_t)s->nt, sizeof(int), t_cmp_cards);
+    char *w = buf;
+    w += sprintf(w, "Team%d:P%d:H[", team, seat);
+    for (int i = 0; i < s->nh[seat]; i++) w += sprintf(w, "%s%d%c", i ? "-" : "", RANK_OF[h[i]], TSUIT_NAME[h[i] / 4][0]);
+    w += sprintf(w, "]:T[");
+    for (int i = 0; i < s->nt; i++) w += sprintf(w, "%s%d%c", i ? "-" : "", RANK_OF[t[i]], TSUIT_NAME[t[i] / 4][0]);
+    w += sprintf(w, "]:A[");
+    for (int i = 0; i < s->nhist; i++) w += sprintf(w, "%s%d", i ? "-" : "", s->history[i]);
+    w += sprintf(w, "]");
+    return (int)(w - buf);
+}
+

@@ -150,3 +150,28 @@ int  ogf_infoset_string(const ogf_state *s, int player, char *buf);
 #ifdef __cplusplus
 }
 #endif
+
+/* ==== Team MiniScopa TPI (4 seats, 16 cards, 16 plies), test-side restatement of src/envs/team_mini_scopa_game.py +
+ * src/envs/openspiel_team_mini_scopa.py ============================================================================== */
+#ifdef __cplusplus
+extern "C" {
+#endif
+typedef struct {
+    int8_t hand[4][4]; int8_t nh[4];       /* hands in deal order (team_mini_scopa_game.py:74-76) */
+    int8_t table[16]; int8_t nt;           /* table in insertion order */
+    int8_t cap[4][16]; int8_t ncap[4];     /* captures as lists */
+    int8_t scopas[4];
+    int8_t last_capture_team;              /* -1 = None */
+    int8_t step;                           /* env.step_count; seat to move = step % 4, team = seat / 2 */
+    int8_t terminal;
+    int8_t history[16]; int8_t nhist;      /* TPIMiniScopaState.action_history */
+    int r2[4];                             /* per-seat rewards x2 once terminal */
+} ogt_state;
+void ogt_reset(ogt_state *s, const uint8_t perm[16]);
+int  ogt_legal(const ogt_state *s, int out[4]);
+void ogt_step(ogt_state *s, int action);
+int  ogt_current_player(const ogt_state *s);                         /* team id, -4 at terminal */
+int  ogt_infoset_string(const ogt_state *s, int team, char *buf);
+#ifdef __cplusplus
+}
+#endif

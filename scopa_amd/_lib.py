@@ -29,7 +29,9 @@ SYMBOLS = [
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
     "scopa_multi_cfr_exact_iterate_lanes", "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
     "scopa_full_state_init", "scopa_full_state_step", "scopa_full_state_legal", "scopa_full_state_infoset_string",
-    "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts",
+    "scopa_team_state_init", "scopa_team_state_step", "scopa_team_state_legal", "scopa_team_state_rewards_x2", "scopa_team_state_infoset_string",
+    "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -148,6 +150,14 @@ def lib():
         "scopa_full_step_batch": (i32, [vp, vp, vp, vp, i64]),
         "scopa_full_step_batch_host": (i32, [vp, vp, vp, vp, i64, i64]),
         "scopa_full_random_playouts": (i32, [vp, vp, i64, vp, vp]),
+        "scopa_team_state_init": (i32, [vp, vp]),
+        "scopa_team_state_step": (i32, [vp, i32]),
+        "scopa_team_state_legal": (i32, [vp, C.POINTER(i32 * 4), C.POINTER(i32)]),
+        "scopa_team_state_rewards_x2": (i32, [vp, C.POINTER(i32 * 4)]),
+        "scopa_team_state_infoset_string": (i32, [vp, i32, C.c_char_p, i32]),
+        "scopa_team_step_batch": (i32, [vp, vp, vp, i64]),
+        "scopa_team_step_batch_host": (i32, [vp, vp, vp, i64]),
+        "scopa_team_random_playouts": (i32, [vp, vp, i64, vp, vp]),
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
@@ -408,6 +418,19 @@ class Context:
         self._ck(self._L.scopa_full_random_playouts(self._h, _ptr(seeds), seeds.size, _ptr(r2), _ptr(plies)), "scopa_full_random_playouts")
         return r2, plies
 
+    def team_step_batch_host(self, states, actions):
+        assert states.dtype == TEAM_STATE_DTYPE
+        actions = np.ascontiguousarray(actions, np.uint8)
+        self._ck(self._L.scopa_team_step_batch_host(self._h, _ptr(states), _ptr(actions), states.size), "scopa_team_step_batch_host")
+        return states
+
+    def team_random_playouts(self, seeds):
+        """-> (reward x2 of team 0 per game, scopas[n][4] per seat)"""
+        seeds = np.ascontiguousarray(seeds, np.int64)
+        r2, sc = np.zeros(seeds.size, np.int8), np.zeros((seeds.size, 4), np.uint8)
+        self._ck(self._L.scopa_team_random_playouts(self._h, _ptr(seeds), seeds.size, _ptr(r2), _ptr(sc)), "scopa_team_random_playouts")
+        return r2, sc
+
     def counters(self):
         a, b = C.c_uint64(), C.c_uint64()
         self._ck(self._L.scopa_counters(self._h, C.byref(a), C.byref(b)), "scopa_counters")
@@ -484,6 +507,87 @@ def unpack_full_state(s):
     last = int(s["last_capture"])
     return dict(hands=hands, table=tab, caps=caps, scopas=[int(s["scopas"][0]), int(s["scopas"][1])], round=int(s["round"]),
                 step=int(s["step"]), deck_remaining=40 - int(s["deck_pos"]), last=-1 if last == 255 else last)
+
+
+TEAM_STATE_DTYPE = np.dtype([("history", "<u8"), ("table", "<u4"), ("hand", "<u2", (4,)), ("cap", "<u2", (4,)), ("nh", "u1", (4,)),
+                             ("scopas", "u1", (4,)), ("nt", "u1"), ("step", "u1"), ("last_capture_team", "u1"), ("flags", "u1")])
+assert TEAM_STATE_DTYPE.itemsize == 40
+
+
+class TeamState:
+    """One packed Team MiniScopa TPI state driven through the host-side protocol (scopa_team_state_*)."""
+
+    def __init__(self, seed=42, perm=None):
+        self.perm = np.ascontiguousarray(deal_py_seed(seed) if perm is None else perm, np.uint8)
+        self.s = np.zeros(1, TEAM_STATE_DTYPE)
+        rc = lib().scopa_team_state_init(_ptr(self.perm), _ptr(self.s))
+        if rc:
+            raise ScopaError(rc, "scopa_team_state_init")
+
+    def copy(self):
+        c = TeamState.__new__(TeamState)
+        c.perm, c.s = self.perm, self.s.copy()
+        return c
+
+    def step(self, action):
+        rc = lib().scopa_team_state_step(_ptr(self.s), int(action))
+        if rc:
+            raise ScopaError(rc, "scopa_team_state_step")
+
+    def legal(self):
+        out, n = (C.c_int32 * 4)(), C.c_int32()
+        lib().scopa_team_state_legal(_ptr(self.s), C.byref(out), C.byref(n))
+        return [out[i] for i in range(n.value)]
+
+    def is_terminal(self):
+        return bool(int(self.s[0]["flags"]) & 1)
+
+    def seat(self):
+        return int(self.s[0]["step"]) & 3
+
+    def current_player(self):
+        return -4 if self.is_terminal() else self.seat() >> 1
+
+    def player_rewards(self):
+        r = (C.c_int32 * 4)()
+        lib().scopa_team_state_rewards_x2(_ptr(self.s), C.byref(r))
+        return [r[i] / 2.0 for i in range(4)]
+
+    def rewards(self):
+        """per TEAM (TPIMiniScopaState.rewards, openspiel_team_mini_scopa.py:106-116)"""
+        if not self.is_terminal():
+            return [0, 0]
+        r = self.player_rewards()
+        return [(r[0] + r[1]) / 2, (r[2] + r[3]) / 2]
+
+    def infoset_string(self, team):
+        buf = C.create_string_buffer(256)
+        lib().scopa_team_state_infoset_string(_ptr(self.s), int(team), buf, 256)
+        return buf.value.decode()
+
+    def history(self):
+        h = int(self.s[0]["history"])
+        return [(h >> (4 * i)) & 15 for i in range(int(self.s[0]["step"]))]
+
+    def history_str(self):
+        h = "-".join(map(str, self.history()))
+        if self.is_terminal():
+            return f"TERMINAL:{h}:" + ",".join(f"{r:.2f}" for r in self.rewards())
+        return f"H:{h}:T{self.current_player()}"
+
+    def snapshot(self):
+        d = unpack_team_state(self.s[0])
+        d.update(cur=self.current_player(), legal=self.legal(), info0=self.infoset_string(0), info1=self.infoset_string(1),
+                 hist=self.history_str(), rewards=[float(r) for r in self.rewards()])
+        return d
+
+
+def unpack_team_state(s):
+    hands = [[(int(s["hand"][p]) >> (4 * i)) & 15 for i in range(int(s["nh"][p]))] for p in range(4)]
+    last = int(s["last_capture_team"])
+    return dict(hands=hands, table=[(int(s["table"]) >> (4 * i)) & 15 for i in range(int(s["nt"]))],
+                caps=[[c for c in range(16) if (int(s["cap"][p]) >> c) & 1] for p in range(4)], scopas=[int(x) for x in s["scopas"]],
+                last=-1 if last == 255 else last, step=int(s["step"]), seat=int(s["step"]) & 3, term=bool(int(s["flags"]) & 1))
 
 
 class MultiDeal:

@@ -151,7 +151,12 @@ def _full_scopa(params=None):
     return FullScopaGame()
 
 
-_REGISTRY = {"mini_scopa": lambda params=None: MiniScopaGame(), "full_scopa": _full_scopa}
+def _team_mini_scopa(params=None):
+    from .openspiel_team_mini_scopa import TPIMiniScopaGame
+    return TPIMiniScopaGame(**(params or {}))
+
+
+_REGISTRY = {"mini_scopa": lambda params=None: MiniScopaGame(), "full_scopa": _full_scopa, "team_mini_scopa_tpi": _team_mini_scopa}
 
 
 def load_game(short_name, params=None):
