@@ -11,6 +11,7 @@ An infoset-traversal = one decision-node visit: 463 per traversal 
         bench.py --gpus N --steps K --warmup W
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -85,6 +86,8 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
     ap.add_argument("--prof-stride", type=int, default=8, help="bracket every n-th traversal launch with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--exchange", choices=["auto", "p2p", "rccl"], default="auto",
+                    help="N>1 delta all-reduce: library one-shot peer-memory exchange (validated against RCCL first), or torch.distributed/RCCL")
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
     args = ap.parse_args()
 
@@ -103,19 +106,23 @@ def main():
         sys.exit("bench.py needs a GPU: the solver path has no CPU fallback")
     torch.cuda.set_device(local_rank)
     use_dist = world > 1 or args.force_dist
+    saved_stdout = None
     if use_dist:
+        # librccl prints a version banner on stdout when its first communicator comes up; stdout is reserved for the ONE JSON
+        # line, so native-library output goes to stderr until that line is printed
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
 
     perm = _lib.deal_py_seed(42)
-    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=2 if use_dist else 1)
+    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=2 if use_dist else 1, rank=rank,
+                                                      exchange=args.exchange)
     batch_total = args.batch * world
-    drv = ShardedMCCFR(ctx, rank, world, all_reduce)
-    if use_dist:
-        drv.world = max(world, 2)  # forces the all-reduce branch; shard_range below still uses the true world size
-        drv.iteration = lambda bt, _d=drv: (_d.engine.mccfr_traverse(_d.engine.mccfr_iteration(), *shard_range(bt, rank, world)),
-                                            _d.all_reduce(), _d.engine.mccfr_apply())
+    # --force-dist with one rank still takes the exchange step (always_exchange), so the N>1 code path can be timed on one GPU
+    drv = ShardedMCCFR(ctx, rank, world, all_reduce, fused_exchange=(use_dist and ctx.exchange == "p2p"), always_exchange=use_dist)
 
     def run(k):
         if not use_dist:
@@ -153,6 +160,17 @@ def main():
         visits = d1 - d0
     expected = VISITS_PER_PAIR * batch_total * args.steps
     assert visits == expected, f"kernel visit counter {visits} != {expected}"
+    replicas_identical = None
+    if use_dist:
+        if ctx.exchange == "p2p":
+            timeouts, exchanges = ctx.p2p_status()
+            assert timeouts == 0, f"peer exchange: {timeouts} wait(s) timed out -- the run is invalid"
+        R, S, _ = ctx.tables_get()
+        h = hashlib.sha256(R.tobytes() + S.tobytes()).digest()[:8]
+        mine = torch.tensor(list(h), dtype=torch.uint8, device=f"cuda:{local_rank}")
+        allh = [torch.zeros(8, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(world)]
+        dist.all_gather(allh, mine)
+        replicas_identical = all(bool((x == mine).all().item()) for x in allh)
 
     if rank == 0:
         kern_us = 1e3 * kernel_ms / max(launches, 1)
@@ -172,7 +190,9 @@ def main():
             "config": {"workload": "BASELINE configs[1]: external-sampling MCCFR on MiniScopa (seed-42 deal, 738 infosets), "
                                    f"{args.batch} parallel traversals per traverser per GPU per iteration, tables frozen per iteration",
                        "batch_per_gpu": args.batch, "global_batch": batch_total, "iterations": args.steps,
-                       "parallelism": f"dp{world}" + (" + 1 RCCL all-reduce of 29520 B per iteration" if world > 1 else ""),
+                       "parallelism": f"dp{world}" + ((" + 1 all-reduce of 29520 B per iteration (" + {"p2p": "one-shot peer-memory exchange over xGMI, rank-ordered sum", "rccl": "RCCL via torch.distributed"}.get(ctx.exchange, ctx.exchange) + ")") if use_dist else ""),
+                       "exchange": ctx.exchange if use_dist else None, "exchange_note": ctx.exchange_note if use_dist else None,
+                       "replicas_bit_identical": replicas_identical,
                        "rng": "Philox4x32-10 keyed by (seed, path code, global traversal id, iteration, traverser)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
@@ -202,6 +222,9 @@ def main():
                 out["large_batch"] = {"batch_per_gpu": big, "value": (ctx.counters()[0] - c0) / dtb, "ms_per_step": 1e3 * dtb / 200}
             except Exception as e:
                 out["large_batch"] = {"error": repr(e)}
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
         print(json.dumps(out), flush=True)
     if use_dist:
         dist.barrier()

@@ -290,6 +290,21 @@ int32_t scopa_team_step_batch_host(scopa_ctx *ctx, scopa_team_state *h_states, c
  * h_r2_team0[n] = reward x2 of team 0 (team 1 = negation), h_scopas[n][4] per seat.  Philox stream (ctx seed, game, ply). */
 int32_t scopa_team_random_playouts(scopa_ctx *ctx, const int64_t *h_seeds, int64_t n_games, int8_t *h_r2_team0, uint8_t *h_scopas);
 
+/* ---- N > 1: one-shot all-reduce of the delta buffer over peer (xGMI) memory -------------------------------------------------
+ * One process per GPU on one node.  create: allocates this rank's inbox (fine-grained device memory) and returns its 64-byte
+ * hipIpc handle; the caller all-gathers the handles (torch.distributed) and passes all `world` of them to connect.
+ * allreduce_delta (on the context's stream): the delta buffer of every rank becomes the sum over ranks, added in rank order on
+ * every rank (bit-identical replicas).  Waits are bounded (5 s); status returns the number of waits that gave up (0 = healthy)
+ * and the exchanges issued.  Replaces torch.distributed.all_reduce(delta) between scopa_mccfr_traverse and scopa_mccfr_apply. */
+int32_t scopa_p2p_create(scopa_ctx *ctx, int32_t rank, int32_t world, uint8_t handle_out[64]);
+int32_t scopa_p2p_connect(scopa_ctx *ctx, const uint8_t *handles /*[world][64]*/);
+int32_t scopa_p2p_allreduce_delta(scopa_ctx *ctx);
+/* n_iters whole iterations of this rank's slice [b0, b0+nb) of the global traversal ids, the exchange fused into the
+ * reduce+apply kernel (two launches per iteration, as on one GPU); all ranks call it with the same n_iters */
+int32_t scopa_mccfr_iterate_sharded(scopa_ctx *ctx, uint32_t b0, uint32_t nb, uint32_t n_iters);
+int32_t scopa_p2p_status(scopa_ctx *ctx, int32_t *timeouts, uint64_t *exchanges);
+int32_t scopa_p2p_destroy(scopa_ctx *ctx);
+
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);

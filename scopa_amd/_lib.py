@@ -31,7 +31,8 @@ SYMBOLS = [
     "scopa_full_state_init", "scopa_full_state_step", "scopa_full_state_legal", "scopa_full_state_infoset_string",
     "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts",
     "scopa_team_state_init", "scopa_team_state_step", "scopa_team_state_legal", "scopa_team_state_rewards_x2", "scopa_team_state_infoset_string",
-    "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts",
+    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
 ]
 
 
@@ -150,6 +151,12 @@ def lib():
         "scopa_full_step_batch": (i32, [vp, vp, vp, vp, i64]),
         "scopa_full_step_batch_host": (i32, [vp, vp, vp, vp, i64, i64]),
         "scopa_full_random_playouts": (i32, [vp, vp, i64, vp, vp]),
+        "scopa_mccfr_iterate_sharded": (i32, [vp, u32, u32, u32]),
+        "scopa_p2p_create": (i32, [vp, i32, i32, vp]),
+        "scopa_p2p_connect": (i32, [vp, vp]),
+        "scopa_p2p_allreduce_delta": (i32, [vp]),
+        "scopa_p2p_status": (i32, [vp, C.POINTER(i32), C.POINTER(u64)]),
+        "scopa_p2p_destroy": (i32, [vp]),
         "scopa_team_state_init": (i32, [vp, vp]),
         "scopa_team_state_step": (i32, [vp, i32]),
         "scopa_team_state_legal": (i32, [vp, C.POINTER(i32 * 4), C.POINTER(i32)]),
@@ -417,6 +424,31 @@ class Context:
         r2, plies = np.zeros(seeds.size, np.int8), np.zeros(seeds.size, np.int16)
         self._ck(self._L.scopa_full_random_playouts(self._h, _ptr(seeds), seeds.size, _ptr(r2), _ptr(plies)), "scopa_full_random_playouts")
         return r2, plies
+
+    def p2p_create(self, rank, world):
+        """-> this rank's 64-byte IPC handle (uint8[64]) of its peer-exchange inbox"""
+        h = np.zeros(64, np.uint8)
+        self._ck(self._L.scopa_p2p_create(self._h, int(rank), int(world), _ptr(h)), "scopa_p2p_create")
+        return h
+
+    def p2p_connect(self, handles):
+        handles = np.ascontiguousarray(handles, np.uint8).reshape(-1, 64)
+        self._ck(self._L.scopa_p2p_connect(self._h, _ptr(handles)), "scopa_p2p_connect")
+
+    def p2p_allreduce_delta(self):
+        self._ck(self._L.scopa_p2p_allreduce_delta(self._h), "scopa_p2p_allreduce_delta")
+
+    def mccfr_iterate_sharded(self, b0, nb, n_iters=1):
+        self._ck(self._L.scopa_mccfr_iterate_sharded(self._h, int(b0), int(nb), int(n_iters)), "scopa_mccfr_iterate_sharded")
+
+    def p2p_status(self):
+        """-> (waits that timed out, exchanges issued); synchronises the stream"""
+        t, n = C.c_int32(), C.c_uint64()
+        self._ck(self._L.scopa_p2p_status(self._h, C.byref(t), C.byref(n)), "scopa_p2p_status")
+        return t.value, n.value
+
+    def p2p_destroy(self):
+        self._ck(self._L.scopa_p2p_destroy(self._h), "scopa_p2p_destroy")
 
     def team_step_batch_host(self, states, actions):
         assert states.dtype == TEAM_STATE_DTYPE

@@ -22,6 +22,8 @@
 //  batched MCCFR:
 //    d_delta    [kDecision][5] float64: 4 regret deltas + traverser-visit count (the all-reduce payload)
 //    d_slabs    [n_cus][n_infosets][5] float64: per-workgroup partial deltas, summed in fixed order into d_delta
+struct scopa_p2p;  // scopa_p2p.hip
+
 struct scopa_ctx {
     int device = -1;
     hipStream_t stream = nullptr;
@@ -66,6 +68,8 @@ struct scopa_ctx {
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
 
+    scopa_p2p *p2p = nullptr;  // peer-memory exchange of the N > 1 path
+
     int lds_limit = 160 * 1024;
     int n_cus = 256;
 };
@@ -95,5 +99,6 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
 // event pair bracketing a launch of the dominant kernel when profiling is on
 void prof_begin(scopa_ctx *ctx);
 void prof_end(scopa_ctx *ctx);
+void p2p_release(scopa_ctx *ctx);
 
 }  // namespace scopa

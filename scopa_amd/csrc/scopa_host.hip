@@ -124,6 +124,7 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     if (!ctx) return SCOPA_EINVAL;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    scopa::p2p_release(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
                     ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs, ctx->d_visit, ctx->d_seen_slabs, ctx->d_sigcdf};

@@ -29,6 +29,7 @@
 // traverser-specialised walk: 20-23 us, 2.8 us per 16 tasks (issue-bound at ~1.5 cycles/instruction); v3 unique
 // nodes with workgroup-wide plies: same time (latency-bound); v4 unique nodes per wavefront: see DESIGN.md.
 #include "scopa_ctx.h"
+#include "scopa_p2p.h"
 #include "scopa_philox.h"
 
 using namespace scopa;
@@ -452,11 +453,14 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
 // Deterministic: the order of every float64 sum is fixed by n_slabs, not by timing.
 namespace { constexpr int kRaRows = 4, kRaCells = kRaRows * 5, kRaPairs = kRaCells / 2, kRaChunks = 24; }
 
+// XCHG (N > 1): between "the 4 rows' deltas of THIS rank are known" and "apply them", each row is exchanged with the
+// peers (scopa_p2p.h) and becomes the rank-ordered sum over ranks -- the whole multi-GPU step stays two launches.
+template <bool XCHG>
 __global__ void __launch_bounds__(256)
 k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_infosets,
                      const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters,
                      const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit, const uint64_t *__restrict__ g_key,
-                     double *__restrict__ g_regret, double *__restrict__ g_strat, double *__restrict__ g_sigcdf) {
+                     double *__restrict__ g_regret, double *__restrict__ g_strat, double *__restrict__ g_sigcdf, scopa::P2PArgs xa) {
     __shared__ double part[kRaChunks][kRaCells];
     __shared__ unsigned int s_any[kRaRows];
     __shared__ unsigned long long s_tot[2];
@@ -516,6 +520,7 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
                 for (int q = 0; q < kRaChunks; q++) t += part[q][tid * 5 + k];
                 d[k] = t;
             }
+            if constexpr (XCHG) scopa::p2p_exchange_row(xa, r, d);
             const int n = (int)((g_key[r] >> 1) & 7);
             double R[4], sg[4], cd[4];
             for (int k = 0; k < 4; k++) R[k] = g_regret[r * 4 + k];
@@ -660,7 +665,7 @@ static size_t traverse_lds_bytes(int n_infosets, int waves) {
     return (b + 15) & ~(size_t)15;
 }
 
-static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb, bool fuse_apply = false) {
+static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb, bool fuse_apply = false, bool exchange = false) {
     // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~870 infosets), fewer for deals
     // with more infosets (the tables alone fit up to 1653, the maximum)
     int waves = 16;
@@ -698,10 +703,18 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
                        iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
     prof_end(ctx);
     SC_HIP(ctx, hipGetLastError());
-    if (fuse_apply) {  // single-GPU iteration: reduce + apply in one kernel
-        hipLaunchKernelGGL(k_mccfr_reduce_apply, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
-                           ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
-                           ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf);
+    if (fuse_apply) {  // reduce (+ exchange with the peers) + apply in one kernel
+        scopa::P2PArgs xa{};
+        if (exchange) {
+            SC_REQUIRE(ctx, scopa::p2p_next_args(ctx, &xa), SCOPA_ESTATE, "mccfr sharded iteration: peer exchange not connected");
+            hipLaunchKernelGGL(k_mccfr_reduce_apply<true>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+                               ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
+                               ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, xa);
+        } else {
+            hipLaunchKernelGGL(k_mccfr_reduce_apply<false>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+                               ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
+                               ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, xa);
+        }
         SC_HIP(ctx, hipGetLastError());
         ctx->sigcdf_valid = true;
         ctx->iteration++;
@@ -815,6 +828,20 @@ int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
     SC_HIP(ctx, hipSetDevice(ctx->device));
     for (uint32_t it = 0; it < n_iters; it++) {
         const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch, /*fuse_apply=*/true);
+        if (rc != SCOPA_OK) return rc;
+    }
+    return SCOPA_OK;
+}
+
+int32_t scopa_mccfr_iterate_sharded(scopa_ctx *ctx, uint32_t b0, uint32_t nb, uint32_t n_iters) {
+    // N > 1: this rank's slice [b0, b0+nb) of every iteration's global traversal ids; the per-row exchange with the peers
+    // (scopa_p2p_create / _connect first) sits inside the reduce+apply kernel.  Every rank must call it with the same n_iters.
+    if (!ctx) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_iterate_sharded: no deal set");
+    SC_REQUIRE(ctx, nb > 0 && nb <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_iterate_sharded: bad slice");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    for (uint32_t it = 0; it < n_iters; it++) {
+        const int32_t rc = launch_traverse(ctx, ctx->iteration, b0, nb, /*fuse_apply=*/true, /*exchange=*/true);
         if (rc != SCOPA_OK) return rc;
     }
     return SCOPA_OK;

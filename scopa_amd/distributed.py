@@ -16,29 +16,107 @@ def shard_range(batch_total, rank, world):
 
 
 class ShardedMCCFR:
-    """Drives one engine per rank.  `engine` needs mccfr_iteration(), mccfr_traverse(it, b0, nb), mccfr_apply();
-    `all_reduce()` must sum the engine's bound delta buffer in place across ranks (no-op for world == 1)."""
+    """Drives one engine per rank.  Split form: `engine` needs mccfr_iteration(), mccfr_traverse(it, b0, nb), mccfr_apply();
+    `all_reduce()` must sum the engine's bound delta buffer in place across ranks (no-op for world == 1).
+    fused_exchange=True (a validated peer-memory exchange is connected, see connect_peer_exchange): the engine's
+    mccfr_iterate_sharded(b0, nb, n) runs whole iterations in the library, the exchange inside the reduce+apply kernel."""
 
-    def __init__(self, engine, rank, world, all_reduce=None):
+    def __init__(self, engine, rank, world, all_reduce=None, fused_exchange=False, always_exchange=False):
         self.engine, self.rank, self.world = engine, int(rank), int(world)
         self.all_reduce = all_reduce if all_reduce is not None else (lambda: None)
+        self.fused_exchange, self.always_exchange = bool(fused_exchange), bool(always_exchange)
 
     def iteration(self, batch_total):
-        it = self.engine.mccfr_iteration()
         b0, nb = shard_range(batch_total, self.rank, self.world)
+        if self.fused_exchange:
+            self.engine.mccfr_iterate_sharded(b0, nb, 1)
+            return
+        it = self.engine.mccfr_iteration()
         self.engine.mccfr_traverse(it, b0, nb)
-        if self.world > 1:
+        if self.world > 1 or self.always_exchange:
             self.all_reduce()
         self.engine.mccfr_apply()
 
     def run(self, batch_total, n_iters):
+        if self.fused_exchange:
+            b0, nb = shard_range(batch_total, self.rank, self.world)
+            self.engine.mccfr_iterate_sharded(b0, nb, int(n_iters))
+            return
         for _ in range(int(n_iters)):
             self.iteration(batch_total)
 
 
-def make_gpu_engine(local_rank, perm16, seed, world=1):
+def connect_peer_exchange(ctx, rank, world, device, rounds=3):
+    """Set up the library's one-shot peer-memory all-reduce (scopa_p2p_*, include/scopa.h) between the `world` ranks of an
+    initialised torch.distributed group (one process per GPU, one node) and PROVE it before use: `rounds` exchanges of
+    rank-distinct random payloads must equal, bit for bit, the rank-ordered sum computed from an all-gather through
+    torch.distributed (RCCL), on every rank, with no wait timing out.  Returns (ok, reason); every rank returns the same
+    answer (the verdict itself is all-reduced), so the ranks switch paths together."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from . import _lib
+    if world > 1 and dist.get_backend() == "gloo":
+        device = torch.device("cpu")      # handles and verdicts travel through the process group, whatever its backend
+
+    def agree(ok):
+        f = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+        if world > 1:
+            dist.all_reduce(f, op=dist.ReduceOp.MIN)
+        return bool(f.item())
+
+    reason, handle = "", np.zeros(64, np.uint8)
+    try:
+        handle = ctx.p2p_create(rank, world)
+        ok = True
+    except _lib.ScopaError as e:
+        ok, reason = False, f"create: {e}"
+    mine = torch.from_numpy(handle.copy()).to(device)
+    parts = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
+    if world > 1:
+        dist.all_gather(parts, mine)
+    else:
+        parts = [mine]
+    if not agree(ok):
+        return False, reason or "a peer could not create its inbox"
+    try:
+        ctx.p2p_connect(np.stack([p.cpu().numpy() for p in parts]))
+    except _lib.ScopaError as e:
+        ok, reason = False, f"connect: {e}"
+    if not agree(ok):
+        ctx.p2p_destroy()
+        return False, reason or "a peer could not map the inboxes"
+    n = ctx.n_infosets * 5
+    for k in range(rounds):
+        x = np.random.RandomState(1000 * k + rank).standard_normal(n) * 10.0 ** np.random.RandomState(k).randint(-6, 7)
+        ctx.mccfr_delta_set(x.reshape(-1, 5))
+        ctx.p2p_allreduce_delta()
+        got = ctx.mccfr_delta_get().reshape(-1)
+        xs = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(world)]
+        if world > 1:
+            dist.all_gather(xs, torch.from_numpy(x).to(device))
+        else:
+            xs = [torch.from_numpy(x).to(device)]
+        want = xs[0].cpu().numpy().copy()
+        for r in range(1, world):
+            want = want + xs[r].cpu().numpy()          # rank order, one rounding per add: what k_p2p_gather does
+        if not np.array_equal(got, want):
+            ok, reason = False, f"round {k}: sum differs from the rank-ordered reference"
+    timeouts, _ = ctx.p2p_status()
+    if timeouts:
+        ok, reason = False, f"{timeouts} wait(s) timed out"
+    ctx.mccfr_delta_set(np.zeros((ctx.n_infosets, 5)))
+    if not agree(ok):
+        ctx.p2p_destroy()
+        return False, reason or "a peer failed validation"
+    return True, "validated"
+
+
+def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl"):
     """Context on `local_rank` launching on a dedicated torch stream, with a torch-owned delta tensor bound as the
-    all-reduce payload.  Returns (ctx, delta_tensor, stream, all_reduce)."""
+    all-reduce payload.  Returns (ctx, delta_tensor, stream, all_reduce).  exchange: "rccl" = torch.distributed.all_reduce;
+    "p2p" = the library's one-shot peer-memory all-reduce (raises if it cannot be validated); "auto" = p2p if it validates on
+    every rank, else rccl.  The path in use is recorded in `ctx.exchange`."""
     import torch
     import torch.distributed as dist
     from . import _lib
@@ -56,6 +134,15 @@ def make_gpu_engine(local_rank, perm16, seed, world=1):
         with torch.cuda.stream(stream):
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)
 
+    ctx.exchange, ctx.exchange_note = ("rccl" if world > 1 else "none"), ""
+    if world > 1 and exchange in ("auto", "p2p"):
+        ok, why = connect_peer_exchange(ctx, rank, dist.get_world_size(), torch.device(f"cuda:{local_rank}"))
+        ctx.exchange_note = why
+        if ok:
+            ctx.exchange = "p2p"
+            return ctx, delta, stream, ctx.p2p_allreduce_delta
+        if exchange == "p2p":
+            raise RuntimeError(f"peer-memory exchange unavailable: {why}")
     return ctx, delta, stream, (all_reduce if world > 1 else (lambda: None))
 
 

@@ -1,0 +1,72 @@
+"""The N > 1 exchange step of the batched-MCCFR path done by the library itself: one-shot all-reduce of the delta buffer
+through peer-mapped (hipIpc) fine-grained memory (scopa_p2p_*, scopa_amd/csrc/scopa_p2p.hip).  The test box has ONE GPU, so
+the ranks are separate processes sharing it: that exercises the IPC plumbing, the flag/parity protocol, the rank-ordered sum
+and the bounded waits; the xGMI hop itself can only be exercised by the driver's multi-GPU run, where bench.py validates the
+exchange against RCCL before using it (scopa_amd.distributed.connect_peer_exchange)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_single_rank_self_exchange(ctx, sl):
+    ctx.set_deal(sl.deal_py_seed(42))
+    h = ctx.p2p_create(0, 1)
+    ctx.p2p_connect(h.reshape(1, 64))
+    rng = np.random.RandomState(0)
+    for k in range(5):                                   # both parities, several sequence numbers
+        x = rng.standard_normal((ctx.n_infosets, 5))
+        ctx.mccfr_delta_set(x)
+        ctx.p2p_allreduce_delta()
+        assert np.array_equal(ctx.mccfr_delta_get(), x)
+    assert ctx.p2p_status() == (0, 5)
+    ctx.p2p_destroy()
+    with pytest.raises(sl.ScopaError):
+        ctx.p2p_allreduce_delta()
+
+
+def test_odd_sized_delta_is_exchanged_whole(ctx, sl):
+    # a deal whose infoset count is odd: n*5 float64 is not a whole number of 16-byte pieces
+    for seed in range(1, 200):
+        if ctx.set_deal(sl.deal_py_seed(seed)) % 2 == 1:
+            break
+    assert ctx.n_infosets % 2 == 1
+    h = ctx.p2p_create(0, 1)
+    ctx.p2p_connect(h.reshape(1, 64))
+    x = np.random.RandomState(1).standard_normal((ctx.n_infosets, 5))
+    ctx.mccfr_delta_set(x)
+    ctx.p2p_allreduce_delta()
+    assert np.array_equal(ctx.mccfr_delta_get(), x)
+    ctx.p2p_destroy()
+    ctx.set_deal(sl.deal_py_seed(42))
+
+
+def test_three_ranks_sharing_the_gpu_match_a_single_process(ctx, sl, tmp_path):
+    world, batch_total, iters = 3, 1000, 6              # 1000 = 334 + 333 + 333 traversal ids
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "p2p_worker.py"), str(r), str(world), "29611",
+                               str(tmp_path), str(batch_total), str(iters)], env=env) for r in range(world)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=240) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
+    assert all(bool(r["ok"]) for r in res), [str(r["why"]) for r in res]
+    assert all(int(r["timeouts"]) == 0 and int(r["exchanges"]) == 3 + iters for r in res)      # 3 validation rounds + the run
+    for r in res[1:]:                                    # rank-ordered sums: replicas are bit-identical
+        assert np.array_equal(r["R"], res[0]["R"]) and np.array_equal(r["S"], res[0]["S"])
+    assert sum(int(r["visits"]) for r in res) == 463 * batch_total * iters
+    # the same global traversal ids in one process: equal up to the summation order of the three partial deltas
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.mccfr_seed(77)
+    ctx.mccfr_iterate(batch_total, iters)
+    R, S, _ = ctx.tables_get()
+    assert np.allclose(res[0]["R"], R, rtol=1e-12, atol=1e-12) and np.allclose(res[0]["S"], S, rtol=1e-12, atol=1e-12)

@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""One rank of the peer-memory exchange test (tests/test_gpu_p2p.py): all ranks share GPU 0 (the test box has one), the
+process group is gloo (RCCL refuses two ranks on one device), the exchange itself is the library's hipIpc path."""
+import os, sys
+import numpy as np
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
+    batch_total, iters = int(sys.argv[5]), int(sys.argv[6])
+    import torch
+    import torch.distributed as dist
+    from scopa_amd import _lib
+    from scopa_amd.distributed import ShardedMCCFR, connect_peer_exchange
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+    dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+    ctx = _lib.Context(0)
+    ctx.set_deal(_lib.deal_py_seed(42))
+    ctx.mccfr_seed(77)
+    ok, why = connect_peer_exchange(ctx, rank, world, torch.device("cuda:0"))
+    res = dict(ok=ok, why=why)
+    if ok:
+        # first half: the fused form (exchange inside the reduce+apply kernel, in-library loop); second half: the split form
+        # (traverse+reduce, stand-alone row exchange, apply) -- both are product paths over the same inbox protocol
+        ShardedMCCFR(ctx, rank, world, fused_exchange=True).run(batch_total, iters // 2)
+        ShardedMCCFR(ctx, rank, world, ctx.p2p_allreduce_delta).run(batch_total, iters - iters // 2)
+        timeouts, exchanges = ctx.p2p_status()
+        R, S, _ = ctx.tables_get()
+        res.update(timeouts=timeouts, exchanges=exchanges, R=R, S=S, visits=ctx.counters()[0])
+    np.savez(os.path.join(out, f"rank{rank}.npz"), **res)
+    dist.barrier()
+    ctx.close()
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
