@@ -89,9 +89,13 @@ def connect_peer_exchange(ctx, rank, world, device, rounds=3):
     n = ctx.n_infosets * 5
     for k in range(rounds):
         x = np.random.RandomState(1000 * k + rank).standard_normal(n) * 10.0 ** np.random.RandomState(k).randint(-6, 7)
-        ctx.mccfr_delta_set(x.reshape(-1, 5))
-        ctx.p2p_allreduce_delta()
-        got = ctx.mccfr_delta_get().reshape(-1)
+        got = None
+        try:                                   # a local failure must not skip the collectives below (the peers are in them)
+            ctx.mccfr_delta_set(x.reshape(-1, 5))
+            ctx.p2p_allreduce_delta()
+            got = ctx.mccfr_delta_get().reshape(-1)
+        except _lib.ScopaError as e:
+            ok, reason = False, f"round {k}: {e}"
         xs = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(world)]
         if world > 1:
             dist.all_gather(xs, torch.from_numpy(x).to(device))
@@ -99,13 +103,16 @@ def connect_peer_exchange(ctx, rank, world, device, rounds=3):
             xs = [torch.from_numpy(x).to(device)]
         want = xs[0].cpu().numpy().copy()
         for r in range(1, world):
-            want = want + xs[r].cpu().numpy()          # rank order, one rounding per add: what k_p2p_gather does
-        if not np.array_equal(got, want):
+            want = want + xs[r].cpu().numpy()          # rank order, one rounding per add: what p2p_exchange_row does
+        if got is not None and not np.array_equal(got, want):
             ok, reason = False, f"round {k}: sum differs from the rank-ordered reference"
-    timeouts, _ = ctx.p2p_status()
-    if timeouts:
-        ok, reason = False, f"{timeouts} wait(s) timed out"
-    ctx.mccfr_delta_set(np.zeros((ctx.n_infosets, 5)))
+    try:
+        timeouts, _ = ctx.p2p_status()
+        if timeouts:
+            ok, reason = False, f"{timeouts} wait(s) timed out"
+        ctx.mccfr_delta_set(np.zeros((ctx.n_infosets, 5)))
+    except _lib.ScopaError as e:
+        ok, reason = False, f"status: {e}"
     if not agree(ok):
         ctx.p2p_destroy()
         return False, reason or "a peer failed validation"
