@@ -30,7 +30,8 @@ def build_lib(force=False, verbose=False):
     if not force and not _stale():
         return LIB
     hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
-    cmd = [hipcc] + FLAGS + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
+    extra = os.environ.get("SCOPA_EXTRA_HIPCC_FLAGS", "").split()   # e.g. -DSCOPA_P2P_LIGHT=0 (scopa_p2p.h) for experiments
+    cmd = [hipcc] + FLAGS + extra + ["-o", LIB] + [os.path.join(CSRC, s) for s in SOURCES]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

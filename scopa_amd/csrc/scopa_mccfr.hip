@@ -510,17 +510,29 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
         part[chunk][pr * 2 + 1] = acc.y;
     }
     __syncthreads();
-    if (tid < kRaRows) {
-        const int r = row0 + tid;
-        if (r < n_infosets) {
-            if (s_any[tid] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
-            double d[5];
+    if (tid < 64) {  // wavefront 0: lane = 16 * row + peer; the 16 lanes of a row hold the same delta, lane 0 of each row applies it
+        const int rl = tid >> 4, q = tid & 15;
+        const int r = row0 + rl;
+        const bool valid = r < n_infosets;
+        double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (valid) {
             for (int k = 0; k < 5; k++) {
                 double t = g_delta[r * 5 + k];                 // whatever earlier launches of this iteration left there
-                for (int q = 0; q < kRaChunks; q++) t += part[q][tid * 5 + k];
+                for (int c2 = 0; c2 < kRaChunks; c2++) t += part[c2][rl * 5 + k];
                 d[k] = t;
             }
-            if constexpr (XCHG) scopa::p2p_exchange_row(xa, r, d);
+        }
+        if constexpr (XCHG) {
+            // the exchange scratch [4 rows][16 ranks][5] reuses `part`: only this wavefront is still running, and its reads of
+            // `part` above are complete (LDS operations of one wavefront are performed in order)
+            static_assert(sizeof(double) * kRaRows * scopa::kP2PMaxWorld * 5 <= sizeof(part), "exchange scratch must fit in part[][]");
+            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+            __builtin_amdgcn_wave_barrier();
+            double (*xch)[5] = reinterpret_cast<double (*)[5]>(&part[0][0]) + rl * scopa::kP2PMaxWorld;
+            scopa::p2p_exchange_wave4(xa, r, valid, q, d, xch);
+        }
+        if (valid && q == 0) {
+            if (s_any[rl] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
             const int n = (int)((g_key[r] >> 1) & 7);
             double R[4], sg[4], cd[4];
             for (int k = 0; k < 4; k++) R[k] = g_regret[r * 4 + k];

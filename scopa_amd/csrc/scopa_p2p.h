@@ -29,40 +29,74 @@ __device__ __forceinline__ double *p2p_line(double *inbox, int par, int world, i
     return inbox + (((size_t)par * world + sender) * kDecision + row) * kP2PLineDoubles;
 }
 
-// d[5] of infoset row `row` on this rank -> sum over ranks, added in rank order (identical bits on every rank).
-__device__ __forceinline__ void p2p_exchange_row(const P2PArgs &a, int row, double (&d)[5]) {
+// One WAVEFRONT exchanges up to four infoset rows: lane = 16*rl + q serves row (row0 + rl) towards peer q and from sender
+// q, so the `world` remote stores, the `world` polls and the `world` line loads of a row each cost one memory round trip,
+// not `world`.  d = this rank's delta of the lane's row (the same values in the 16 lanes of a row); xch = LDS scratch
+// [kP2PMaxWorld][5] of the lane's row.  On return d is the sum over ranks, added in rank order (identical bits on every
+// rank), in all 16 lanes of the row.  Must be called by all 64 lanes of the wavefront.
+//
+// Two forms of the same protocol.  kP2PLight = false is the textbook one: plain stores, __threadfence_system() (L2
+// write-back + invalidate at system scope), release-store of the sequence word; poll, system-scope acquire fence, plain
+// loads.  kP2PLight = true makes every access to the line a system-scope (sc0 sc1) access -- inbox memory is fine-grained,
+// such accesses go to memory, not through this XCD's L2 -- ordered by s_waitcnt alone: the sequence word is issued only
+// after the data stores of the same line were acknowledged (vmcnt(0)), and the data loads are issued only after the
+// sequence word was seen.  No cache maintenance, so the kernel's L2 contents (slabs, tables) are left alone.
+#ifndef SCOPA_P2P_LIGHT
+#define SCOPA_P2P_LIGHT 1
+#endif
+constexpr bool kP2PLight = SCOPA_P2P_LIGHT != 0;
+
+typedef double p2p_v2f64 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ void p2p_exchange_wave4(const P2PArgs &a, int row, bool row_valid, int q, double (&d)[5], double (*xch)[5]) {
     const int par = (int)(a.seq & 1ull);
-    for (int p = 0; p < a.world; p++) {
-        double *ln = p2p_line(a.inbox[p], par, a.world, a.rank, row);
-        reinterpret_cast<double2 *>(ln)[0] = make_double2(d[0], d[1]);
-        reinterpret_cast<double2 *>(ln)[1] = make_double2(d[2], d[3]);
-        ln[4] = d[4];
+    if (row_valid && q < a.world) {
+        double *out = p2p_line(a.inbox[q], par, a.world, a.rank, row);        // my row, in peer q's inbox
+        const double *in = p2p_line(a.inbox[a.rank], par, a.world, q, row);   // sender q's row, in my inbox
+        double v[5];
+        if constexpr (kP2PLight) {
+            for (int k = 0; k < 5; k++) __hip_atomic_store(out + k, d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the write-through stores are acknowledged (gfx9: vmcnt counts stores)
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + 5), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        } else {
+            reinterpret_cast<double2 *>(out)[0] = make_double2(d[0], d[1]);
+            reinterpret_cast<double2 *>(out)[1] = make_double2(d[2], d[3]);
+            out[4] = d[4];
+            __threadfence_system();
+            __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + 5), a.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(reinterpret_cast<const unsigned long long *>(in + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
+            if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // an earlier wait already gave up
+            if (wall_clock64() - t0 > a.budget) { atomicAdd(a.err, 1u); break; }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if constexpr (kP2PLight) {
+            p2p_v2f64 lo, hi;
+            double last;
+            asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
+                         "global_load_dwordx4 %1, %3, off offset:16 sc0 sc1\n\t"
+                         "global_load_dwordx2 %2, %3, off offset:32 sc0 sc1\n\t"
+                         "s_waitcnt vmcnt(0)"
+                         : "=&v"(lo), "=&v"(hi), "=&v"(last) : "v"(in) : "memory");
+            v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y; v[4] = last;
+        } else {
+            __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: the row as the peer published it
+            const double2 lo = reinterpret_cast<const double2 *>(in)[0], hi = reinterpret_cast<const double2 *>(in)[1];
+            v[0] = lo.x; v[1] = lo.y; v[2] = hi.x; v[3] = hi.y; v[4] = in[4];
+        }
+        for (int k = 0; k < 5; k++) xch[q][k] = v[k];
     }
-    __threadfence_system();   // the row is visible system-wide before any peer can see its sequence number
-    for (int p = 0; p < a.world; p++)
-        __hip_atomic_store(reinterpret_cast<unsigned long long *>(p2p_line(a.inbox[p], par, a.world, a.rank, row) + 5), a.seq,
-                           __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-    double *mine = a.inbox[a.rank];
-    const unsigned long long t0 = wall_clock64();
-    for (;;) {
-        bool all = true;
-        for (int q = 0; q < a.world; q++)   // the loads are independent: one memory round trip per poll, not `world`
-            all = all && __hip_atomic_load(reinterpret_cast<unsigned long long *>(p2p_line(mine, par, a.world, q, row) + 5),
-                                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) >= a.seq;
-        if (all) break;
-        if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // an earlier wait already gave up
-        if (wall_clock64() - t0 > a.budget) { atomicAdd(a.err, 1u); break; }
-        __builtin_amdgcn_s_sleep(2);
+    // the wavefront's own LDS hand-off: writes above, broadcast reads below
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (row_valid) {
+        for (int k = 0; k < 5; k++) d[k] = xch[0][k];
+        for (int s = 1; s < a.world; s++)
+            for (int k = 0; k < 5; k++) d[k] += xch[s][k];   // rank order, everywhere
     }
-    __atomic_thread_fence(__ATOMIC_ACQUIRE);   // system scope: the rows as the peers published them
-    double2 lo[kP2PMaxWorld], hi[kP2PMaxWorld];
-    double cnt[kP2PMaxWorld];
-    for (int q = 0; q < a.world; q++) {
-        const double *ln = p2p_line(mine, par, a.world, q, row);
-        lo[q] = reinterpret_cast<const double2 *>(ln)[0]; hi[q] = reinterpret_cast<const double2 *>(ln)[1]; cnt[q] = ln[4];
-    }
-    d[0] = lo[0].x; d[1] = lo[0].y; d[2] = hi[0].x; d[3] = hi[0].y; d[4] = cnt[0];
-    for (int q = 1; q < a.world; q++) { d[0] += lo[q].x; d[1] += lo[q].y; d[2] += hi[q].x; d[3] += hi[q].y; d[4] += cnt[q]; }
 }
 
 // host side (scopa_p2p.hip): arguments of the NEXT exchange (increments the sequence number); false if not connected

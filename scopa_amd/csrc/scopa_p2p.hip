@@ -37,14 +37,16 @@ struct scopa_p2p {
     bool connected = false;
 };
 
-// stand-alone exchange of the delta buffer: one lane per infoset row
+// stand-alone exchange of the delta buffer: one wavefront per 4 infoset rows (lane = 16 * row + peer)
 __global__ void __launch_bounds__(64) k_p2p_rows(P2PArgs a, double *__restrict__ delta, int n_rows) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r >= n_rows) return;
-    double d[5];
-    for (int k = 0; k < 5; k++) d[k] = delta[r * 5 + k];
-    scopa::p2p_exchange_row(a, r, d);
-    for (int k = 0; k < 5; k++) delta[r * 5 + k] = d[k];
+    __shared__ double xch[4][kP2PMaxWorld][5];
+    const int rl = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int r = blockIdx.x * 4 + rl;
+    const bool valid = r < n_rows;
+    double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (valid) for (int k = 0; k < 5; k++) d[k] = delta[r * 5 + k];
+    scopa::p2p_exchange_wave4(a, r, valid, q, d, xch[rl]);
+    if (valid && q == 0) for (int k = 0; k < 5; k++) delta[r * 5 + k] = d[k];
 }
 
 namespace scopa {
@@ -121,7 +123,7 @@ int32_t scopa_p2p_allreduce_delta(scopa_ctx *ctx) {
     SC_HIP(ctx, hipSetDevice(ctx->device));
     P2PArgs a;
     scopa::p2p_next_args(ctx, &a);
-    hipLaunchKernelGGL(k_p2p_rows, dim3((ctx->n_infosets + 63) / 64), dim3(64), 0, ctx->stream, a, ctx->d_delta, ctx->n_infosets);
+    hipLaunchKernelGGL(k_p2p_rows, dim3((ctx->n_infosets + 3) / 4), dim3(64), 0, ctx->stream, a, ctx->d_delta, ctx->n_infosets);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }

@@ -46,11 +46,10 @@ def test_odd_sized_delta_is_exchanged_whole(ctx, sl):
     ctx.set_deal(sl.deal_py_seed(42))
 
 
-def test_three_ranks_sharing_the_gpu_match_a_single_process(ctx, sl, tmp_path):
-    world, batch_total, iters = 3, 1000, 6              # 1000 = 334 + 333 + 333 traversal ids
+def _run_ranks(tmp_path, world, batch_total, iters, mode, port):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
-    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "p2p_worker.py"), str(r), str(world), "29611",
-                               str(tmp_path), str(batch_total), str(iters)], env=env) for r in range(world)]
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "p2p_worker.py"), str(r), str(world), str(port),
+                               str(tmp_path), str(batch_total), str(iters), mode], env=env) for r in range(world)]
     try:
         for p in procs:
             assert p.wait(timeout=240) == 0
@@ -60,13 +59,34 @@ def test_three_ranks_sharing_the_gpu_match_a_single_process(ctx, sl, tmp_path):
                 p.kill()
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     assert all(bool(r["ok"]) for r in res), [str(r["why"]) for r in res]
-    assert all(int(r["timeouts"]) == 0 and int(r["exchanges"]) == 3 + iters for r in res)      # 3 validation rounds + the run
+    assert [int(r["timeouts"]) for r in res] == [0] * world
+    assert [int(r["exchanges"]) for r in res] == [3 + iters] * world           # 3 validation rounds + the run
     for r in res[1:]:                                    # rank-ordered sums: replicas are bit-identical
         assert np.array_equal(r["R"], res[0]["R"]) and np.array_equal(r["S"], res[0]["S"])
     assert sum(int(r["visits"]) for r in res) == 463 * batch_total * iters
-    # the same global traversal ids in one process: equal up to the summation order of the three partial deltas
+    return res
+
+
+def _single_process(ctx, sl, batch_total, iters):
     ctx.set_deal(sl.deal_py_seed(42))
     ctx.mccfr_seed(77)
     ctx.mccfr_iterate(batch_total, iters)
     R, S, _ = ctx.tables_get()
+    return R, S
+
+
+def test_two_ranks_free_running_fused_and_split(ctx, sl, tmp_path):
+    """Two processes sharing the GPU, no host synchronisation inside the run: 3 fused iterations (exchange inside the
+    reduce+apply kernel, in-library loop) then 3 split ones (traverse+reduce, stand-alone exchange, apply)."""
+    batch_total, iters = 1001, 6                         # 1001 = 501 + 500 traversal ids
+    res = _run_ranks(tmp_path, 2, batch_total, iters, "free", 29611)
+    # the same global traversal ids in one process: equal up to the summation order of the partial deltas
+    R, S = _single_process(ctx, sl, batch_total, iters)
+    assert np.allclose(res[0]["R"], R, rtol=1e-12, atol=1e-12) and np.allclose(res[0]["S"], S, rtol=1e-12, atol=1e-12)
+
+
+def test_three_ranks_lockstep_rank_ordered_sum(ctx, sl, tmp_path):
+    batch_total, iters = 1000, 4                         # 1000 = 334 + 333 + 333 traversal ids
+    res = _run_ranks(tmp_path, 3, batch_total, iters, "lockstep", 29612)
+    R, S = _single_process(ctx, sl, batch_total, iters)
     assert np.allclose(res[0]["R"], R, rtol=1e-12, atol=1e-12) and np.allclose(res[0]["S"], S, rtol=1e-12, atol=1e-12)

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 
 def main():
     rank, world, port, out = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], sys.argv[4]
-    batch_total, iters = int(sys.argv[5]), int(sys.argv[6])
+    batch_total, iters, mode = int(sys.argv[5]), int(sys.argv[6]), sys.argv[7]
     import torch
     import torch.distributed as dist
     from scopa_amd import _lib
@@ -22,10 +22,23 @@ def main():
     ok, why = connect_peer_exchange(ctx, rank, world, torch.device("cuda:0"))
     res = dict(ok=ok, why=why)
     if ok:
-        # first half: the fused form (exchange inside the reduce+apply kernel, in-library loop); second half: the split form
-        # (traverse+reduce, stand-alone row exchange, apply) -- both are product paths over the same inbox protocol
-        ShardedMCCFR(ctx, rank, world, fused_exchange=True).run(batch_total, iters // 2)
-        ShardedMCCFR(ctx, rank, world, ctx.p2p_allreduce_delta).run(batch_total, iters - iters // 2)
+        if mode == "free":
+            # first half: the fused form (exchange inside the reduce+apply kernel, in-library loop); second half: the split form
+            # (traverse+reduce, stand-alone row exchange, apply) -- both are product paths over the same inbox protocol
+            ShardedMCCFR(ctx, rank, world, fused_exchange=True).run(batch_total, iters // 2)
+            ShardedMCCFR(ctx, rank, world, ctx.p2p_allreduce_delta).run(batch_total, iters - iters // 2)
+        else:
+            # "lockstep": the split form with a host barrier before every exchange.  The ranks SHARE one GPU here and the traversal
+            # kernel needs a whole CU's LDS, so a rank spinning in an exchange while another still has its traversal queued could
+            # starve it (with one process per GPU -- the deployment -- a GPU only ever runs its own stream)
+            from scopa_amd.distributed import shard_range
+            b0, nb = shard_range(batch_total, rank, world)
+            for _ in range(iters):
+                ctx.mccfr_traverse(ctx.mccfr_iteration(), b0, nb)
+                ctx.synchronize()
+                dist.barrier()
+                ctx.p2p_allreduce_delta()
+                ctx.mccfr_apply()
         timeouts, exchanges = ctx.p2p_status()
         R, S, _ = ctx.tables_get()
         res.update(timeouts=timeouts, exchanges=exchanges, R=R, S=S, visits=ctx.counters()[0])
