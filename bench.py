@@ -139,6 +139,7 @@ def main():
     run(args.warmup)
     fence()
     d0, _ = ctx.counters()
+    dev_n0, dev_ms0 = ctx.prof_device()
     ctx.prof_enable(args.prof_stride)
     fence()
     t0 = time.perf_counter()
@@ -146,6 +147,7 @@ def main():
     fence()
     elapsed = time.perf_counter() - t0
     launches, kernel_ms = ctx.prof_read()
+    dev_n1, dev_ms1 = ctx.prof_device()
     ctx.prof_enable(0)
     d1, _ = ctx.counters()
 
@@ -197,6 +199,11 @@ def main():
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
+                         "kernel_avg_us_device_clock": 1e3 * (dev_ms1 - dev_ms0) / max(dev_n1 - dev_n0, 1), "launches_device_clock": dev_n1 - dev_n0,
+                         "timing_note": "kernel_avg_us: HIP events on the kernel's stream around every prof-stride-th launch (includes the "
+                                        "event records' own dispatch gap); kernel_avg_us_device_clock: first workgroup start -> last "
+                                        "workgroup end on the 100 MHz device clock, all launches of the timed region (the figure to hold "
+                                        "against rocprofv3's kernel duration)",
                          "algorithmic_bytes_per_launch": visits_per_launch * ALG_BYTES_PER_VISIT,
                          "note": "algorithmic bytes = 111.6 B/visit x 463 x batch visits per launch (SURVEY 8d); the working set "
                                  "(tables, tree) is LDS-resident by design, so HBM traffic is far below the algorithmic bytes"},

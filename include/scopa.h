@@ -313,6 +313,10 @@ int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *term
  * launches and their summed kernel milliseconds since enable. */
 int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride);
 int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
+/* the same kernel timed by ITSELF: per launch, first workgroup start -> last workgroup end on the 100 MHz device-wide clock,
+ * every launch since the context was created (take differences); no events, no dispatch latency: comparable with a profiler's
+ * kernel durations */
+int32_t scopa_prof_device(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
 
 #ifdef __cplusplus
 }

@@ -32,7 +32,7 @@ SYMBOLS = [
     "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts",
     "scopa_team_state_init", "scopa_team_state_step", "scopa_team_state_legal", "scopa_team_state_rewards_x2", "scopa_team_state_infoset_string",
     "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts",
-    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read",
+    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device",
 ]
 
 
@@ -168,6 +168,7 @@ def lib():
         "scopa_counters": (i32, [vp, C.POINTER(u64), C.POINTER(u64)]),
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
+        "scopa_prof_device": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -475,6 +476,12 @@ class Context:
     def prof_read(self):
         n, ms = C.c_int64(), C.c_double()
         self._ck(self._L.scopa_prof_read(self._h, C.byref(n), C.byref(ms)), "scopa_prof_read")
+        return n.value, ms.value
+
+    def prof_device(self):
+        """-> (traversal launches, their summed milliseconds by the kernel's own 100 MHz clock) since the context was created"""
+        n, ms = C.c_int64(), C.c_double()
+        self._ck(self._L.scopa_prof_device(self._h, C.byref(n), C.byref(ms)), "scopa_prof_device")
         return n.value, ms.value
 
 

@@ -314,6 +314,18 @@ int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *term
     return SCOPA_OK;
 }
 
+int32_t scopa_prof_device(scopa_ctx *ctx, int64_t *launches, double *kernel_ms) {
+    // the traversal kernel's own clock: per launch, first workgroup start -> last workgroup end on the 100 MHz device-wide
+    // counter (s_memrealtime), summed on device since the context was created; every launch is counted, nothing is bracketed
+    if (!ctx) return SCOPA_EINVAL;
+    unsigned long long h[5] = {0, 0, 0, 0, 0};
+    SC_HIP(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (launches) *launches = (int64_t)h[4];
+    if (kernel_ms) *kernel_ms = (double)h[3] * 1e-5;   // 10 ns ticks
+    return SCOPA_OK;
+}
+
 int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride) {
     if (!ctx || stride < 0) return SCOPA_EINVAL;
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));

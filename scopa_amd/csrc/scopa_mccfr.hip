@@ -276,6 +276,9 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
     wave_lds_sync();  // the next pair overwrites this wave's scratch
 }
 
+// per-workgroup records behind the 8 context totals: [0, 1024) visit-count pairs, [1024, 2048) (start, end) clock pairs
+namespace { constexpr int kWgTimeOff = 1024; }
+
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_slabs,
@@ -283,6 +286,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                  unsigned long long *__restrict__ g_wg_counts, uint8_t *__restrict__ g_seen_slabs) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
+    const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's life span, for scopa_prof_device
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | cdf thresholds[4] | pad
     double *s_dR = s_sigcdf + (size_t)I * kRow + (I & 1);                        // [I][4] (16-byte aligned)
@@ -315,7 +319,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         double *slab = g_slabs + (size_t)blockIdx.x * ((size_t)I * 5);
         for (int c = tid; c < I * 5; c += blockDim.x) {
             const int r = c / 5, k = c - r * 5;
-            slab[c] = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
+            // streamed: nothing on this XCD reads the slab again, and lines already on their way to memory shorten the end-of-kernel write-back
+            __builtin_nontemporal_store(k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r], &slab[c]);
         }
         uint8_t *seen = g_seen_slabs + (size_t)blockIdx.x * kDecision;
         for (int r = tid; r < I; r += blockDim.x) seen[r] = s_seen[r];
@@ -328,6 +333,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
     __syncthreads();
     if (tid < 2) g_wg_counts[blockIdx.x * 2 + tid] = s_vis[tid];
+    if (tid == 0) { g_wg_counts[kWgTimeOff + blockIdx.x * 2] = t_start; g_wg_counts[kWgTimeOff + blockIdx.x * 2 + 1] = wall_clock64(); }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -397,20 +403,41 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
 // delta[c] += sum over slabs, in slab order (deterministic).  A workgroup owns 16 consecutive cells; thread
 // (chunk = tid / 16, cell = tid % 16) adds slabs chunk, chunk+16, ... so that 16 lanes read 128 contiguous bytes of
 // one slab; the 16 partial sums per cell are then combined in chunk order through LDS.
+// fold the per-workgroup records of a traversal launch: wavefront shuffles first, then ONE LDS atomic per wavefront and
+// quantity (256 same-address LDS atomics serialise and made this workgroup the kernel's critical path)
+__device__ __forceinline__ void wg_record_fold(unsigned long long d, unsigned long long t, unsigned long long t0, unsigned long long t1,
+                                               unsigned long long *s_tot, unsigned long long *s_span) {
+    for (int off = 32; off > 0; off >>= 1) {
+        d += __shfl_down(d, off); t += __shfl_down(t, off);
+        const unsigned long long a = __shfl_down(t0, off), b = __shfl_down(t1, off);
+        t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
+    }
+    if ((threadIdx.x & 63) == 0) {
+        atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t);
+        atomicMin(&s_span[0], t0); atomicMax(&s_span[1], t1);
+    }
+}
+
 __global__ void __launch_bounds__(256)
 k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_cells,
                const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters,
                const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit) {
     __shared__ double part[16][17];
-    __shared__ unsigned long long s_tot[2];
+    __shared__ unsigned long long s_tot[2], s_span[2];
     if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch: one lane per workgroup record, LDS reduce
-        if (threadIdx.x < 2) s_tot[threadIdx.x] = 0ull;
+        if (threadIdx.x < 2) { s_tot[threadIdx.x] = 0ull; s_span[threadIdx.x] = threadIdx.x ? 0ull : ~0ull; }
         __syncthreads();
         unsigned long long d = 0ull, t = 0ull;
-        for (int w = threadIdx.x; w < n_slabs; w += blockDim.x) { d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1]; }
-        if (d | t) { atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t); }
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (int w = threadIdx.x; w < n_slabs; w += blockDim.x) {
+            d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1];
+            const unsigned long long a = g_wg_counts[kWgTimeOff + w * 2], b = g_wg_counts[kWgTimeOff + w * 2 + 1];
+            t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
+        }
+        wg_record_fold(d, t, t0, t1, s_tot, s_span);
         __syncthreads();
         if (threadIdx.x < 2) g_counters[threadIdx.x] += s_tot[threadIdx.x];
+        if (threadIdx.x == 2) { g_counters[3] += s_span[1] - s_span[0]; g_counters[4] += 1ull; }   // traversal kernel: first start -> last end, launches
     }
     {   // infosets first seen by this launch: 16 per workgroup, 16 lanes OR the slabs' flags
         const int r = blockIdx.x * 16 + (threadIdx.x & 15);
@@ -463,17 +490,23 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
                      double *__restrict__ g_regret, double *__restrict__ g_strat, double *__restrict__ g_sigcdf, scopa::P2PArgs xa) {
     __shared__ double part[kRaChunks][kRaCells];
     __shared__ unsigned int s_any[kRaRows];
-    __shared__ unsigned long long s_tot[2];
+    __shared__ unsigned long long s_tot[2], s_span[2];
     const int tid = threadIdx.x, n_cells = n_infosets * 5;
     if (tid < kRaRows) s_any[tid] = 0u;
     if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch
-        if (tid < 2) s_tot[tid] = 0ull;
+        if (tid < 2) { s_tot[tid] = 0ull; s_span[tid] = tid ? 0ull : ~0ull; }
         __syncthreads();
         unsigned long long d = 0ull, t = 0ull;
-        for (int w = tid; w < n_slabs; w += blockDim.x) { d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1]; }
-        if (d | t) { atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t); }
+        unsigned long long t0 = ~0ull, t1 = 0ull;
+        for (int w = tid; w < n_slabs; w += blockDim.x) {
+            d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1];
+            const unsigned long long a = g_wg_counts[kWgTimeOff + w * 2], b = g_wg_counts[kWgTimeOff + w * 2 + 1];
+            t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
+        }
+        wg_record_fold(d, t, t0, t1, s_tot, s_span);
         __syncthreads();
         if (tid < 2) g_counters[tid] += s_tot[tid];
+        if (tid == 2) { g_counters[3] += s_span[1] - s_span[0]; g_counters[4] += 1ull; }   // traversal kernel: first start -> last end, launches
     }
     __syncthreads();
     const int row0 = blockIdx.x * kRaRows;
