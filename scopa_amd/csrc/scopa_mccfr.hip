@@ -424,7 +424,7 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
                const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit) {
     __shared__ double part[16][17];
     __shared__ unsigned long long s_tot[2], s_span[2];
-    if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch: one lane per workgroup record, LDS reduce
+    if (blockIdx.x == gridDim.x - 1) {  // the extra, last workgroup owns no cells: it folds the launch's per-workgroup records
         if (threadIdx.x < 2) { s_tot[threadIdx.x] = 0ull; s_span[threadIdx.x] = threadIdx.x ? 0ull : ~0ull; }
         __syncthreads();
         unsigned long long d = 0ull, t = 0ull;
@@ -478,7 +478,12 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
 // chunk, chunk+24, ... (<= 11 at 256 slabs); all its loads are issued before the first add.  The 24 partial sums per cell
 // are combined in chunk order through LDS, then 4 lanes apply their rows exactly as k_mccfr_apply does.
 // Deterministic: the order of every float64 sum is fixed by n_slabs, not by timing.
-namespace { constexpr int kRaRows = 4, kRaCells = kRaRows * 5, kRaPairs = kRaCells / 2, kRaChunks = 24; }
+namespace {
+// measured: 4 rows x 24 chunks 8.3 us; 2 rows x 51 chunks 10.5 us (the serial 51-term combine); 16 rows x 6 chunks slower still
+constexpr int kRaRows = 4, kRaCells = kRaRows * 5, kRaPairs = kRaCells / 2, kRaChunks = 24;
+constexpr int kRaUnroll = 12;  // slabs in flight per lane and batch: kRaChunks * kRaUnroll >= 256 covers the usual launch in one batch
+static_assert(kRaRows <= 4 && (kRaCells % 2) == 0 && kRaChunks * kRaPairs <= 256, "reduce_apply tiling");
+}
 
 // XCHG (N > 1): between "the 4 rows' deltas of THIS rank are known" and "apply them", each row is exchanged with the
 // peers (scopa_p2p.h) and becomes the rank-ordered sum over ranks -- the whole multi-GPU step stays two launches.
@@ -493,7 +498,7 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
     __shared__ unsigned long long s_tot[2], s_span[2];
     const int tid = threadIdx.x, n_cells = n_infosets * 5;
     if (tid < kRaRows) s_any[tid] = 0u;
-    if (blockIdx.x == gridDim.x - 1) {  // visit counters of this launch
+    if (blockIdx.x == gridDim.x - 1) {  // the extra, last workgroup owns no rows: it folds the launch's per-workgroup records
         if (tid < 2) { s_tot[tid] = 0ull; s_span[tid] = tid ? 0ull : ~0ull; }
         __syncthreads();
         unsigned long long d = 0ull, t = 0ull;
@@ -510,11 +515,20 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
     }
     __syncthreads();
     const int row0 = blockIdx.x * kRaRows;
+    // the applying lanes (lane 0 of each 16-lane row group of wavefront 0) fetch their table rows now, under the slab loads
+    double pre_R[4] = {0.0, 0.0, 0.0, 0.0}, pre_d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    int pre_n = 0;
+    if (tid < 16 * kRaRows && (tid & 15) == 0 && row0 + (tid >> 4) < n_infosets) {
+        const int r = row0 + (tid >> 4);
+        pre_n = (int)((g_key[r] >> 1) & 7);
+        for (int k = 0; k < 4; k++) pre_R[k] = g_regret[r * 4 + k];
+        for (int k = 0; k < 5; k++) pre_d[k] = g_delta[r * 5 + k];   // whatever earlier launches of this iteration left there
+    }
     {   // infosets first seen by this launch: 4 rows x 64 lanes OR the slabs' flags
-        const int rl = tid & 3, r = row0 + rl;
+        const int rl = tid % kRaRows, r = row0 + rl;
         unsigned int any = 0u;
         if (r < n_infosets)
-            for (int w = tid >> 2; w < n_slabs; w += 64) any |= g_seen_slabs[(size_t)w * kDecision + r];
+            for (int w = tid / kRaRows; w < n_slabs; w += 256 / kRaRows) any |= g_seen_slabs[(size_t)w * kDecision + r];
         if (any) s_any[rl] = 1u;  // benign race
     }
     const int chunk = tid / kRaPairs, pr = tid - chunk * kRaPairs;
@@ -523,10 +537,10 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
         double2 acc = make_double2(0.0, 0.0);
         if (c < n_cells) {
             const bool has2 = c + 1 < n_cells;
-            for (int base = chunk; base < n_slabs; base += kRaChunks * 12) {
-                double2 v[12];
+            for (int base = chunk; base < n_slabs; base += kRaChunks * kRaUnroll) {
+                double2 v[kRaUnroll];
 #pragma unroll
-                for (int q = 0; q < 12; q++) {
+                for (int q = 0; q < kRaUnroll; q++) {
                     const int sl = base + kRaChunks * q;
                     v[q] = make_double2(0.0, 0.0);
                     if (sl < n_slabs) {
@@ -536,7 +550,7 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 12; q++) { acc.x += v[q].x; acc.y += v[q].y; }
+                for (int q = 0; q < kRaUnroll; q++) { acc.x += v[q].x; acc.y += v[q].y; }
             }
         }
         part[chunk][pr * 2] = acc.x;
@@ -546,11 +560,11 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
     if (tid < 64) {  // wavefront 0: lane = 16 * row + peer; the 16 lanes of a row hold the same delta, lane 0 of each row applies it
         const int rl = tid >> 4, q = tid & 15;
         const int r = row0 + rl;
-        const bool valid = r < n_infosets;
+        const bool valid = rl < kRaRows && r < n_infosets;
         double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
         if (valid) {
             for (int k = 0; k < 5; k++) {
-                double t = g_delta[r * 5 + k];                 // whatever earlier launches of this iteration left there
+                double t = __shfl(pre_d[k], tid & 48);         // the row's lane 0 fetched it
                 for (int c2 = 0; c2 < kRaChunks; c2++) t += part[c2][rl * 5 + k];
                 d[k] = t;
             }
@@ -558,7 +572,7 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
         if constexpr (XCHG) {
             // the exchange scratch [4 rows][16 ranks][5] reuses `part`: only this wavefront is still running, and its reads of
             // `part` above are complete (LDS operations of one wavefront are performed in order)
-            static_assert(sizeof(double) * kRaRows * scopa::kP2PMaxWorld * 5 <= sizeof(part), "exchange scratch must fit in part[][]");
+            static_assert(sizeof(double) * 4 * scopa::kP2PMaxWorld * 5 <= sizeof(part), "exchange scratch must fit in part[][]");
             __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
             __builtin_amdgcn_wave_barrier();
             double (*xch)[5] = reinterpret_cast<double (*)[5]>(&part[0][0]) + rl * scopa::kP2PMaxWorld;
@@ -566,9 +580,9 @@ k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__
         }
         if (valid && q == 0) {
             if (s_any[rl] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
-            const int n = (int)((g_key[r] >> 1) & 7);
+            const int n = pre_n;
             double R[4], sg[4], cd[4];
-            for (int k = 0; k < 4; k++) R[k] = g_regret[r * 4 + k];
+            for (int k = 0; k < 4; k++) R[k] = pre_R[k];
             mc_sigma(R, n, sg);
             for (int k = 0; k < n; k++) {
                 R[k] += d[k];
@@ -752,11 +766,11 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
         scopa::P2PArgs xa{};
         if (exchange) {
             SC_REQUIRE(ctx, scopa::p2p_next_args(ctx, &xa), SCOPA_ESTATE, "mccfr sharded iteration: peer exchange not connected");
-            hipLaunchKernelGGL(k_mccfr_reduce_apply<true>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+            hipLaunchKernelGGL(k_mccfr_reduce_apply<true>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows + 1), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
                                ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
                                ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, xa);
         } else {
-            hipLaunchKernelGGL(k_mccfr_reduce_apply<false>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+            hipLaunchKernelGGL(k_mccfr_reduce_apply<false>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows + 1), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
                                ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
                                ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, xa);
         }
@@ -765,7 +779,7 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
         ctx->iteration++;
         return SCOPA_OK;
     }
-    hipLaunchKernelGGL(k_mccfr_reduce, dim3((n_cells + 15) / 16), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
+    hipLaunchKernelGGL(k_mccfr_reduce, dim3((n_cells + 15) / 16 + 1), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
                        ctx->d_delta, n_cells, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
