@@ -299,11 +299,43 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     if (tid < 2) s_vis[tid] = 0u;
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
-    for (int i = tid; i < I * 8; i += blockDim.x) if ((i & 7) < kRow) s_sigcdf[(i >> 3) * kRow + (i & 7)] = g_sigcdf[i];  // prepared rows, re-strided
-    for (int i = tid; i < I * 4; i += blockDim.x) s_dR[i] = 0.0;
-    for (int r = tid; r < I; r += blockDim.x) { s_cnt[r] = 0u; s_seen[r] = 0; }
-    for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
-    for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
+    // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue instead
+    // of one per loop iteration), the LDS zeroing runs underneath them, then the loaded pieces are stored.
+    {
+        constexpr int kSig = 7;                                                   // pieces per thread held in registers: covers I <= 1653 at 1024 threads
+        const int nthr = blockDim.x;
+        const double2 *g2 = reinterpret_cast<const double2 *>(g_sigcdf);
+        const uint32_t *gi = reinterpret_cast<const uint32_t *>(g_infoset), *gp = reinterpret_cast<const uint32_t *>(g_payoff);
+        auto put = [&](int idx, double2 x) {                                      // 16-byte piece idx of the [I][8] rows -> the 7-double LDS rows
+            const int row = idx >> 2, piece = idx & 3;                            // pieces 0,1: sigma[4]; 2: thresholds 0,1; 3: threshold 2 (| unused)
+            s_sigcdf[row * kRow + piece * 2] = x.x;
+            if (piece * 2 + 1 < kRow) s_sigcdf[row * kRow + piece * 2 + 1] = x.y;
+        };
+        double2 v[kSig];
+#pragma unroll
+        for (int j = 0; j < kSig; j++) {
+            const int idx = tid + j * nthr;
+            v[j] = idx < I * 4 ? g2[idx] : make_double2(0.0, 0.0);
+        }
+        // node -> infoset map: 1653 u16 = 826 words + one half word; leaf payoffs: 576 bytes = 144 words (both arrays 4-byte aligned)
+        const uint32_t wi = tid < kDecision / 2 ? gi[tid] : 0u;
+        const uint32_t wp = tid < kTerminal / 4 ? gp[tid] : 0u;
+        const uint16_t last_inf = g_infoset[kDecision - 1];
+        for (int i = tid; i < I * 4; i += nthr) s_dR[i] = 0.0;
+        for (int r = tid; r < I; r += nthr) { s_cnt[r] = 0u; s_seen[r] = 0; }
+#pragma unroll
+        for (int j = 0; j < kSig; j++) {
+            const int idx = tid + j * nthr;
+            if (idx < I * 4) put(idx, v[j]);
+        }
+        if (tid < kDecision / 2) reinterpret_cast<uint32_t *>(s_inf)[tid] = wi;
+        if (tid == 0) s_inf[kDecision - 1] = last_inf;
+        if (tid < kTerminal / 4) reinterpret_cast<uint32_t *>(s_pay)[tid] = wp;
+        // narrower workgroups (deals with many infosets leave room for fewer wavefronts): the rest, plainly
+        for (int idx = tid + kSig * nthr; idx < I * 4; idx += nthr) put(idx, g2[idx]);
+        for (int i = tid + nthr; i < kDecision / 2; i += nthr) reinterpret_cast<uint32_t *>(s_inf)[i] = gi[i];
+        for (int i = tid + nthr; i < kTerminal / 4; i += nthr) reinterpret_cast<uint32_t *>(s_pay)[i] = gp[i];
+    }
     __syncthreads();
 
     WaveScratch &ws = s_wave[wave];
