@@ -90,3 +90,20 @@ def test_three_ranks_lockstep_rank_ordered_sum(ctx, sl, tmp_path):
     res = _run_ranks(tmp_path, 3, batch_total, iters, "lockstep", 29612)
     R, S = _single_process(ctx, sl, batch_total, iters)
     assert np.allclose(res[0]["R"], R, rtol=1e-12, atol=1e-12) and np.allclose(res[0]["S"], S, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("mode", ["fail1", "failconnect"])
+def test_setup_failure_on_one_rank_is_agreed_by_all(tmp_path, mode):
+    """The fallback decision (peer exchange vs torch.distributed all-reduce) must be the same on every rank."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "p2p_worker.py"), str(r), "2", "29613", str(tmp_path), "64", "1", mode],
+                              env=env) for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=120) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    res = [np.load(tmp_path / f"rank{r}.npz") for r in range(2)]
+    assert [bool(r["ok"]) for r in res] == [False, False], [str(r["why"]) for r in res]

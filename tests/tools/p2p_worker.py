@@ -19,6 +19,14 @@ def main():
     ctx = _lib.Context(0)
     ctx.set_deal(_lib.deal_py_seed(42))
     ctx.mccfr_seed(77)
+    if mode == "fail1" and rank == 1:            # one rank cannot set the exchange up: every rank must come back with ok == False, nobody hangs
+        def refuse(*a, **k):
+            raise _lib.ScopaError(-3, "scopa_p2p_create (simulated failure)")
+        ctx.p2p_create = refuse
+    if mode == "failconnect" and rank == 0:
+        def refuse2(*a, **k):
+            raise _lib.ScopaError(-3, "scopa_p2p_connect (simulated failure)")
+        ctx.p2p_connect = refuse2
     ok, why = connect_peer_exchange(ctx, rank, world, torch.device("cuda:0"))
     res = dict(ok=ok, why=why)
     if ok:
