@@ -295,7 +295,7 @@ int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const 
 // Fused traversal: ONE launch per traversal batch instead of ~65 (8 plies x {features, 3 GEMMs + activations, expand} +
 // 8 backward steps).  One WAVEFRONT walks one traversal level-synchronously; both players' advantage MLPs
 // (34-128-64-16, float32, 13 776 parameters = 55 KB each) sit in LDS for the whole launch and the forward pass of the
-// <= 24 frontier nodes of a ply runs inside the wave, four nodes at a time:
+// <= 24 frontier nodes of a ply runs inside the wave, kG = 4 nodes at a time:
 //   layer 1  sparse: the input is one-hot/multi-hot (<= 4 hand cards, <= 8 table cards, one constant), so a hidden unit is
 //            b1 + a handful of weight columns -- no multiplies;  each lane owns hidden units lane and lane+64
 //   layer 2  each lane owns one of the 64 units for the four nodes: 128 x (one weight read + one float4 broadcast read + 4 FMA)
@@ -307,13 +307,14 @@ namespace {
 constexpr int kNetFloats = 34 * 128 + 128 + 128 * 64 + 64 + 64 * 16 + 16;  // 13 776
 constexpr int kW1 = 0, kB1 = 34 * 128, kW2 = kB1 + 128, kB2 = kW2 + 128 * 64, kW3 = kB2 + 64, kB3 = kW3 + 64 * 16;
 
+constexpr int kG = 4;         // frontier nodes evaluated together (a "group"); measured: 4 nodes x 10 wavefronts 1.18 ms per iteration, 8 nodes x 6 wavefronts (what LDS then allows) 1.76 ms
 struct SdWave {               // per-wavefront scratch
-    float h1[128][4];         // hidden layer 1 of the four nodes in flight
-    float h2[64][4];
+    float h1[128][kG];        // hidden layer 1 of the nodes in flight
+    float h2[64][kG];
     float pol_trav[41][4];    // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
     float val[2][24];
-    float polcur[4][4];
-    scopa_state st[4];        // packed states of the four nodes in flight
+    float polcur[kG][4];
+    scopa_state st[kG];       // packed states of the nodes in flight
     uint16_t idx[9][24];      // tree index of every frontier node, per ply (ply 8 = leaves)
     uint16_t pad[8];
 };
@@ -353,15 +354,24 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
             const float *W = s_w + p * kNetFloats;
             const int m = (d - traverser) >> 1;                       // traverser-ply index when trav_ply
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
-            for (int g0 = 0; g0 < width; g0 += 4) {
-                // the group's four packed states: one global load per node, then LDS broadcasts for every phase below
-                if (lane < 4 && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[d][g0 + lane]];
+            if (!trav_ply && nl == 1) {
+                // opponent node with ONE legal action (plies 6/7): whatever the advantages are, regret matching either puts all mass
+                // on it or falls back to uniform over it (deep_cfr.py:353-359) -- the child is forced and nothing else of this
+                // node is used (no memory row, no value weight), so its forward pass is skipped: 24 of the 105 / 82 node
+                // evaluations of a traversal
+                if (lane < width) ws.idx[d + 1][lane] = ws.idx[d][lane];
                 sd_sync();
-                // layer 1 (sparse): hidden units lane, lane + 64 for up to four nodes.  Static, predicated loops: all
+                continue;
+            }
+            for (int g0 = 0; g0 < width; g0 += kG) {
+                // the group's packed states: one global load per node, then LDS broadcasts for every phase below
+                if (lane < kG && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[d][g0 + lane]];
+                sd_sync();
+                // layer 1 (sparse): hidden units lane, lane + 64 for the group's nodes.  Static, predicated loops: all
                 // weight-column reads of a node are independent and can be in flight together.
-                float a0[4], a1[4];
+                float a0[kG], a1[kG];
 #pragma unroll
-                for (int q = 0; q < 4; q++) {
+                for (int q = 0; q < kG; q++) {
                     const bool liveq = g0 + q < width;
                     const scopa_state s = ws.st[q];
                     const int nh = liveq ? s.nh[p] : 0, nt = liveq ? s.nt : 0;
@@ -379,41 +389,56 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                         const float w0 = W[kW1 + c * 128 + lane], w1 = W[kW1 + c * 128 + 64 + lane];
                         if (k < nt) { x0 += w0; x1 += w1; }
                     }
-                    a0[q] = x0; a1[q] = x1;
+                    a0[q] = fmaxf(x0, 0.0f); a1[q] = fmaxf(x1, 0.0f);
                 }
-                *reinterpret_cast<float4 *>(ws.h1[lane]) = make_float4(fmaxf(a0[0], 0.0f), fmaxf(a0[1], 0.0f), fmaxf(a0[2], 0.0f), fmaxf(a0[3], 0.0f));
-                *reinterpret_cast<float4 *>(ws.h1[lane + 64]) = make_float4(fmaxf(a1[0], 0.0f), fmaxf(a1[1], 0.0f), fmaxf(a1[2], 0.0f), fmaxf(a1[3], 0.0f));
+#pragma unroll
+                for (int q4 = 0; q4 < kG / 4; q4++) {
+                    reinterpret_cast<float4 *>(ws.h1[lane])[q4] = make_float4(a0[4 * q4], a0[4 * q4 + 1], a0[4 * q4 + 2], a0[4 * q4 + 3]);
+                    reinterpret_cast<float4 *>(ws.h1[lane + 64])[q4] = make_float4(a1[4 * q4], a1[4 * q4 + 1], a1[4 * q4 + 2], a1[4 * q4 + 3]);
+                }
                 sd_sync();
-                // layer 2: hidden unit `lane` for the four nodes
-                float4 acc = make_float4(W[kB2 + lane], W[kB2 + lane], W[kB2 + lane], W[kB2 + lane]);
+                // layer 2: hidden unit `lane` for the group's nodes: per input one weight read + kG/4 float4 broadcasts + kG FMAs
+                float acc[kG];
+#pragma unroll
+                for (int q = 0; q < kG; q++) acc[q] = W[kB2 + lane];
 #pragma unroll 8
                 for (int i = 0; i < 128; i++) {
                     const float w = W[kW2 + i * 64 + lane];
-                    const float4 h = *reinterpret_cast<const float4 *>(ws.h1[i]);
-                    acc.x = fmaf(w, h.x, acc.x); acc.y = fmaf(w, h.y, acc.y); acc.z = fmaf(w, h.z, acc.z); acc.w = fmaf(w, h.w, acc.w);
+#pragma unroll
+                    for (int q4 = 0; q4 < kG / 4; q4++) {
+                        const float4 h = reinterpret_cast<const float4 *>(ws.h1[i])[q4];
+                        acc[4 * q4] = fmaf(w, h.x, acc[4 * q4]); acc[4 * q4 + 1] = fmaf(w, h.y, acc[4 * q4 + 1]);
+                        acc[4 * q4 + 2] = fmaf(w, h.z, acc[4 * q4 + 2]); acc[4 * q4 + 3] = fmaf(w, h.w, acc[4 * q4 + 3]);
+                    }
                 }
-                *reinterpret_cast<float4 *>(ws.h2[lane]) = make_float4(fmaxf(acc.x, 0.0f), fmaxf(acc.y, 0.0f), fmaxf(acc.z, 0.0f), fmaxf(acc.w, 0.0f));
+#pragma unroll
+                for (int q4 = 0; q4 < kG / 4; q4++)
+                    reinterpret_cast<float4 *>(ws.h2[lane])[q4] = make_float4(fmaxf(acc[4 * q4], 0.0f), fmaxf(acc[4 * q4 + 1], 0.0f),
+                                                                              fmaxf(acc[4 * q4 + 2], 0.0f), fmaxf(acc[4 * q4 + 3], 0.0f));
                 sd_sync();
-                // layer 3: lane = node q * 16 + output o
-                const int q = lane >> 4, o = lane & 15;
-                float adv = W[kB3 + o];
+                // layer 3: lane = (node within a quartet) * 16 + output o, one pass per quartet of the group
+#pragma unroll
+                for (int q4 = 0; q4 < kG / 4; q4++) {
+                    const int q = 4 * q4 + (lane >> 4), o = lane & 15;
+                    float adv = W[kB3 + o];
 #pragma unroll 8
-                for (int i = 0; i < 64; i++) adv = fmaf(W[kW3 + i * 16 + o], ws.h2[i][q], adv);
-                // positive_regret_policy over the node's 16 outputs (nets.py:93-101)
-                const bool live = g0 + q < width;
-                const scopa_state s = ws.st[q];
-                uint32_t hand_bits = 0;
+                    for (int i = 0; i < 64; i++) adv = fmaf(W[kW3 + i * 16 + o], ws.h2[i][q], adv);
+                    // positive_regret_policy over the node's 16 outputs (nets.py:93-101)
+                    const bool live = g0 + q < width;
+                    const scopa_state s = ws.st[q];
+                    uint32_t hand_bits = 0;
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (live && k < nl) hand_bits |= 1u << nib(s.hand[p], k);
-                const float pos = (live && ((hand_bits >> o) & 1u) && adv > 0.0f) ? adv : 0.0f;
-                float z = pos;
-                z += __shfl_xor(z, 8); z += __shfl_xor(z, 4); z += __shfl_xor(z, 2); z += __shfl_xor(z, 1);
-                const float prob = pos / (z > 1e-8f ? z : 1e-8f);
+                    for (int k = 0; k < 4; k++) if (live && k < nl) hand_bits |= 1u << nib(s.hand[p], k);
+                    const float pos = (live && ((hand_bits >> o) & 1u) && adv > 0.0f) ? adv : 0.0f;
+                    float z = pos;
+                    z += __shfl_xor(z, 8); z += __shfl_xor(z, 4); z += __shfl_xor(z, 2); z += __shfl_xor(z, 1);
+                    const float prob = pos / (z > 1e-8f ? z : 1e-8f);
 #pragma unroll
-                for (int k = 0; k < 4; k++) if (live && k < nl && nib(s.hand[p], k) == o) ws.polcur[q][k] = prob;
+                    for (int k = 0; k < 4; k++) if (live && k < nl && nib(s.hand[p], k) == o) ws.polcur[q][k] = prob;
+                }
                 sd_sync();
                 // expand / sample: one lane per node of the group
-                if (lane < 4 && g0 + lane < width) {
+                if (lane < kG && g0 + lane < width) {
                     const int j = g0 + lane, idx = ws.idx[d][j];
                     float pk[4];
                     for (int k = 0; k < 4; k++) pk[k] = k < nl ? ws.polcur[lane][k] : 0.0f;
@@ -513,7 +538,11 @@ extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser,
     SC_REQUIRE(ctx, ((uintptr_t)d_weights & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: weights must be 16-byte aligned");
     if (!batch) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    const int waves = 10, threads = waves * 64;  // 110 KB of weights + 10 x 4.5 KB of wave scratch
+    // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 10, the kernel's launch bound)
+    int waves = (int)(((size_t)ctx->lds_limit - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
+    waves = waves > 10 ? 10 : waves;
+    SC_REQUIRE(ctx, waves >= 1, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
+    const int threads = waves * 64;
     const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
     static bool attr_set = false;
