@@ -340,6 +340,46 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
     for (int i = tid; i < 2 * kNetFloats / 4; i += blockDim.x)
         reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_weights)[i];
     __syncthreads();
+    // The three weight matrices are kept as k-QUADS, Wq[k/4][unit][k%4] (the buffer holds W^T[k][unit]), so that a lane fetches
+    // its unit's weights for four inputs with one 16-byte, conflict-free LDS read -- the A operand of four v_mfma_f32_4x4x1.
+    // In-place permutation through registers: W1 rows 0..31 (rows 32, 33 stay: constant-1 feature, unused feature), W2, W3.
+    {
+        constexpr int kQ1 = 8 * 128, kQ2 = 32 * 64, kQ3 = 16 * 16, kQ = kQ1 + kQ2 + kQ3;   // float4 quads per net
+        constexpr int kPer = (kQ + 511) / 512;                                            // per thread at >= 512 threads
+        float4 t[2][kPer];
+        auto src_of = [&](int net, int e) -> const float * {
+            const float *base = s_w + net * kNetFloats;
+            if (e < kQ1) return base + kW1 + (e >> 7) * 4 * 128 + (e & 127);
+            e -= kQ1;
+            if (e < kQ2) return base + kW2 + (e >> 6) * 4 * 64 + (e & 63);
+            e -= kQ2;
+            return base + kW3 + (e >> 4) * 4 * 16 + (e & 15);
+        };
+        auto stride_of = [&](int e) { return e < kQ1 ? 128 : e < kQ1 + kQ2 ? 64 : 16; };
+        auto dst_of = [&](int net, int e) -> float4 * {
+            float *base = s_w + net * kNetFloats;
+            if (e < kQ1) return reinterpret_cast<float4 *>(base + kW1) + e;
+            e -= kQ1;
+            if (e < kQ2) return reinterpret_cast<float4 *>(base + kW2) + e;
+            return reinterpret_cast<float4 *>(base + kW3) + (e - kQ2);
+        };
+#pragma unroll
+        for (int net = 0; net < 2; net++)
+#pragma unroll
+            for (int r = 0; r < kPer; r++) {
+                const int e = tid + r * (int)blockDim.x;
+                if (e < kQ) { const float *src = src_of(net, e); const int st = stride_of(e); t[net][r] = make_float4(src[0], src[st], src[2 * st], src[3 * st]); }
+            }
+        __syncthreads();
+#pragma unroll
+        for (int net = 0; net < 2; net++)
+#pragma unroll
+            for (int r = 0; r < kPer; r++) {
+                const int e = tid + r * (int)blockDim.x;
+                if (e < kQ) *dst_of(net, e) = t[net][r];
+            }
+        __syncthreads();
+    }
     SdWave &ws = s_wave[wave];
 
     for (int tb = blockIdx.x * n_waves + wave; tb < batch; tb += gridDim.x * n_waves) {
@@ -363,78 +403,113 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 sd_sync();
                 continue;
             }
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            static_assert(kG == 4, "the 4x4x1 mapping serves four nodes per group");
+            // The whole forward pass runs on the matrix cores with v_mfma_f32_4x4x1 (16 independent 4x4 outer products per
+            // instruction, K = 1): block b = lane / 4, A = four units' weights for input k (row i = lane % 4), B = input k of the four
+            // nodes in flight (node j = lane % 4), D[i] of lane (b, j) = unit 4b+i of node j.
+            const int bq = lane >> 2, nj = lane & 3;
+            // layer-1 accumulators start from bias + the constant-1 feature's column (feature 33 is 0.0), per 64-unit half
+            v4f bias1[2];
+#pragma unroll
+            for (int h = 0; h < 2; h++)
+#pragma unroll
+                for (int i = 0; i < 4; i++) bias1[h][i] = W[kB1 + 64 * h + 4 * bq + i] + W[kW1 + 32 * 128 + 64 * h + 4 * bq + i];
+            const float4 *w1q = reinterpret_cast<const float4 *>(W + kW1), *w2q = reinterpret_cast<const float4 *>(W + kW2) + lane;
+            const float4 *w3q = reinterpret_cast<const float4 *>(W + kW3);
             for (int g0 = 0; g0 < width; g0 += kG) {
-                // the group's packed states: one global load per node, then LDS broadcasts for every phase below
+                // the group's packed states: one global load per node, then every lane reads the state of ITS node (lane % 4)
                 if (lane < kG && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[d][g0 + lane]];
                 sd_sync();
-                // layer 1 (sparse): hidden units lane, lane + 64 for the group's nodes.  Static, predicated loops: all
-                // weight-column reads of a node are independent and can be in flight together.
-                float a0[kG], a1[kG];
+                const bool live = g0 + nj < width;
+                const scopa_state sj = ws.st[nj];
+                uint32_t hand_bits = 0, table_bits = 0;
+                if (live) {
 #pragma unroll
-                for (int q = 0; q < kG; q++) {
-                    const bool liveq = g0 + q < width;
-                    const scopa_state s = ws.st[q];
-                    const int nh = liveq ? s.nh[p] : 0, nt = liveq ? s.nt : 0;
-                    float x0 = W[kB1 + lane] + W[kW1 + 32 * 128 + lane];           // bias + feature 32 (1.0); feature 33 is 0.0
-                    float x1 = W[kB1 + 64 + lane] + W[kW1 + 32 * 128 + 64 + lane];
+                    for (int k = 0; k < 4; k++) if (k < sj.nh[p]) hand_bits |= 1u << nib(sj.hand[p], k);
 #pragma unroll
-                    for (int k = 0; k < 4; k++) {
-                        const int c = nib(s.hand[p], k) & 15;
-                        const float w0 = W[kW1 + c * 128 + lane], w1 = W[kW1 + c * 128 + 64 + lane];
-                        if (k < nh) { x0 += w0; x1 += w1; }
-                    }
-#pragma unroll
-                    for (int k = 0; k < 8; k++) {
-                        const int c = 16 + (nib(s.table, k) & 15);
-                        const float w0 = W[kW1 + c * 128 + lane], w1 = W[kW1 + c * 128 + 64 + lane];
-                        if (k < nt) { x0 += w0; x1 += w1; }
-                    }
-                    a0[q] = fmaxf(x0, 0.0f); a1[q] = fmaxf(x1, 0.0f);
+                    for (int k = 0; k < 8; k++) if (k < sj.nt) table_bits |= 1u << nib(sj.table, k);
                 }
+                const uint32_t xbits = hand_bits | (table_bits << 16);       // the 32 one-hot features of this lane's node
+                // layer 1: K = 32 dense 0/1 inputs (a zero input adds an exact zero), 128 units = two halves of 16 blocks
+                {
+                    v4f acc0 = bias1[0], acc1 = bias1[1];
 #pragma unroll
-                for (int q4 = 0; q4 < kG / 4; q4++) {
-                    reinterpret_cast<float4 *>(ws.h1[lane])[q4] = make_float4(a0[4 * q4], a0[4 * q4 + 1], a0[4 * q4 + 2], a0[4 * q4 + 3]);
-                    reinterpret_cast<float4 *>(ws.h1[lane + 64])[q4] = make_float4(a1[4 * q4], a1[4 * q4 + 1], a1[4 * q4 + 2], a1[4 * q4 + 3]);
+                    for (int kq = 0; kq < 8; kq++) {
+                        const float4 wa = w1q[kq * 128 + lane], wb = w1q[kq * 128 + 64 + lane];
+                        const float x0 = (float)((xbits >> (4 * kq)) & 1u), x1 = (float)((xbits >> (4 * kq + 1)) & 1u);
+                        const float x2 = (float)((xbits >> (4 * kq + 2)) & 1u), x3 = (float)((xbits >> (4 * kq + 3)) & 1u);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.x, x0, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.x, x0, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.y, x1, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.y, x1, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.z, x2, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.z, x2, acc1, 0, 0, 0);
+                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.w, x3, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.w, x3, acc1, 0, 0, 0);
+                    }
+                    // h1 as k-quads for layer 2: h1q[unit / 4][node][unit % 4] -- exactly this lane's accumulator vectors
+                    float4 *h1q = reinterpret_cast<float4 *>(&ws.h1[0][0]);
+                    h1q[bq * 4 + nj] = make_float4(fmaxf(acc0[0], 0.0f), fmaxf(acc0[1], 0.0f), fmaxf(acc0[2], 0.0f), fmaxf(acc0[3], 0.0f));
+                    h1q[(16 + bq) * 4 + nj] = make_float4(fmaxf(acc1[0], 0.0f), fmaxf(acc1[1], 0.0f), fmaxf(acc1[2], 0.0f), fmaxf(acc1[3], 0.0f));
                 }
                 sd_sync();
-                // layer 2: hidden unit `lane` for the group's nodes: per input one weight read + kG/4 float4 broadcasts + kG FMAs
-                float acc[kG];
-#pragma unroll
-                for (int q = 0; q < kG; q++) acc[q] = W[kB2 + lane];
+                // layer 2: K = 128, 64 units = 16 blocks.  Per four inputs: two 16-byte LDS reads and four MFMAs.
+                {
+                    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const float4 *hq = reinterpret_cast<const float4 *>(&ws.h1[0][0]) + nj;
 #pragma unroll 8
-                for (int i = 0; i < 128; i++) {
-                    const float w = W[kW2 + i * 64 + lane];
-#pragma unroll
-                    for (int q4 = 0; q4 < kG / 4; q4++) {
-                        const float4 h = reinterpret_cast<const float4 *>(ws.h1[i])[q4];
-                        acc[4 * q4] = fmaf(w, h.x, acc[4 * q4]); acc[4 * q4 + 1] = fmaf(w, h.y, acc[4 * q4 + 1]);
-                        acc[4 * q4 + 2] = fmaf(w, h.z, acc[4 * q4 + 2]); acc[4 * q4 + 3] = fmaf(w, h.w, acc[4 * q4 + 3]);
+                    for (int kq = 0; kq < 32; kq++) {
+                        const float4 w = w2q[kq * 64];
+                        const float4 h = hq[kq * 4];
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, h.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, h.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, h.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0);
                     }
+                    // h2 as k-quads for layer 3: h2q[unit / 4][node][unit % 4]
+                    reinterpret_cast<float4 *>(&ws.h2[0][0])[bq * 4 + nj] =
+                        make_float4(fmaxf(acc[0] + W[kB2 + 4 * bq], 0.0f), fmaxf(acc[1] + W[kB2 + 4 * bq + 1], 0.0f),
+                                    fmaxf(acc[2] + W[kB2 + 4 * bq + 2], 0.0f), fmaxf(acc[3] + W[kB2 + 4 * bq + 3], 0.0f));
                 }
-#pragma unroll
-                for (int q4 = 0; q4 < kG / 4; q4++)
-                    reinterpret_cast<float4 *>(ws.h2[lane])[q4] = make_float4(fmaxf(acc[4 * q4], 0.0f), fmaxf(acc[4 * q4 + 1], 0.0f),
-                                                                              fmaxf(acc[4 * q4 + 2], 0.0f), fmaxf(acc[4 * q4 + 3], 0.0f));
                 sd_sync();
-                // layer 3: lane = (node within a quartet) * 16 + output o, one pass per quartet of the group
+                // layer 3: K = 64, 16 outputs = 4 blocks; the other factor 4 of the 16 blocks splits K (block = ks * 4 + ob), the four
+                // partial sums are added across lanes afterwards
+                {
+                    const int ks = bq >> 2, ob = bq & 3;
+                    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    const float4 *hq = reinterpret_cast<const float4 *>(&ws.h2[0][0]);
 #pragma unroll
-                for (int q4 = 0; q4 < kG / 4; q4++) {
-                    const int q = 4 * q4 + (lane >> 4), o = lane & 15;
-                    float adv = W[kB3 + o];
-#pragma unroll 8
-                    for (int i = 0; i < 64; i++) adv = fmaf(W[kW3 + i * 16 + o], ws.h2[i][q], adv);
-                    // positive_regret_policy over the node's 16 outputs (nets.py:93-101)
-                    const bool live = g0 + q < width;
-                    const scopa_state s = ws.st[q];
-                    uint32_t hand_bits = 0;
+                    for (int t = 0; t < 4; t++) {
+                        const int kq = ks * 4 + t;
+                        const float4 w = w3q[kq * 16 + 4 * ob + nj];          // A role: output 4*ob + (lane % 4)
+                        const float4 h = hq[kq * 4 + nj];                      // B role: node lane % 4
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, h.x, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, h.y, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, h.z, acc, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0);
+                    }
+                    float adv[4], pos[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (live && k < nl) hand_bits |= 1u << nib(s.hand[p], k);
-                    const float pos = (live && ((hand_bits >> o) & 1u) && adv > 0.0f) ? adv : 0.0f;
-                    float z = pos;
-                    z += __shfl_xor(z, 8); z += __shfl_xor(z, 4); z += __shfl_xor(z, 2); z += __shfl_xor(z, 1);
-                    const float prob = pos / (z > 1e-8f ? z : 1e-8f);
+                    for (int i = 0; i < 4; i++) {
+                        float v = acc[i];
+                        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);        // the four K-splits
+                        adv[i] = v + W[kB3 + 4 * ob + i];
+                    }
+                    // positive_regret_policy over the node's 16 outputs (nets.py:93-101): this lane holds outputs 4*ob .. 4*ob+3 of node nj
+                    float z = 0.0f;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (live && k < nl && nib(s.hand[p], k) == o) ws.polcur[q][k] = prob;
+                    for (int i = 0; i < 4; i++) { pos[i] = (((hand_bits >> (4 * ob + i)) & 1u) && adv[i] > 0.0f) ? adv[i] : 0.0f; z += pos[i]; }
+                    z += __shfl_xor(z, 4); z += __shfl_xor(z, 8);              // the four output groups
+                    const float den = z > 1e-8f ? z : 1e-8f;
+                    if (ks == 0 && live) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) {
+                            const int c = nib(sj.hand[p], k);
+                            if (k < nl && (c >> 2) == ob) {
+                                float pv = pos[0];
+#pragma unroll
+                                for (int i = 1; i < 4; i++) pv = (c & 3) == i ? pos[i] : pv;
+                                ws.polcur[nj][k] = pv / den;
+                            }
+                        }
+                    }
                 }
                 sd_sync();
                 // expand / sample: one lane per node of the group
@@ -541,7 +616,7 @@ extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser,
     // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 10, the kernel's launch bound)
     int waves = (int)(((size_t)ctx->lds_limit - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
     waves = waves > 10 ? 10 : waves;
-    SC_REQUIRE(ctx, waves >= 1, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
+    SC_REQUIRE(ctx, waves >= 8, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (the weight staging assumes >= 512 threads)");
     const int threads = waves * 64;
     const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
