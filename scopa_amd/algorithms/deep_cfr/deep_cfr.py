@@ -234,8 +234,6 @@ class DeepCFR:
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}
         self._iteration = 0
         self._eval_calls = 0
-        # None = automatic: the one-launch kernel wins while the ply-by-ply path is launch-bound (measured crossover ~8k
-        # traversals per batch on MI355X: beyond it rocBLAS GEMMs beat the LDS-bound in-kernel MLP)
         # the one-launch traversal kernel (forward pass on the matrix cores) is the faster path at every batch size measured
         # (9.2e8 visits/s at B=4096, 1.55e9 at B=32768 against 3.2e8 / 9e8 for the ply-by-ply path); the latter stays selectable
         self.fused_traversal = True if fused_traversal is None else bool(fused_traversal)
