@@ -119,3 +119,18 @@ def test_lane_per_deal_exact_cfr_is_bit_identical(ctx, sl, oracle, golden):
         Rg, Sg, Lg, _ = a.tables_get(i)
         assert np.array_equal(Rg, R) and np.array_equal(Sg, S) and np.array_equal(Lg, L), seeds[i]
     a.close(); b.close()
+
+
+def test_lane_per_deal_cfr_refuses_tables_another_solver_left_inconsistent(ctx, sl):
+    """The lane-per-deal kernel relies on local_strategy == regret_matching(regret_sum) (true for every table the reference's
+    own CFR produces); synchronous CFR moves regret_sum without touching local_strategy, so packing must refuse -- loudly, and
+    leave the tables usable by the workgroup-per-deal kernel."""
+    m = sl.MultiDeal(ctx, 8)
+    m.deal_py_seeds(list(range(8)))
+    m.build()
+    m.cfr_exact_iterate_lanes(1)            # fine on fresh tables
+    m.cfr_sync_iterate(3)                   # regret_sum changes, local_strategy does not
+    with pytest.raises(sl.ScopaError):
+        m.cfr_exact_iterate_lanes(1)
+    m.cfr_exact_iterate(1)                  # the literal kernel still runs on them
+    m.close()
