@@ -4,9 +4,9 @@
 // refreshes node.local_strategy at the end of EVERY node visit (:97) and 302 of the 738 infosets are visited more
 // than once per traversal, so its tables are a function of DFS visit order: the exact path is inherently one
 // sequential walk per solve ("replicas only" -- independent solves go to independent workgroups / GPUs).
-// The walk runs on one lane with the three tables, the node->infoset map, the payoffs and the DFS frames all in
-// LDS (~75 KB for 738 infosets), so a visit costs LDS latencies rather than HBM round trips; the other lanes of
-// the workgroup stage tables in and out.  float64 arithmetic follows numpy operation by operation (no FMA
+// The walk runs on one lane as a compile-time recursion over the 8 plies (frames in registers) with the three tables,
+// the node->infoset map, the payoffs and the first-visit flags in LDS (~80 KB for 738 infosets), so a visit costs a
+// few LDS latencies rather than HBM round trips; the other lanes of the workgroup stage tables in and out.  float64 arithmetic follows numpy operation by operation (no FMA
 // contraction: built with -ffp-contract=off), which is what makes the result bit-identical to the reference.
 #include "scopa_ctx.h"
 
@@ -14,18 +14,75 @@ using namespace scopa;
 
 namespace {
 
-struct CfrFrame {
-    int idx, I, i;
-    double au[4], r0, r1;
+// InfoNode.get_strategy, vanilla_cfr.py:23-30
+template <int N>
+__device__ __forceinline__ void regret_match(const double *R, double *out) {
+    double pos[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = 0; i < N; i++) pos[i] = R[i] > 0.0 ? R[i] : 0.0;
+    double s = pos[0];
+    for (int i = 1; i < N; i++) s += pos[i];  // np.sum, n < 8: left-to-right
+    for (int i = 0; i < N; i++) out[i] = s > 0.0 ? pos[i] / s : 1.0 / (double)N;
+}
+
+struct ExactWalk {
+    double *R, *S, *L;          // tables (LDS when they fit, else HBM)
+    const uint16_t *inf;        // node -> infoset (LDS)
+    const int8_t *pay;          // leaf payoffs x2 (LDS)
+    uint32_t *visit;            // first-visit sequence numbers (LDS)
+    uint32_t seq;
+    unsigned long long dvis, tvis;
 };
 
-// InfoNode.get_strategy, vanilla_cfr.py:23-30
-__device__ __forceinline__ void regret_match(const double *R, int n, double *out) {
-    double pos[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < n; i++) pos[i] = R[i] > 0.0 ? R[i] : 0.0;
-    double s = pos[0];
-    for (int i = 1; i < n; i++) s += pos[i];  // np.sum, n < 8: left-to-right
-    for (int i = 0; i < n; i++) out[i] = s > 0.0 ? pos[i] / s : 1.0 / (double)n;
+// CFRTrainer._cfr_recursive (vanilla_cfr.py:56-99) as a compile-time recursion over the 8 plies: the frames (action
+// utilities, reaches, the node's strategy row) live in registers, only table rows and the two maps are memory operations.
+// The strategy row is read once on entry: local_strategy of an infoset cannot change before this visit ends, because all
+// of its other nodes are on the same ply.
+template <int D, int TRAV>
+__device__ __forceinline__ double exact_rec(ExactWalk &w, int idx, double r0, double r1) {
+    if constexpr (D == kPlies) {  // terminal (:58-59)
+        w.tvis++;
+        const int p0 = w.pay[idx];
+        return 0.5 * (double)(TRAV == 0 ? p0 : -p0);
+    } else {
+        constexpr int n = 4 - (D >> 1), p = D & 1;
+        w.dvis++;
+        const int I = w.inf[level_offset(D) + idx];
+        if (w.visit[I] == 0u) w.visit[I] = ++w.seq;  // dict insertion on first visit (:51-54)
+        double *Lr = w.L + I * 4;
+        double ls[4], au[4];
+        for (int i = 0; i < n; i++) ls[i] = Lr[i];
+#pragma unroll 1
+        for (int i = 0; i < n; i++)  // recurse into legal action i (:79-85)
+            au[i] = exact_rec<D + 1, TRAV>(w, idx * n + i, p == 0 ? r0 * ls[i] : r0, p == 1 ? r1 * ls[i] : r1);
+        double v = ls[0] * au[0];  // np.sum(local_strategy * action_utils) (:87)
+        for (int i = 1; i < n; i++) v += ls[i] * au[i];
+        double *Rr = w.R + I * 4;
+        if constexpr (p == TRAV) {  // (:89-95)
+            const double reach = TRAV == 0 ? r0 : r1, opp = TRAV == 0 ? r1 : r0;
+            double *Sr = w.S + I * 4;
+            for (int i = 0; i < n; i++) {
+                Rr[i] += opp * (au[i] - v);
+                Sr[i] += reach * ls[i];
+            }
+        }
+        regret_match<n>(Rr, Lr);  // local_strategy refresh on EVERY visit (:97)
+        return v;
+    }
+}
+
+template <int TRAV>
+__device__ double exact_from(ExactWalk &w, int depth, int idx, double r0, double r1) {
+    switch (depth) {
+        case 0: return exact_rec<0, TRAV>(w, idx, r0, r1);
+        case 1: return exact_rec<1, TRAV>(w, idx, r0, r1);
+        case 2: return exact_rec<2, TRAV>(w, idx, r0, r1);
+        case 3: return exact_rec<3, TRAV>(w, idx, r0, r1);
+        case 4: return exact_rec<4, TRAV>(w, idx, r0, r1);
+        case 5: return exact_rec<5, TRAV>(w, idx, r0, r1);
+        case 6: return exact_rec<6, TRAV>(w, idx, r0, r1);
+        case 7: return exact_rec<7, TRAV>(w, idx, r0, r1);
+        default: return exact_rec<8, TRAV>(w, idx, r0, r1);  // a terminal state was passed in
+    }
 }
 
 }  // namespace
@@ -39,7 +96,7 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ uint16_t s_inf[1656];
     __shared__ int8_t s_pay[kTerminal];
-    __shared__ CfrFrame fr[kPlies + 1];
+    __shared__ uint32_t s_visit[kDecision];
     if (n_infosets <= 0) {  // multi-deal mode: one workgroup per deal, shapes from the deal's meta block
         const size_t deal = blockIdx.x;
         g_infoset += deal * kDecision; g_payoff += deal * kTerminal;
@@ -58,73 +115,26 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
     }
     for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
+    for (int i = tid; i < n_infosets; i += blockDim.x) s_visit[i] = g_visit[i];
     __syncthreads();
 
     if (tid == 0) {
-        unsigned long long dvis = 0, tvis = 0;
-        uint32_t seq = (uint32_t)g_meta[1];
+        ExactWalk w;
+        w.R = R; w.S = S; w.L = L; w.inf = s_inf; w.pay = s_pay; w.visit = s_visit;
+        w.seq = (uint32_t)g_meta[1]; w.dvis = 0; w.tvis = 0;
+#pragma unroll 1
         for (int t = 0; t < n_traversals; t++) {
             const int trav = (first_traverser + t) & 1;  // train(): for i in range(num_players) (:108-110)
-            int d = start_depth;
-            fr[d].idx = start_idx; fr[d].i = -1; fr[d].r0 = start_r0; fr[d].r1 = start_r1;
-            double ret = 0.0;
-            if (d == kPlies) {  // a terminal state was passed in (:58-59)
-                const int p0 = s_pay[start_idx];
-                ret = 0.5 * (double)(trav == 0 ? p0 : -p0);
-                tvis++;
-                d = start_depth - 1;
-            }
-            while (d >= start_depth) {
-                if (d == kPlies) {  // terminal (:58-59)
-                    const int p0 = s_pay[fr[d].idx];
-                    ret = 0.5 * (double)(trav == 0 ? p0 : -p0);
-                    tvis++;
-                    d--;
-                    fr[d].au[fr[d].i] = ret;  // d >= start_depth here: a terminal start never enters the loop
-                    continue;
-                }
-                CfrFrame &f = fr[d];
-                const int n = 4 - (d >> 1), p = d & 1;
-                if (f.i < 0) {  // node entry (:73-77)
-                    dvis++;
-                    f.I = s_inf[level_offset(d) + f.idx];
-                    f.i = 0;
-                    if (g_visit[f.I] == 0u) g_visit[f.I] = ++seq;  // dict insertion on first visit (:51-54)
-                } else {
-                    f.i++;  // child f.i returned into au[f.i]
-                }
-                double *ls = L + f.I * 4;
-                if (f.i < n) {  // recurse into legal action i with the CURRENT local_strategy[i] (:79-85)
-                    CfrFrame &c = fr[d + 1];
-                    c.idx = f.idx * n + f.i;
-                    c.i = -1;
-                    c.r0 = p == 0 ? f.r0 * ls[f.i] : f.r0;
-                    c.r1 = p == 1 ? f.r1 * ls[f.i] : f.r1;
-                    d++;
-                    continue;
-                }
-                double v = ls[0] * f.au[0];  // np.sum(local_strategy * action_utils) (:87)
-                for (int i = 1; i < n; i++) v += ls[i] * f.au[i];
-                if (p == trav) {  // (:89-95)
-                    const double reach = trav == 0 ? f.r0 : f.r1, opp = trav == 0 ? f.r1 : f.r0;
-                    for (int i = 0; i < n; i++) {
-                        const double regret = f.au[i] - v;
-                        R[f.I * 4 + i] += opp * regret;
-                        S[f.I * 4 + i] += reach * ls[i];
-                    }
-                }
-                regret_match(R + f.I * 4, n, ls);  // local_strategy refresh on EVERY visit (:97)
-                ret = v;
-                d--;
-                if (d >= start_depth) fr[d].au[fr[d].i] = ret;
-            }
+            const double ret = trav == 0 ? exact_from<0>(w, start_depth, start_idx, start_r0, start_r1)
+                                         : exact_from<1>(w, start_depth, start_idx, start_r0, start_r1);
             if (root_values) root_values[t] = ret;
         }
-        g_counters[0] += dvis;
-        g_counters[1] += tvis;
-        g_meta[1] = (int32_t)seq;
+        g_counters[0] += w.dvis;
+        g_counters[1] += w.tvis;
+        g_meta[1] = (int32_t)w.seq;
     }
     __syncthreads();
+    for (int i = tid; i < n_infosets; i += blockDim.x) g_visit[i] = s_visit[i];
     if (use_lds)
         for (int i = tid; i < cells; i += blockDim.x) { g_regret[i] = R[i]; g_strat[i] = S[i]; g_local[i] = L[i]; }
 }
@@ -134,7 +144,7 @@ static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, 
     SC_HIP(ctx, hipSetDevice(ctx->device));
     { const int32_t rc = ensure_scratch(ctx, (size_t)(n_traversals > 0 ? n_traversals : 1) * sizeof(double)); if (rc != SCOPA_OK) return rc; }
     const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 3;
-    const size_t static_lds = 1656 * 2 + kTerminal + sizeof(CfrFrame) * (kPlies + 1) + 256;
+    const size_t static_lds = 1656 * 2 + kTerminal + sizeof(uint32_t) * kDecision + 256;
     const int use_lds = lds + static_lds <= (size_t)ctx->lds_limit ? 1 : 0;
     static bool attr_set = false;
     if (!attr_set) {

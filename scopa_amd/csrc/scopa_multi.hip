@@ -357,7 +357,7 @@ int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters) {
     if (!n_iters) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = (size_t)m->max_infosets * 4 * 8 * 3;
-    const size_t static_lds = 1656 * 2 + kTerminal + 9 * 80 + 256;
+    const size_t static_lds = 1656 * 2 + kTerminal + sizeof(uint32_t) * kDecision + 256;   // k_cfr_exact: maps + first-visit flags
     const int use_lds = lds + static_lds <= (size_t)ctx->lds_limit ? 1 : 0;
     SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cfr_exact), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     ctx->lds_limit - (int)static_lds));
