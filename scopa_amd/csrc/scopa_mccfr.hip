@@ -655,95 +655,99 @@ k_mccfr_apply(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret,
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Replay mode: the reference's own sequential semantics (tables are live: every update is seen by the next visit),
-// driven by the uniforms np.random.choice would have drawn.  One lane; this is the bit-exactness anchor, not the
-// throughput path.
+// driven by the uniforms np.random.choice would have drawn.  One lane walks, the others stage the tables in and out of
+// LDS; this is the bit-exactness anchor, not the throughput path.
 namespace {
-struct ReplayFrame {
-    int idx, I, phase, a_first;
-    double sigma[4], cfv[4], reach_opp, samp_trav, util;
+struct ReplayWalk {
+    double *R, *S;              // live tables (LDS)
+    const uint16_t *inf;        // node -> infoset (LDS)
+    const int8_t *pay;          // leaf payoffs x2 (LDS)
+    uint32_t *visit;            // first-visit sequence numbers (LDS)
+    const double *uniforms;     // what np.random.choice would have drawn, in DFS entry order (HBM, read sequentially)
+    long long upos, n_uniforms;
+    uint32_t seq;
+    unsigned long long dvis, tvis;
 };
+
+// MCCFRTrainer._sample (mc_cfr.py:37-86) as a compile-time recursion over the 8 plies: frames in registers, tables and
+// maps in LDS.  sigma is computed once on entry from the live regret row -- the row cannot change before this visit ends
+// (its other nodes are on the same ply) -- and used for the sampling, the child reaches and the update.
+template <int D, int TRAV>
+__device__ __forceinline__ double replay_rec(ReplayWalk &w, int idx, double reach_opp, double samp_trav) {
+    if constexpr (D == kPlies) {  // terminal: state.rewards()[traversing_player] (:38-39)
+        w.tvis++;
+        const int p0 = w.pay[idx];
+        return 0.5 * (double)(TRAV == 0 ? p0 : -p0);
+    } else {
+        constexpr int n = 4 - (D >> 1);
+        constexpr bool is_trav = (D & 1) == TRAV;
+        w.dvis++;  // node entry (:49-55)
+        const int I = w.inf[level_offset(D) + idx];
+        if (w.visit[I] == 0u) w.visit[I] = ++w.seq;  // _get_node inserts on first visit (:32-35)
+        double R[4], sigma[4], cdf[4];
+        for (int c = 0; c < 4; c++) R[c] = w.R[I * 4 + c];
+        mc_sigma(R, n, sigma);
+        choice_cdf_f64(sigma, n, cdf);
+        const double u = w.upos < w.n_uniforms ? w.uniforms[w.upos] : 0.0;
+        w.upos++;
+        int a = (cdf[0] <= u) + (cdf[1] <= u) + (cdf[2] <= u) + (cdf[3] <= u);
+        a = a < n - 1 ? a : n - 1;
+        double sa = sigma[0];
+        for (int i = 1; i < n; i++) sa = a == i ? sigma[i] : sa;
+        if constexpr (!is_trav) {  // opponent node: pass the sampled child's value up (:86)
+            return replay_rec<D + 1, TRAV>(w, idx * n + a, reach_opp * sa, samp_trav);
+        } else {
+            const double util = replay_rec<D + 1, TRAV>(w, idx * n + a, reach_opp, samp_trav * sa);
+            double cfv[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+            for (int i = 0; i < n; i++)  // re-expand every legal action (:72-78)
+                cfv[i] = replay_rec<D + 1, TRAV>(w, idx * n + i, reach_opp, samp_trav * sigma[i]);
+            double v = 0.0;  // (:79-84)
+            for (int i = 0; i < n; i++) v = fma(sigma[i], cfv[i], v);
+            const double wt = samp_trav > 0.0 ? reach_opp / samp_trav : 0.0;
+            for (int i = 0; i < n; i++) {
+                w.R[I * 4 + i] += wt * (cfv[i] - v);
+                w.S[I * 4 + i] += 1.0 * sigma[i];  // reach_probs[traverser] stays 1.0 (:61-65)
+            }
+            return util;
+        }
+    }
+}
 }  // namespace
 
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(256)
 k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
                double *__restrict__ g_regret, double *__restrict__ g_strat, const double *__restrict__ uniforms,
                long long n_uniforms, int n_iters, unsigned long long *__restrict__ g_counters, long long *__restrict__ consumed,
                uint32_t *__restrict__ g_visit, int32_t *__restrict__ g_meta) {
-    __shared__ ReplayFrame fr[kPlies + 1];
-    if (threadIdx.x != 0 || blockIdx.x != 0) return;
-    long long upos = 0;
-    unsigned long long dvis = 0, tvis = 0;
-    uint32_t seq = (uint32_t)g_meta[1];
-    for (int it = 0; it < n_iters; it++) {
-        for (int trav = 0; trav < 2; trav++) {  // iteration(), mc_cfr.py:88-92
-            int d = 0;
-            fr[0].idx = 0; fr[0].phase = -1; fr[0].reach_opp = 1.0; fr[0].samp_trav = 1.0;
-            double ret = 0.0;
-            bool returning = false;
-            while (d >= 0) {
-                if (d == kPlies) {  // terminal: state.rewards()[traversing_player] (:38-39)
-                    const int p0 = g_payoff[fr[d].idx];
-                    ret = 0.5 * (double)(trav == 0 ? p0 : -p0);
-                    tvis++;
-                    returning = true;
-                    d--;
-                    continue;
-                }
-                ReplayFrame &f = fr[d];
-                const int n = 4 - (d >> 1);
-                const bool is_trav = (d & 1) == trav;
-                if (!returning) {  // node entry (:49-55)
-                    dvis++;
-                    f.I = g_infoset[level_offset(d) + f.idx];
-                    if (g_visit[f.I] == 0u) g_visit[f.I] = ++seq;  // _get_node inserts on first visit (mc_cfr.py:32-35)
-                    double R[4];
-                    for (int c = 0; c < 4; c++) R[c] = g_regret[f.I * 4 + c];
-                    mc_sigma(R, n, f.sigma);
-                    double cdf[4];
-                    choice_cdf_f64(f.sigma, n, cdf);
-                    const double u = upos < n_uniforms ? uniforms[upos] : 0.0;
-                    upos++;
-                    int a = (cdf[0] <= u) + (cdf[1] <= u) + (cdf[2] <= u) + (cdf[3] <= u);
-                    a = a < n - 1 ? a : n - 1;
-                    f.a_first = a;
-                    f.phase = 0;
-                    ReplayFrame &c = fr[d + 1];
-                    c.idx = f.idx * n + a;
-                    if (is_trav) { c.reach_opp = f.reach_opp; c.samp_trav = f.samp_trav * f.sigma[a]; }
-                    else         { c.reach_opp = f.reach_opp * f.sigma[a]; c.samp_trav = f.samp_trav; }
-                    d++;
-                    continue;
-                }
-                // a child returned `ret`
-                if (!is_trav) { d--; continue; }  // opponent node: pass the sampled child's value up (:86)
-                if (f.phase == 0) f.util = ret; else f.cfv[f.phase - 1] = ret;
-                if (f.phase < n) {  // re-expand legal action number f.phase (:72-78)
-                    const int i = f.phase;
-                    f.phase++;
-                    ReplayFrame &c = fr[d + 1];
-                    c.idx = f.idx * n + i;
-                    c.reach_opp = f.reach_opp;
-                    c.samp_trav = f.samp_trav * f.sigma[i];
-                    returning = false;
-                    d++;
-                    continue;
-                }
-                double v = 0.0;  // (:79-84)
-                for (int i = 0; i < n; i++) v = fma(f.sigma[i], f.cfv[i], v);
-                const double w = f.samp_trav > 0.0 ? f.reach_opp / f.samp_trav : 0.0;
-                for (int i = 0; i < n; i++) {
-                    g_regret[f.I * 4 + i] += w * (f.cfv[i] - v);
-                    g_strat[f.I * 4 + i] += 1.0 * f.sigma[i];  // reach_probs[traverser] stays 1.0 (:61-65)
-                }
-                ret = f.util;
-                d--;
-            }
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ uint16_t s_inf[1656];
+    __shared__ int8_t s_pay[kTerminal];
+    __shared__ uint32_t s_visit[kDecision];
+    const int tid = threadIdx.x, I = g_meta[0], cells = I * 4;
+    double *R = reinterpret_cast<double *>(smem), *S = R + cells;
+    for (int i = tid; i < cells; i += blockDim.x) { R[i] = g_regret[i]; S[i] = g_strat[i]; }
+    for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
+    for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
+    for (int i = tid; i < I; i += blockDim.x) s_visit[i] = g_visit[i];
+    __syncthreads();
+    if (tid == 0) {
+        ReplayWalk w;
+        w.R = R; w.S = S; w.inf = s_inf; w.pay = s_pay; w.visit = s_visit; w.uniforms = uniforms; w.upos = 0; w.n_uniforms = n_uniforms;
+        w.seq = (uint32_t)g_meta[1]; w.dvis = 0; w.tvis = 0;
+#pragma unroll 1
+        for (int it = 0; it < n_iters; it++) {  // iteration(), mc_cfr.py:88-92
+            replay_rec<0, 0>(w, 0, 1.0, 1.0);
+            replay_rec<0, 1>(w, 0, 1.0, 1.0);
         }
+        g_counters[0] += w.dvis;
+        g_counters[1] += w.tvis;
+        g_meta[1] = (int32_t)w.seq;
+        *consumed = w.upos;
     }
-    g_counters[0] += dvis;
-    g_counters[1] += tvis;
-    g_meta[1] = (int32_t)seq;
-    *consumed = upos;
+    __syncthreads();
+    for (int i = tid; i < cells; i += blockDim.x) { g_regret[i] = R[i]; g_strat[i] = S[i]; }
+    for (int i = tid; i < I; i += blockDim.x) g_visit[i] = s_visit[i];
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -947,7 +951,14 @@ int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_unif
     long long *d_consumed = reinterpret_cast<long long *>(ctx->d_scratch);
     double *d_u = ctx->d_scratch + 8;
     if (n_uniforms) SC_HIP(ctx, hipMemcpyAsync(d_u, h_uniforms, ubytes, hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_mccfr_replay, dim3(1), dim3(64), 0, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key,
+    {
+        static bool attr_set = false;
+        if (!attr_set) {
+            SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_replay), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 12 * 1024));
+            attr_set = true;
+        }
+    }
+    hipLaunchKernelGGL(k_mccfr_replay, dim3(1), dim3(256), (size_t)ctx->n_infosets * 64, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key,
                        ctx->d_regret, ctx->d_strat, d_u, (long long)n_uniforms, (int)n_iters, ctx->d_counters, d_consumed,
                        ctx->d_visit, ctx->d_meta);
     SC_HIP(ctx, hipGetLastError());
