@@ -223,6 +223,7 @@ int32_t scopa_multi_deal_py_seeds(scopa_multi *m, const int64_t *h_seeds);
 int32_t scopa_multi_set_perms(scopa_multi *m, const uint8_t *h_perms /*[n][16]*/);
 int32_t scopa_multi_perms_get(scopa_multi *m, uint8_t *h_perms);
 int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets);
+/* one workgroup per deal; from 8192 deals on it takes the lane form below (same bits) when that form's precondition holds */
 int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters);
 /* the same exact solve with one LANE per deal (64 deals share an instruction stream: the tree shape is deal-independent),
  * tables gathered from HBM: the throughput form for thousands of deals; bit-identical results */

@@ -349,12 +349,22 @@ int32_t scopa_multi_build(scopa_multi *m, int32_t *h_n_infosets) {
     return SCOPA_OK;
 }
 
+int32_t scopa_multi_cfr_exact_iterate_lanes(scopa_multi *m, int32_t n_iters);
+
 int32_t scopa_multi_cfr_exact_iterate(scopa_multi *m, int32_t n_iters) {
     if (!m || n_iters < 0 || n_iters > (1 << 20)) return SCOPA_EINVAL;
     scopa_ctx *ctx = m->ctx;
     SC_REQUIRE(ctx, m->built, SCOPA_ESTATE, "scopa_multi_cfr_exact_iterate: call scopa_multi_build first");
-    if (int32_t rc = rows_convert(m, false)) return rc;
     if (!n_iters) return SCOPA_OK;
+    // Both kernels produce the same bits.  One workgroup per deal costs ~0.86 ms per iteration and round of ~512 resident
+    // workgroups; one lane per deal is bound by memory latency below a few thousand deals and by HBM beyond (4e10 visits/s):
+    // from 8192 deals on the lane form is taken, unless its precondition or its extra row image is not available.
+    if (m->n >= 8192) {
+        const int32_t rc = scopa_multi_cfr_exact_iterate_lanes(m, n_iters);
+        if (rc == SCOPA_OK) return SCOPA_OK;
+        if (rc != SCOPA_ESTATE && rc != SCOPA_ENOMEM) return rc;
+    }
+    if (int32_t rc = rows_convert(m, false)) return rc;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = (size_t)m->max_infosets * 4 * 8 * 3;
     const size_t static_lds = 1656 * 2 + kTerminal + sizeof(uint32_t) * kDecision + 256;   // k_cfr_exact: maps + first-visit flags

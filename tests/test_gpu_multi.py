@@ -134,3 +134,19 @@ def test_lane_per_deal_cfr_refuses_tables_another_solver_left_inconsistent(ctx, 
         m.cfr_exact_iterate_lanes(1)
     m.cfr_exact_iterate(1)                  # the literal kernel still runs on them
     m.close()
+
+
+def test_exact_cfr_on_many_deals_takes_the_lane_form_with_identical_results(ctx, sl, oracle):
+    """scopa_multi_cfr_exact_iterate switches to one lane per deal from 8192 deals on; same bits as the oracle either way."""
+    n = 8192
+    m = sl.MultiDeal(ctx, n)
+    m.deal_py_seeds(np.arange(n))
+    m.build()
+    m.cfr_exact_iterate(2)
+    m.cfr_exact_iterate(1)
+    assert m.counters() == (3306 * 3 * n, 1152 * 3 * n)
+    for i in (0, 4097, 8191):
+        t = oracle.Tree(seed=i); R, S, L = t.tables(); t.cfr_exact(R, S, L, 3)
+        Rg, Sg, Lg, _ = m.tables_get(i)
+        assert np.array_equal(Rg, R) and np.array_equal(Sg, S) and np.array_equal(Lg, L), i
+    m.close()
