@@ -166,7 +166,9 @@ def main():
     if use_dist:
         if ctx.exchange == "p2p":
             timeouts, exchanges = ctx.p2p_status()
-            assert timeouts == 0, f"peer exchange: {timeouts} wait(s) timed out -- the run is invalid"
+            tt = torch.tensor([timeouts], dtype=torch.int32, device=f"cuda:{local_rank}")
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # every rank learns it, so every rank stops (none is left in a collective)
+            assert int(tt.item()) == 0, f"peer exchange: wait(s) timed out on some rank (here: {timeouts}) -- the run is invalid"
         R, S, _ = ctx.tables_get()
         h = hashlib.sha256(R.tobytes() + S.tobytes()).digest()[:8]
         mine = torch.tensor(list(h), dtype=torch.uint8, device=f"cuda:{local_rank}")
