@@ -91,6 +91,7 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
     args = ap.parse_args()
 
+    import numpy as np
     import torch
     import torch.distributed as dist
     from scopa_amd import _lib
@@ -135,6 +136,24 @@ def main():
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    # N > 1: before anything is timed, prove the sharded pipeline on THIS topology -- 10 iterations over `world` ranks must give
+    # the tables of the same 10 iterations (same global traversal ids) on one GPU, up to the summation order of the rank deltas
+    sharded_check = None
+    if use_dist:
+        run(10)
+        fence()
+        Rn, Sn, _ = ctx.tables_get()
+        if rank == 0:
+            ref = _lib.Context(local_rank)
+            ref.set_deal(perm)
+            ref.mccfr_seed(0x5C09A)
+            ref.mccfr_iterate(batch_total, 10)
+            R1, S1, _ = ref.tables_get()
+            ref.close()
+            sharded_check = bool(np.allclose(Rn, R1, rtol=1e-10, atol=1e-10) and np.allclose(Sn, S1, rtol=1e-10, atol=1e-10))
+        ctx.tables_reset()
+        fence()
 
     run(args.warmup)
     fence()
@@ -196,7 +215,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": batch_total, "iterations": args.steps,
                        "parallelism": f"dp{world}" + ((" + 1 all-reduce of 29520 B per iteration (" + {"p2p": "one-shot peer-memory exchange over xGMI, rank-ordered sum", "rccl": "RCCL via torch.distributed"}.get(ctx.exchange, ctx.exchange) + ")") if use_dist else ""),
                        "exchange": ctx.exchange if use_dist else None, "exchange_note": ctx.exchange_note if use_dist else None,
-                       "replicas_bit_identical": replicas_identical,
+                       "replicas_bit_identical": replicas_identical, "sharded_10_iterations_match_one_gpu": sharded_check,
                        "rng": "Philox4x32-10 keyed by (seed, path code, global traversal id, iteration, traverser)"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
