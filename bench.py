@@ -84,7 +84,7 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
-    ap.add_argument("--prof-stride", type=int, default=8, help="bracket every n-th traversal launch with HIP events")
+    ap.add_argument("--prof-stride", type=int, default=32, help="bracket every n-th traversal launch with HIP events")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["auto", "p2p", "rccl"], default="auto",
                     help="N>1 delta all-reduce: library one-shot peer-memory exchange (validated against RCCL first), or torch.distributed/RCCL")
