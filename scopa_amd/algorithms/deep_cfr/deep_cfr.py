@@ -69,7 +69,10 @@ class AdvantageNetwork:
             if isinstance(layer, nn.Linear):
                 nn.init.xavier_uniform_(layer.weight)
                 nn.init.constant_(layer.bias, 0.1)
-        self.optimizer = optim.Adam(self.net.parameters(), lr=lr, capturable=bool(use_graph))
+        # graph mode: the single-kernel ("fused") Adam of PyTorch-ROCm -- the same update rule in one launch instead of ~15 foreach
+        # kernels per step; eager mode keeps the reference's default implementation
+        self.optimizer = (optim.Adam(self.net.parameters(), lr=lr, capturable=True, fused=True) if use_graph and str(device).startswith("cuda")
+                          else optim.Adam(self.net.parameters(), lr=lr, capturable=bool(use_graph)))
         self.criterion = nn.MSELoss()
         self.buffer = DeviceMemory(memory_size, input_dim, device)
         self._rng = random.Random()
