@@ -295,11 +295,15 @@ int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const 
 // Fused traversal: ONE launch per traversal batch instead of ~65 (8 plies x {features, 3 GEMMs + activations, expand} +
 // 8 backward steps).  One WAVEFRONT walks one traversal level-synchronously; both players' advantage MLPs
 // (34-128-64-16, float32, 13 776 parameters = 55 KB each) sit in LDS for the whole launch and the forward pass of the
-// <= 24 frontier nodes of a ply runs inside the wave, kG = 4 nodes at a time:
-//   layer 1  sparse: the input is one-hot/multi-hot (<= 4 hand cards, <= 8 table cards, one constant), so a hidden unit is
-//            b1 + a handful of weight columns -- no multiplies;  each lane owns hidden units lane and lane+64
-//   layer 2  each lane owns one of the 64 units for the four nodes: 128 x (one weight read + one float4 broadcast read + 4 FMA)
-//   layer 3  lane = node*16 + output;  regret matching needs sum(relu(adv)*mask) over a node's 16 lanes: 4 shuffles
+// <= 24 frontier nodes of a ply runs inside the wave, kG = 4 nodes at a time, on the matrix cores (v_mfma_f32_4x4x1: 16
+// independent 4x4 outer products per instruction -- 4 hidden units x 4 nodes per lane quad):
+//   layer 1  K = 32 dense 0/1 inputs built from the node's hand/table bit masks (a zero input adds an exact zero), bias and
+//            the constant-1 feature's column as the initial accumulator, 128 units = two halves of 16 blocks
+//   layer 2  K = 128, 64 units = 16 blocks; per four inputs two 16-byte LDS reads (weights and activations both kept as
+//            k-quads) and four MFMAs
+//   layer 3  K = 64, 16 outputs = 4 blocks x 4 K-splits, partial sums added with two cross-lane shuffles; regret matching
+//            (sum of relu(adv)*mask over a node's 16 outputs) stays in the accumulator layout
+// Opponent nodes with a single legal action skip the forward pass: their child is forced and nothing else of them is used.
 // then expand / sample exactly as k_sdcfr_expand does (same Philox keying, so the two paths sample identical actions), and
 // after ply 7 the values flow back up inside the wave with the memory rows written straight to the caller's ring.
 // Weights per net, as one float32 buffer: W1^T [34][128] | b1 [128] | W2^T [128][64] | b2 [64] | W3^T [64][16] | b3 [16].
