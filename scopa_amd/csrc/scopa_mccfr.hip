@@ -8,26 +8,29 @@
 // 120 leaves), a node being named by the branch digits taken at the traverser plies above it (0 = the sampled child,
 // i+1 = re-expansion of action i).
 //
-// Kernel design (k_mccfr_traverse, v4): LEVEL-SYNCHRONOUS over the recursion tree, one lane per UNIQUE node, one
+// Kernel design (k_mccfr_traverse): LEVEL-SYNCHRONOUS over the recursion tree, one lane per UNIQUE node, one
 // WAVEFRONT per traversal pair.  Ply d of a pair is one step over its 2, 6, 10, 25, 40, 80 nodes (plies 0..5), each
-// lane deriving its node from its parent's 32-byte record in LDS (index arithmetic: the game tree is regular),
+// lane deriving its node from its parent's 24-byte record in LDS (index arithmetic: the game tree is regular),
 // sampling its action from the frozen sigma|cdf row and leaving its own record for the next ply.  The 16 wavefronts
 // of a workgroup run their pairs independently -- only wave-level LDS ordering between plies, no workgroup barrier
-// in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).  Random draws are Philox4x32-10 blocks keyed by the node's
-// PATH (ntl + 16*digits, global traversal id, iteration, traverser): an opponent node computes the block, uses words
-// 0,1 and hands words 2,3 to the traverser node below it -- so results do not depend on launch geometry, pass size or
-// GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
+// in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).
+// Random draws are Philox4x32-10 blocks keyed by the node's PATH (ntl + 16*digits, global traversal id, iteration,
+// traverser), all 112 blocks of a pair computed in a dense pre-pass (draw_pair) and kept as 53-bit integers that are compared
+// with integer thresholds ceil(cdf * 2^53): words 0,1 feed the opponent node, words 2,3 the traverser node below it -- so
+// results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
 // The update step then gives one lane per traverser node (26 per task): v as the reference's fma chain over <= 4 leaf
 // payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Everything a pair touches is LDS resident
-// (sigma|cdf rows 47 KB, delta 24 KB, 16 x 4.4 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
-// 1024-thread workgroup per CU); each workgroup finally writes its partial table as one coalesced SLAB in HBM and
-// k_mccfr_reduce sums the slabs in a fixed order.  Strategy sums are integer visit counts (sigma is frozen, so
+// (sigma|threshold rows 41 KB, delta 24 KB, 16 x 5.6 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
+// 1024-thread workgroup per CU); each workgroup finally streams its partial table as one coalesced SLAB to HBM and
+// k_mccfr_reduce_apply (k_mccfr_reduce + k_mccfr_apply on the split path) sums the slabs in a fixed order, for N > 1
+// exchanges the rows with the peers (scopa_p2p.h), and applies them.  Strategy sums are integer visit counts (sigma is frozen, so
 // strategy_sum += count * sigma).
 //
 // History (rocprofv3, B = 4096 per traverser, profiles/): v1 one lane per leaf path + global f64 atomics + one global
 // counter atomic per wavefront: 122 us (100 us of it 8192 same-address atomics); v2 slabs + per-workgroup counters +
 // traverser-specialised walk: 20-23 us, 2.8 us per 16 tasks (issue-bound at ~1.5 cycles/instruction); v3 unique
-// nodes with workgroup-wide plies: same time (latency-bound); v4 unique nodes per wavefront: see DESIGN.md.
+// nodes with workgroup-wide plies: same time (latency-bound); v4-v6 (unique nodes per wavefront, dense Philox pre-pass,
+// integer thresholds, batched prologue loads, streamed slabs): 14.9 us, see DESIGN.md section 4.
 #include "scopa_ctx.h"
 #include "scopa_p2p.h"
 #include "scopa_philox.h"
