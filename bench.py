@@ -221,10 +221,10 @@ def main():
                          "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
                          "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
                          "kernel_avg_us_device_clock": 1e3 * (dev_ms1 - dev_ms0) / max(dev_n1 - dev_n0, 1), "launches_device_clock": dev_n1 - dev_n0,
-                         "timing_note": "kernel_avg_us: HIP events on the kernel's stream around every prof-stride-th launch (includes the "
-                                        "event records' own dispatch gap); kernel_avg_us_device_clock: first workgroup start -> last "
-                                        "workgroup end on the 100 MHz device clock, all launches of the timed region (the figure to hold "
-                                        "against rocprofv3's kernel duration)",
+                         "timing_note": "kernel_avg_us: HIP start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL) of every "
+                                        "prof-stride-th launch on the kernel's stream -- the kernel's own begin/end timestamps, what rocprofv3 "
+                                        "reports as its duration; kernel_avg_us_device_clock: first workgroup start -> last workgroup end on the "
+                                        "100 MHz device clock, every launch of the timed region (launch ramp and end-of-kernel write-back excluded)",
                          "algorithmic_bytes_per_launch": visits_per_launch * ALG_BYTES_PER_VISIT,
                          "note": "algorithmic bytes = 111.6 B/visit x 463 x batch visits per launch (SURVEY 8d); the working set "
                                  "(tables, tree) is LDS-resident by design, so HBM traffic is far below the algorithmic bytes"},

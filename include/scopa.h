@@ -309,9 +309,9 @@ int32_t scopa_p2p_destroy(scopa_ctx *ctx);
 /* ---- counters / profiling -------------------------------------------------------------------------------
  * exact integer counts of decision-node visits ("infoset-traversals") and terminal visits since creation */
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits);
-/* stride > 0: every stride-th launch of the dominant traversal kernel is bracketed by HIP events on the context's
- * stream (stride 1 = every launch); 0 = off.  scopa_prof_read synchronises and returns the number of bracketed
- * launches and their summed kernel milliseconds since enable. */
+/* stride > 0: every stride-th launch of the dominant traversal kernel carries a (start, stop) HIP event pair attached to
+ * the dispatch itself (hipExtLaunchKernelGGL) on the context's stream (stride 1 = every launch); 0 = off.  scopa_prof_read
+ * synchronises and returns the number of sampled launches and their summed kernel milliseconds since enable. */
 int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride);
 int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
 /* the same kernel timed by ITSELF: per launch, first workgroup start -> last workgroup end on the 100 MHz device-wide clock,

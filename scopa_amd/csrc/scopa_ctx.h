@@ -62,7 +62,6 @@ struct scopa_ctx {
     bool prof_on = false;
     int prof_stride = 1;
     long long prof_tick = 0;
-    bool prof_open = false;
     std::vector<hipEvent_t> ev_pool;
     size_t ev_used = 0;
     int64_t prof_launches = 0;
@@ -96,9 +95,8 @@ inline int32_t fail(scopa_ctx *ctx, int32_t code, const char *what, hipError_t e
     } while (0)
 
 int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
-// event pair bracketing a launch of the dominant kernel when profiling is on
-void prof_begin(scopa_ctx *ctx);
-void prof_end(scopa_ctx *ctx);
+// (start, stop) events to attach to a sampled launch of the dominant kernel when profiling is on
+bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 void p2p_release(scopa_ctx *ctx);
 
 }  // namespace scopa

@@ -19,10 +19,13 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes) {
     return SCOPA_OK;
 }
 
-void prof_begin(scopa_ctx *ctx) {
-    ctx->prof_open = false;
-    if (!ctx->prof_on) return;
-    if ((ctx->prof_tick++ % ctx->prof_stride) != 0) return;
+// A sampled launch of the dominant kernel gets a (start, stop) HIP event pair attached to the dispatch itself
+// (hipExtLaunchKernelGGL): the events carry the kernel's own begin/end timestamps, i.e. what a profiler reports as its
+// duration, without the dispatch gaps that hipEventRecord before/after a launch would add.  Returns false when this launch
+// is not sampled (profiling off, or not the stride's turn).
+bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
+    if (!ctx->prof_on) return false;
+    if ((ctx->prof_tick++ % ctx->prof_stride) != 0) return false;
     if (ctx->ev_used + 2 > ctx->ev_pool.size()) {
         // drain: fold finished pairs into the running sum, then reuse the pool
         if (ctx->ev_used) {
@@ -39,20 +42,12 @@ void prof_begin(scopa_ctx *ctx) {
             ctx->ev_pool.push_back(e);
         }
     }
-    if (ctx->ev_used + 2 <= ctx->ev_pool.size()) {
-        (void)hipEventRecord(ctx->ev_pool[ctx->ev_used], ctx->stream);
-        ctx->prof_open = true;
-    }
-}
-
-void prof_end(scopa_ctx *ctx) {
-    if (!ctx->prof_on || !ctx->prof_open) return;
-    ctx->prof_open = false;
-    if (ctx->ev_used + 2 <= ctx->ev_pool.size()) {
-        (void)hipEventRecord(ctx->ev_pool[ctx->ev_used + 1], ctx->stream);
-        ctx->ev_used += 2;
-        ctx->prof_launches++;
-    }
+    if (ctx->ev_used + 2 > ctx->ev_pool.size()) return false;
+    *start = ctx->ev_pool[ctx->ev_used];
+    *stop = ctx->ev_pool[ctx->ev_used + 1];
+    ctx->ev_used += 2;
+    ctx->prof_launches++;
+    return true;
 }
 
 }  // namespace scopa
@@ -332,7 +327,6 @@ int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride) {
     ctx->prof_on = stride != 0;
     ctx->prof_stride = stride > 0 ? stride : 1;
     ctx->prof_tick = 0;
-    ctx->prof_open = false;
     ctx->ev_used = 0;
     ctx->prof_launches = 0;
     ctx->prof_ms = 0.0;

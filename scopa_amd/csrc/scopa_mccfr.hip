@@ -31,6 +31,8 @@
 // traverser-specialised walk: 20-23 us, 2.8 us per 16 tasks (issue-bound at ~1.5 cycles/instruction); v3 unique
 // nodes with workgroup-wide plies: same time (latency-bound); v4-v6 (unique nodes per wavefront, dense Philox pre-pass,
 // integer thresholds, batched prologue loads, streamed slabs): 14.9 us, see DESIGN.md section 4.
+#include <hip/hip_ext.h>
+
 #include "scopa_ctx.h"
 #include "scopa_p2p.h"
 #include "scopa_philox.h"
@@ -795,11 +797,17 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
         SC_HIP(ctx, hipGetLastError());
         ctx->sigcdf_valid = true;
     }
-    prof_begin(ctx);
-    hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
-                       ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                       iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
-    prof_end(ctx);
+    {
+        hipEvent_t ev0, ev1;
+        if (prof_events(ctx, &ev0, &ev1))
+            hipExtLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ev0, ev1, 0, ctx->d_infoset, ctx->d_payoff,
+                                  ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
+                                  iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
+        else
+            hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
+                               ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
+                               iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
+    }
     SC_HIP(ctx, hipGetLastError());
     if (fuse_apply) {  // reduce (+ exchange with the peers) + apply in one kernel
         scopa::P2PArgs xa{};
