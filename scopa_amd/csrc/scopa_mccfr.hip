@@ -81,17 +81,6 @@ __host__ __device__ constexpr int task_nodes(int trav, int d) {
     return ntl_at(trav, d) == 0 ? 1 : ntl_at(trav, d) == 1 ? 5 : ntl_at(trav, d) == 2 ? 20 : 60;
 }
 
-struct NodeRec {      // 24 bytes, one per recursion-tree node of the ply being handed down
-    double reach;     // product of the opponent's sigma on the path          (reach_probs[1 - traverser])
-    double samp;      // product of the traverser's sigma on the path         (sampling_probs[traverser])
-    uint16_t idx;     // BFS index of the game-tree node within its ply
-    uint16_t dig;     // branch digits so far, 3 bits per traverser ply
-    uint16_t inf;     // its infoset id
-    uint8_t a;        // sampled action index (np.random.choice)
-    uint8_t pad;
-};
-static_assert(sizeof(NodeRec) == 24, "NodeRec must be 24 bytes");
-
 constexpr int kRow = 7;   // doubles per frozen row in LDS: sigma[4] | 3 cdf thresholds.  The last threshold of a row is always >= 2^53
                            // (cdf[n-1] = 1.0, padding = ~0) and never counts, so it is not kept; the 56-byte stride also spreads
                            // random-row gathers over 32 bank alignments (64-byte rows could only start at 4 of them: every gather
@@ -116,8 +105,7 @@ k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g
 // ---------------------------------------------------------------------------------------------------------------------
 // Per-wavefront scratch in LDS: the records of one traversal pair (2 tasks) + what the update step needs.
 struct WaveScratch {
-    NodeRec recA[40];        // even plies: <= 20 + 20 nodes
-    NodeRec recB[80];        // odd plies:  <= 60 + 20 nodes
+    uint32_t pk5[80];        // ply 5 (60 + 20 nodes, two rounds): idx | sampled action << 21, for the leaf stage
     double updr[2 * kUpd];   // opponent reach ...
     double upds[2 * kUpd];   // ... and own sampling probability at every traverser node with > 1 action
     uint16_t updI[2 * kUpd]; // ... and its infoset
@@ -164,37 +152,55 @@ __device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b,
     wave_lds_sync();
 }
 
+// What a node hands down to its children, kept in the REGISTERS of the lane that computed it: plies 0..4 have at most 40
+// nodes per pair, so a child fetches its parent's values with cross-lane reads (ds_bpermute: the LDS crossbar, no memory, no
+// bank conflicts) instead of a 24-byte record written to and read back from LDS.  Only ply 5 (80 nodes, two rounds) leaves
+// something in LDS: (idx, sampled action) in one word per node, for the leaf stage.
+struct NodeRegs {
+    double reach, samp;
+    uint32_t pk;   // idx (10 bits) | infoset << 10 (11 bits) | sampled action << 21
+};
+
 // One ply of one traversal pair: lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's.
 template <int D>
 __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf,
                                                  const double *__restrict__ s_sigcdf, uint8_t *__restrict__ s_seen,
-                                                 unsigned int *__restrict__ s_cnt) {
+                                                 unsigned int *__restrict__ s_cnt, NodeRegs &st) {
     constexpr int n = 4 - (D >> 1);
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
-    NodeRec *rec_out = (D & 1) ? ws.recB : ws.recA;
-    const NodeRec *rec_in = (D & 1) ? ws.recA : ws.recB;
     unsigned int visited = 0;
+    NodeRegs mine = st;
 #pragma unroll
     for (int t0 = 0; t0 < c0 + c1; t0 += 64) {
         const int t = t0 + lane;
-        if (t < c0 + c1) {
-            const int trav = t < c0 ? 0 : 1;
-            const int j = trav ? t - c0 : t;
-            const bool is_trav = (D & 1) == trav;
-            const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
-            int idx = 0;
+        const bool valid = t < c0 + c1;
+        const int trav = t < c0 ? 0 : 1;
+        const int j = trav ? t - c0 : t;
+        const bool is_trav = (D & 1) == trav;
+        const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
+        int idx = 0, p_inf = 0, act = 0;
+        double p_reach = 1.0, p_samp = 1.0;
+        bool p_trav = false;
+        if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
+            constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
+            p_trav = (pd & 1) == trav;
+            int pj = j, br = 0;
+            if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
+            int plane = (trav ? task_nodes(0, pd) : 0) + pj;
+            plane = valid ? plane : 0;
+            p_reach = __shfl(st.reach, plane);
+            p_samp = __shfl(st.samp, plane);
+            const uint32_t ppk = (uint32_t)__shfl((int)st.pk, plane);
+            p_inf = (int)((ppk >> 10) & 2047u);
+            act = (p_trav && br > 0) ? br - 1 : (int)(ppk >> 21);
+            idx = (int)(ppk & 1023u) * pn + act;
+        }
+        if (valid) {
             double reach = 1.0, samp = 1.0;
-            if (D > 0) {
-                constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
-                const bool p_trav = (pd & 1) == trav;
-                int pj = j, br = 0;
-                if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
-                const NodeRec pr = rec_in[(trav ? task_nodes(0, pd) : 0) + pj];
-                const int act = (p_trav && br > 0) ? br - 1 : pr.a;
-                const double sg = s_sigcdf[pr.inf * kRow + act];
-                idx = pr.idx * pn + act;
-                if (p_trav) { samp = pr.samp * sg; reach = pr.reach; }
-                else        { reach = pr.reach * sg; samp = pr.samp; }
+            if constexpr (D > 0) {
+                const double sg = s_sigcdf[p_inf * kRow + act];
+                if (p_trav) { samp = p_samp * sg; reach = p_reach; }
+                else        { reach = p_reach * sg; samp = p_samp; }
             }
             const int In = s_inf[level_offset(D) + idx];
             s_seen[In] = 1;  // benign race: every writer stores 1
@@ -202,8 +208,11 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
             const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
             const unsigned long long k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
             const unsigned long long *thr = reinterpret_cast<const unsigned long long *>(s_sigcdf + In * kRow + 4);
-            int a = (thr[0] <= k) + (thr[1] <= k) + (thr[2] <= k);  // thr[3] >= 2^53 > k always
-            a = a < n - 1 ? a : n - 1;
+            // only the first n-1 thresholds can count (those from n-1 on are >= 2^53 > k): one LDS read at the n = 2 plies, where
+            // most nodes are, instead of three
+            int a = (thr[0] <= k);
+            if constexpr (n > 2) a += (thr[1] <= k);
+            if constexpr (n > 3) a += (thr[2] <= k);
             if (is_trav) {  // what the update step needs (mc_cfr.py:81-82)
                 const int x = trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + j;
                 ws.updI[x] = (uint16_t)In;
@@ -211,14 +220,17 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
                 ws.upds[x] = samp;
                 atomicAdd(&s_cnt[In], 1u);
             }
-            NodeRec out;
-            out.reach = reach; out.samp = samp;
-            out.idx = (uint16_t)idx; out.dig = 0; out.inf = (uint16_t)In; out.a = (uint8_t)a; out.pad = 0;
-            rec_out[t] = out;
+            if constexpr (D == 5) {  // 80 nodes in two rounds: the leaf stage reads (idx, sampled action) from LDS
+                ws.pk5[t] = (uint32_t)idx | ((uint32_t)a << 21);
+            } else {
+                mine.reach = reach; mine.samp = samp;
+                mine.pk = (uint32_t)idx | ((uint32_t)In << 10) | ((uint32_t)a << 21);
+            }
             visited += 1;
         }
     }
-    wave_lds_sync();
+    st = mine;
+    if constexpr (D == 5) wave_lds_sync();
     return visited;
 }
 
@@ -229,13 +241,15 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
                                           uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis) {
     draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
-    // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time)
-    my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
-    my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
-    my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
-    my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
-    my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
-    my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt);
+    // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
+    // stay in their lanes' registers for the next ply to fetch
+    NodeRegs st = {1.0, 1.0, 0u};
+    my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
+    my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
+    my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
+    my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
+    my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
+    my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
     // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts
     for (int t = lane; t < 2 * 60; t += 64) {
         const int trav = t < 60 ? 0 : 1;
@@ -243,9 +257,9 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
         int pj = j, k = 0;
         if (trav == 1) { pj = j / 3; k = j - pj * 3; }
-        const NodeRec pr = ws.recB[(trav ? 60 : 0) + pj];
-        const int act = (trav == 1 && k > 0) ? k - 1 : pr.a;
-        const int idx6 = pr.idx * 2 + act;                 // = index of the ply-7 node and of the leaf as well
+        const uint32_t ppk = ws.pk5[(trav ? 60 : 0) + pj];
+        const int act = (trav == 1 && k > 0) ? k - 1 : (int)(ppk >> 21);
+        const int idx6 = (int)(ppk & 1023u) * 2 + act;     // = index of the ply-7 node and of the leaf as well
         const int I6 = s_inf[level_offset(6) + idx6], I7 = s_inf[level_offset(7) + idx6];
         s_seen[I6] = 1;
         s_seen[I7] = 1;
