@@ -10,7 +10,8 @@
 //
 // Kernel design (k_mccfr_traverse): LEVEL-SYNCHRONOUS over the recursion tree, one lane per UNIQUE node, one
 // WAVEFRONT per traversal pair.  Ply d of a pair is one step over its 2, 6, 10, 25, 40, 80 nodes (plies 0..5), each
-// lane deriving its node from its parent's 24-byte record in LDS (index arithmetic: the game tree is regular),
+// lane deriving its node from its parent's values, fetched from the parent's lane with cross-lane reads (index arithmetic:
+// the game tree is regular),
 // sampling its action from the frozen sigma|cdf row and leaving its own record for the next ply.  The 16 wavefronts
 // of a workgroup run their pairs independently -- only wave-level LDS ordering between plies, no workgroup barrier
 // in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).
@@ -20,7 +21,7 @@
 // results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
 // The update step then gives one lane per traverser node (26 per task): v as the reference's fma chain over <= 4 leaf
 // payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Everything a pair touches is LDS resident
-// (sigma|threshold rows 41 KB, delta 24 KB, 16 x 5.6 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
+// (sigma|threshold rows 41 KB, delta 24 KB, 16 x 3.1 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
 // 1024-thread workgroup per CU); each workgroup finally streams its partial table as one coalesced SLAB to HBM and
 // k_mccfr_reduce_apply (k_mccfr_reduce + k_mccfr_apply on the split path) sums the slabs in a fixed order, for N > 1
 // exchanges the rows with the peers (scopa_p2p.h), and applies them.  Strategy sums are integer visit counts (sigma is frozen, so
