@@ -529,7 +529,8 @@ k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restri
 // slab.  Thread (chunk = tid / 10, pair = tid % 10) owns two adjacent cells (one 16-byte load per slab) and the slabs
 // chunk, chunk+24, ... (<= 11 at 256 slabs); all its loads are issued before the first add.  The 24 partial sums per cell
 // are combined in chunk order through LDS, then 4 lanes apply their rows exactly as k_mccfr_apply does.
-// Deterministic: the order of every float64 sum is fixed by n_slabs, not by timing.
+// The order of every float64 sum in THIS kernel is fixed by n_slabs, not by timing (the slabs themselves come from LDS float64
+// atomics whose order inside a workgroup is not: two runs agree to rounding, ~1e-15 relative).
 namespace {
 // measured: 4 rows x 24 chunks 8.3 us; 2 rows x 51 chunks 10.5 us (the serial 51-term combine); 16 rows x 6 chunks slower still
 constexpr int kRaRows = 4, kRaCells = kRaRows * 5, kRaPairs = kRaCells / 2, kRaChunks = 24;
