@@ -126,10 +126,12 @@ SC_HD void step(scopa_state &s, int action) {
             s.table = tab;
             s.nt = (uint8_t)nt_new;
             if (nt_new == 0) s.scopas[p]++;                            // (:100-101), last ply included
-        } else {
+        } else if (s.nt < 8) {
             s.table |= (uint32_t)action << (4 * s.nt);                 // (:103)
             s.nt++;
-        }
+        }   // a ninth table card cannot happen in play (table ranks are distinct and an equal rank always captures); a crafted
+            // state that would need it keeps its eight cards -- the packed state has no ninth slot and no error channel
+
         s.hand[p] = (uint16_t)nib_remove(hand, pos);                   // (:104)
         s.nh[p] = (uint8_t)(nh - 1);
     }  // else: card not in hand -> silent no-op that still consumes the turn (:155-159)

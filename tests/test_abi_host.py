@@ -72,6 +72,42 @@ def test_host_rules_match_oracle_on_random_states(sl, oracle):
             assert [out[i] for i in range(n.value)] == o.legal()
 
 
+def test_capture_rule_on_arbitrary_tables(sl, oracle):
+    """States no game can reach -- tables with several cards of one rank, full 8-card tables, any mover -- so that the bitmask
+    subset-sum DP is compared with the oracle's literal list DP on everything the packed state can express, not only on what
+    play produces: 30k random (hands, table, card) triples, the whole successor state compared."""
+    L = sl.lib()
+    rng = np.random.RandomState(77)
+    for trial in range(30000):
+        cards = rng.permutation(16)
+        nt = int(rng.randint(0, 9))                       # 0..8 table cards (the packed state holds 8)
+        nh0, nh1 = int(rng.randint(1, 5)), int(rng.randint(1, 5))
+        if nt + nh0 + nh1 > 16:
+            nt = 16 - nh0 - nh1
+        table, h0, h1 = cards[:nt], cards[nt:nt + nh0], cards[nt + nh0:nt + nh0 + nh1]
+        step = int(rng.randint(0, 7))
+        mover = step & 1
+        hand = h0 if mover == 0 else h1
+        card = int(hand[rng.randint(len(hand))])
+        s = sl.State16()
+        s.hand[0] = sum(int(c) << (4 * i) for i, c in enumerate(h0)); s.hand[1] = sum(int(c) << (4 * i) for i, c in enumerate(h1))
+        s.table = sum(int(c) << (4 * i) for i, c in enumerate(table))
+        s.nh[0], s.nh[1], s.nt, s.step = nh0, nh1, nt, step
+        o = oracle.State(perm=np.arange(16, dtype=np.uint8))
+        for i in range(4):
+            o.s.hand[0][i] = int(h0[i]) if i < nh0 else 0
+            o.s.hand[1][i] = int(h1[i]) if i < nh1 else 0
+        for i in range(8):
+            o.s.table[i] = int(table[i]) if i < nt else 0
+        o.s.nh[0], o.s.nh[1], o.s.nt, o.s.step = nh0, nh1, nt, step
+        o.s.ncap[0] = o.s.ncap[1] = o.s.scopas[0] = o.s.scopas[1] = 0
+        if nt == 8 and not o.capture(card):
+            continue                                      # a ninth table card: not representable (and not reachable) -- see scopa_rules.h
+        L.scopa_state_step(C.byref(s), card)
+        o.step(card)
+        assert unpack_state(s) == o.snapshot(), (list(table), list(hand), card)
+
+
 def test_bad_arguments_are_rejected(sl):
     L = sl.lib()
     s = sl.State16()
