@@ -132,19 +132,30 @@ __device__ __forceinline__ void wave_lds_sync() {
 // All random draws of one traversal pair in a dense pre-pass: 86 + 26 Philox blocks over 64 lanes (2 rounds = 40 64-bit
 // multiplies per wavefront instead of one Philox per ply round at 3-60 % lane use).  Block (traverser, ntl, j): j indexes the
 // branch prefix in the same mixed radix (5,4,3) as the node index of its ply; counter = (ntl + 16*digits, b, iteration, traverser).
-__device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
+// Philox counter word 0 of draw block `item` (0..85: traverser 0's blocks, 86..111: traverser 1's): ntl + 16 * digits.  Computed
+// once per workgroup into a 112-entry LDS table: the mixed-radix decode costs ~30 VALU instructions per lane and round, and the
+// VALU pipes are what this kernel is bound by.
+constexpr int kDrawItems = 86 + 26;
+constexpr int kStaticLds = 64 + 512;   // s_vis (+ alignment) and the draw table, beside the dynamic LDS
+__device__ __forceinline__ uint32_t draw_counter0(int item) {
+    const int blk = item < 86 ? item : item - 86;
+    const int ntl = blk == 0 ? 0 : blk < 6 ? 1 : blk < 26 ? 2 : 3;
+    const int j = blk - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26);
+    uint32_t dig;
+    if (ntl <= 1) dig = (uint32_t)j;
+    else if (ntl == 2) dig = (uint32_t)(j / 4) | ((uint32_t)(j % 4) << 3);
+    else dig = (uint32_t)(j / 12) | ((uint32_t)((j / 3) % 4) << 3) | ((uint32_t)(j % 3) << 6);
+    return (uint32_t)ntl + 16u * dig;
+}
+
+__device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi,
+                                          const uint32_t *__restrict__ s_c0) {
 #pragma unroll
     for (int r = 0; r < 2; r++) {
         const int item = r * 64 + lane;
-        if (item < 86 + 26) {
+        if (item < kDrawItems) {
             const int trav = item < 86 ? 0 : 1, blk = trav ? item - 86 : item;
-            const int ntl = blk == 0 ? 0 : blk < 6 ? 1 : blk < 26 ? 2 : 3;
-            const int j = blk - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26);
-            uint32_t dig;
-            if (ntl <= 1) dig = (uint32_t)j;
-            else if (ntl == 2) dig = (uint32_t)(j / 4) | ((uint32_t)(j % 4) << 3);
-            else dig = (uint32_t)(j / 12) | ((uint32_t)((j / 3) % 4) << 3) | ((uint32_t)(j % 3) << 6);
-            const philox_out x = philox4x32_10((uint32_t)ntl + 16u * dig, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
+            const philox_out x = philox4x32_10(s_c0[item], b, iteration, (uint32_t)trav, seed_lo, seed_hi);
             const unsigned long long kx = k53(x.x0, x.x1), ky = k53(x.x2, x.x3);
             if (trav == 0) { ws.kx0[blk] = kx; if (blk < 26) ws.ky0[blk] = ky; }
             else           { ws.kx1[blk] = kx; ws.ky1[blk] = ky; }
@@ -240,8 +251,8 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
 __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
-                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis) {
-    draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
+                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const uint32_t *__restrict__ s_c0) {
+    draw_pair(ws, lane, b, iteration, seed_lo, seed_hi, s_c0);
     // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
     NodeRegs st = {1.0, 1.0, 0u};
@@ -306,6 +317,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                  unsigned long long *__restrict__ g_wg_counts, uint8_t *__restrict__ g_seen_slabs) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
+    __shared__ uint32_t s_c0[128];
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's life span, for scopa_prof_device
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | cdf thresholds[4] | pad
@@ -318,6 +330,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     if (tid < 2) s_vis[tid] = 0u;
+    if (tid < kDrawItems) s_c0[tid] = draw_counter0(tid);
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
     // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue instead
     // of one per loop iteration), the LDS zeroing runs underneath them, then the loaded pieces are stored.
@@ -362,7 +375,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis);
+        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, s_c0);
     }
     __syncthreads();
 
@@ -400,6 +413,8 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
               uint32_t batch) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
+    __shared__ uint32_t s_c0[128];
+    if (threadIdx.x < kDrawItems) s_c0[threadIdx.x] = draw_counter0(threadIdx.x);
     {
         const size_t deal = blockIdx.x;
         g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision; g_regret += deal * kDecision * 4;
@@ -432,7 +447,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         }
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
-            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis);
+            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, s_c0);
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
@@ -785,14 +800,14 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~870 infosets), fewer for deals
     // with more infosets (the tables alone fit up to 1653, the maximum)
     int waves = 16;
-    while (waves > 1 && traverse_lds_bytes(ctx->n_infosets, waves) + 64 > (size_t)ctx->lds_limit) waves -= 2;
+    while (waves > 1 && traverse_lds_bytes(ctx->n_infosets, waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
     const int threads = waves * 64;
     const size_t lds = traverse_lds_bytes(ctx->n_infosets, waves);
-    SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
+    SC_REQUIRE(ctx, lds + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
     static bool attr_set = false;
     if (!attr_set) {
         SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_traverse),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 64));  // 8 B of static LDS (s_vis)
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - kStaticLds));
         attr_set = true;
     }
     const uint32_t n_passes = (nb + waves - 1) / waves;  // one traversal pair per wavefront pass
@@ -858,9 +873,9 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
         b += (((size_t)max_infosets * 4 + 15) & ~(size_t)15) + 1656 * 2 + 576 + (size_t)max_infosets;
         return (b + 15) & ~(size_t)15;
     };
-    while (waves > 1 && need(waves) + 64 > (size_t)ctx->lds_limit) waves -= 2;
-    SC_REQUIRE(ctx, need(waves) + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
-    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_multi), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 64));
+    while (waves > 1 && need(waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
+    SC_REQUIRE(ctx, need(waves) + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
+    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_multi), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - kStaticLds));
     hipLaunchKernelGGL(k_mccfr_multi, dim3(n_deals), dim3(waves * 64), need(waves), ctx->stream, d_infoset, d_payoff, d_key, d_regret, d_strat,
                        d_meta, d_visit, d_counters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, n_iters, batch);
     SC_HIP(ctx, hipGetLastError());
