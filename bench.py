@@ -2,18 +2,28 @@
 """bench.py -- MiniScopa infoset-traversals/sec (BASELINE.json metric) on N MI355X of one node.
 
 A "step" is one batched external-sampling MCCFR iteration: `batch` traversals per traverser per GPU against the
-iteration's frozen tables (k_mccfr_traverse), [N>1: one sum-all-reduce of the [738][5] float64 delta over RCCL],
-apply.  N=1 workload = BASELINE configs[1] ("External-sampling MCCFR, 4096 parallel traversals, 1 MI355X").
+iteration's frozen tables (k_mccfr_traverse), [N>1: one sum-all-reduce of the [738][5] float64 delta], apply.
+N=1 workload = BASELINE configs[1] ("External-sampling MCCFR, 4096 parallel traversals, 1 MI355X").
 An infoset-traversal = one decision-node visit: 463 per traversal pair, counted exactly by the kernel.
 
-    python bench.py --gpus 1 --steps 2000 --warmup 100
+    python bench.py                                   # N = 1, defaults finish within ~1.5 min (most of it the CPU baseline)
+    python bench.py --gpus 4 --steps 20 --warmup 5    # spawns its 4 ranks itself (fresh child processes, one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
-        bench.py --gpus N --steps K --warmup W
+        bench.py --gpus N --steps K --warmup W        # or under torchrun: RANK / LOCAL_RANK / WORLD_SIZE from the env
+
+Timing protocol (what the one JSON line reports).  The timed region is EXACTLY `--steps` iterations bracketed by
+barrier + device synchronisation on both sides, max over ranks.  A region of 20 iterations is ~0.5 ms, and on a GPU that
+has just idled through process start-up the first such region runs at half speed (clock and queue ramp), so:
+(1) a fixed pre-phase of >= 0.4 s of iterations runs first, whatever --warmup says; (2) then --warmup iterations; (3) the
+region is then timed R times back to back (R = 31, fewer only if a region is so long that 31 would exceed ~20 s) and the
+MEDIAN region is reported (`ms_per_step`, `value`), with min / max / first beside it in `timing`.
 """
 import argparse
 import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -23,13 +33,16 @@ sys.path.insert(0, ROOT)
 VISITS_PER_PAIR = 463          # 291 + 172 decision visits per (traverser 0, traverser 1) traversal pair
 ALG_BYTES_PER_VISIT = 111.6    # 32 B state + 32 B regret row + 0.3715 * 128 B table RMW
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
+CLOCK_HZ = 2.4e9               # MI355X_MICROARCH.md: max clock
+N_CUS, SIMDS_PER_CU = 256, 4
 REF_PY_VISITS_PER_S = 9300.0   # reference Python MCCFR, 1 Xeon core, survey container
+PRE_PHASE_S = 0.4
+REGIONS = 31
 
 
 def cpu_baseline(batch, target_s=12.0):
     """The oracle's batched MCCFR (same workload, same RNG keying) on ONE host core, bounded sample."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
-    import numpy as np
     import oracle as O
     t = O.Tree(seed=42)
     R, S, _ = t.tables()
@@ -78,34 +91,84 @@ def cpu_baseline_all_cores(batch, target_s=6.0):
             "sample": f"{n} independent oracle replicas x {target_s:.0f} s of the same MCCFR workload"}
 
 
+def spawn_ranks(n, argv):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes (this process has made no GPU
+    call and makes none), wire them like torchrun would (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*), pass rank 0's stdout --
+    the one JSON line -- through, and exit non-zero if any rank failed (the others are then stopped by PID)."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    base = dict(os.environ, WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    procs = []
+    for r in range(n):
+        env = dict(base, RANK=str(r), LOCAL_RANK=str(r))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc, deadline = 0, None
+    while any(p.poll() is None for p in procs):
+        for p in procs:
+            if p.poll() not in (None, 0) and rc == 0:
+                rc = p.returncode
+                deadline = time.time() + 20.0          # the others normally follow (a failed collective); then they are stopped
+        if deadline is not None and time.time() > deadline:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+        time.sleep(0.05)
+    for p in procs:
+        if p.returncode != 0 and rc == 0:
+            rc = p.returncode
+    return rc
+
+
+def load_profile_json(name):
+    path = os.path.join(ROOT, "profiles", name)
+    try:
+        with open(path) as f:
+            return json.load(f)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
-    ap.add_argument("--prof-stride", type=int, default=32, help="bracket every n-th traversal launch with HIP events")
+    ap.add_argument("--regions", type=int, default=REGIONS, help="how many times the --steps region is timed (median reported)")
+    ap.add_argument("--prof-stride", type=int, default=0, help="bracket every n-th traversal launch with HIP events (0 = so that >= 64 launches are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["auto", "p2p", "rccl"], default="auto",
                     help="N>1 delta all-reduce: library one-shot peer-memory exchange (validated against RCCL first), or torch.distributed/RCCL")
+    ap.add_argument("--exchange-form", choices=["auto", "light", "fenced"], default="auto",
+                    help="peer-memory exchange protocol form: light (sc0 sc1 accesses + s_waitcnt) only if it validates on this topology, else fenced")
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
+    ap.add_argument("--share-gpu", action="store_true",
+                    help="rehearsal on a box with fewer GPUs than ranks: all ranks use device 0, the process group is gloo (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
 
     import numpy as np
     import torch
     import torch.distributed as dist
     from scopa_amd import _lib
-    from scopa_amd.distributed import ShardedMCCFR, make_gpu_engine, shard_range
+    from scopa_amd.distributed import ShardedMCCFR, make_gpu_engine
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the solver path has no CPU fallback")
+    if local_rank >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {local_rank}, the node shows {torch.cuda.device_count()} (use --share-gpu to rehearse on fewer GPUs)")
     torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
     use_dist = world > 1 or args.force_dist
     saved_stdout = None
     if use_dist:
@@ -116,11 +179,15 @@ def main():
         os.dup2(2, 1)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local_rank}"))
+        if args.share_gpu:
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=dev)
+    coll_dev = torch.device("cpu") if args.share_gpu else dev     # where small collectives' tensors live
 
     perm = _lib.deal_py_seed(42)
     ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=2 if use_dist else 1, rank=rank,
-                                                      exchange=args.exchange)
+                                                      exchange=args.exchange, exchange_form=args.exchange_form)
     batch_total = args.batch * world
     # --force-dist with one rank still takes the exchange step (always_exchange), so the N>1 code path can be timed on one GPU
     drv = ShardedMCCFR(ctx, rank, world, all_reduce, fused_exchange=(use_dist and ctx.exchange == "p2p"), always_exchange=use_dist)
@@ -129,13 +196,20 @@ def main():
         if not use_dist:
             ctx.mccfr_iterate(args.batch, k)  # in-library launch loop: traverse + apply per iteration
         else:
-            drv.run(batch_total, k)
+            drv.run(batch_total, k)           # raises (SCOPA_ETIMEOUT) if a peer did not answer: the process then exits non-zero
 
     def fence():
         torch.cuda.synchronize()
         if use_dist:
             dist.barrier()
             torch.cuda.synchronize()
+
+    def all_max(x):
+        if not use_dist:
+            return x
+        t = torch.tensor([x], dtype=torch.float64, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item())
 
     # N > 1: before anything is timed, prove the sharded pipeline on THIS topology -- 10 iterations over `world` ranks must give
     # the tables of the same 10 iterations (same global traversal ids) on one GPU, up to the summation order of the rank deltas
@@ -155,79 +229,131 @@ def main():
         ctx.tables_reset()
         fence()
 
-    run(args.warmup)
-    fence()
-    d0, _ = ctx.counters()
-    dev_n0, dev_ms0 = ctx.prof_device()
-    ctx.prof_enable(args.prof_stride)
+    # ---- (1) pre-phase: >= PRE_PHASE_S of iterations, the same count on every rank (calibrated, max over ranks) ----------------
+    run(50)
     fence()
     t0 = time.perf_counter()
-    run(args.steps)
+    run(100)
     fence()
-    elapsed = time.perf_counter() - t0
+    per_step = all_max((time.perf_counter() - t0) / 100)
+    n_pre = int(min(max(PRE_PHASE_S / per_step, 100), 200000))
+    fence()
+    t0 = time.perf_counter()
+    run(n_pre)
+    fence()
+    pre_s = time.perf_counter() - t0
+    # ---- (2) the caller's warm-up ----------------------------------------------------------------------------------------------
+    run(args.warmup)
+    fence()
+    # ---- (3) the region: EXACTLY --steps iterations between fences, R times; the median region is the result -------------------
+    per_step = all_max(pre_s / n_pre)
+    regions = max(3, min(args.regions, int(20.0 / max(per_step * args.steps, 1e-9)))) if args.regions > 3 else max(1, args.regions)
+    stride = args.prof_stride if args.prof_stride > 0 else max(1, (args.steps * regions) // 64)
+    d0, _ = ctx.counters()
+    dev_n0, dev_ms0 = ctx.prof_device()
+    ctx.prof_enable(stride)
+    times = []
+    for _ in range(regions):
+        fence()
+        t0 = time.perf_counter()
+        run(args.steps)
+        fence()
+        times.append(all_max(time.perf_counter() - t0))
     launches, kernel_ms = ctx.prof_read()
     dev_n1, dev_ms1 = ctx.prof_device()
     ctx.prof_enable(0)
     d1, _ = ctx.counters()
+    med = sorted(times)[len(times) // 2]
 
     if use_dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local_rank}")
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-        cnt = torch.tensor([d1 - d0], dtype=torch.float64, device=f"cuda:{local_rank}")
+        cnt = torch.tensor([d1 - d0], dtype=torch.float64, device=coll_dev)
         dist.all_reduce(cnt, op=dist.ReduceOp.SUM)
         visits = int(cnt.item())
     else:
         visits = d1 - d0
-    expected = VISITS_PER_PAIR * batch_total * args.steps
-    assert visits == expected, f"kernel visit counter {visits} != {expected}"
+    visits_per_region = VISITS_PER_PAIR * batch_total * args.steps
+    assert visits == visits_per_region * regions, f"kernel visit counter {visits} != {visits_per_region * regions}"
     replicas_identical = None
     if use_dist:
         if ctx.exchange == "p2p":
             timeouts, exchanges = ctx.p2p_status()
-            tt = torch.tensor([timeouts], dtype=torch.int32, device=f"cuda:{local_rank}")
+            tt = torch.tensor([timeouts], dtype=torch.int32, device=coll_dev)
             dist.all_reduce(tt, op=dist.ReduceOp.MAX)          # every rank learns it, so every rank stops (none is left in a collective)
             assert int(tt.item()) == 0, f"peer exchange: wait(s) timed out on some rank (here: {timeouts}) -- the run is invalid"
         R, S, _ = ctx.tables_get()
         h = hashlib.sha256(R.tobytes() + S.tobytes()).digest()[:8]
-        mine = torch.tensor(list(h), dtype=torch.uint8, device=f"cuda:{local_rank}")
-        allh = [torch.zeros(8, dtype=torch.uint8, device=f"cuda:{local_rank}") for _ in range(world)]
+        mine = torch.tensor(list(h), dtype=torch.uint8, device=coll_dev)
+        allh = [torch.zeros(8, dtype=torch.uint8, device=coll_dev) for _ in range(world)]
         dist.all_gather(allh, mine)
         replicas_identical = all(bool((x == mine).all().item()) for x in allh)
+        assert replicas_identical, "replicas' tables differ after the run: the exchange delivered different sums to different ranks"
+        assert sharded_check is None or sharded_check, "10 sharded iterations do not reproduce the one-GPU tables"
 
     if rank == 0:
         kern_us = 1e3 * kernel_ms / max(launches, 1)
-        visits_per_launch = VISITS_PER_PAIR * args.batch  # this rank's slice
-        achieved = visits_per_launch * ALG_BYTES_PER_VISIT / (kern_us * 1e-6) / 1e9 if launches else None
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "hbm_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                traffic = json.load(open(tpath)).get("bytes_per_launch")
-            except Exception:
-                traffic = None
+        kern_s = kern_us * 1e-6
+        pairs_per_launch = args.batch                             # this rank's slice
+        visits_per_launch = VISITS_PER_PAIR * pairs_per_launch
+        alg_bytes = visits_per_launch * ALG_BYTES_PER_VISIT
+        # per-pair work of k_mccfr_traverse from the SQ counters (rocprofv3 --pmc passes folded by tests/tools/fold_profiles.py)
+        sq = load_profile_json("traverse_sq.json") or {}
+        valu_cyc = sq.get("valu_busy_cycles_per_pair", 2411.0)    # SQ_ACTIVE_INST_VALU x 4 (quad-cycles) / pairs
+        lds_cyc = sq.get("lds_array_cycles_per_pair", 510.3)      # SQ_LDS_IDX_ACTIVE / pairs
+        tr = load_profile_json("hbm_traffic.json") or {}
+        traffic = tr.get("bytes_per_launch") if tr.get("batch", 4096) == args.batch else None
+        bounds = {}
+        if launches:
+            bounds = {
+                "valu-issue": {"achieved": valu_cyc * pairs_per_launch / kern_s, "peak": N_CUS * SIMDS_PER_CU * CLOCK_HZ, "unit": "SIMD busy-cycles/s",
+                               "how": f"{valu_cyc:.0f} VALU-busy cycles per traversal pair (SQ_ACTIVE_INST_VALU, quad-cycles x 4) x {pairs_per_launch} pairs per launch "
+                                      "/ kernel time, against 1024 SIMDs x 2.4 GHz"},
+                "lds": {"achieved": lds_cyc * pairs_per_launch / kern_s, "peak": N_CUS * CLOCK_HZ, "unit": "LDS-array cycles/s",
+                        "how": f"{lds_cyc:.0f} LDS-array cycles per traversal pair (SQ_LDS_IDX_ACTIVE, bank-conflict cycles included) x {pairs_per_launch} pairs "
+                               "/ kernel time, against 256 LDS arrays x 2.4 GHz"},
+                "hbm-measured": {"achieved": (traffic / kern_s / 1e9) if traffic else None, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                 "how": "HBM bytes per launch from the FETCH_SIZE / WRITE_SIZE PMC passes (profiles/hbm_traffic.json) / kernel time"},
+            }
+            for b in bounds.values():
+                b["frac"] = (b["achieved"] / b["peak"]) if b["achieved"] else None
+        top = max((k for k in bounds if bounds[k]["frac"] is not None), key=lambda k: bounds[k]["frac"], default=None)
+        roofline = {
+            "bound": top, "achieved": bounds[top]["achieved"] if top else None, "peak": bounds[top]["peak"] if top else None,
+            "unit": bounds[top]["unit"] if top else None, "frac": bounds[top]["frac"] if top else None, "traffic": traffic,
+            "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
+            "kernel_avg_us_device_clock": 1e3 * (dev_ms1 - dev_ms0) / max(dev_n1 - dev_n0, 1), "launches_device_clock": dev_n1 - dev_n0,
+            "bounds": bounds,
+            "bound_note": "the kernel's working set (frozen strategy rows, delta table, tree maps) is LDS-resident by design, so the resources that can "
+                          "bound it are VALU issue and the LDS array; `bound` is whichever of the candidate ceilings the kernel sits closest to.  Per-pair "
+                          "cycle counts come from SQ counter passes of this kernel (profiles/traverse_sq.json: " + str(sq.get("source", "round-1 v7 kernel, B=65536")) + ")",
+            "hbm_algorithmic": {"bytes_per_launch": alg_bytes, "GBps": alg_bytes / kern_s / 1e9 if launches else None,
+                                "ratio_to_hbm_peak": alg_bytes / kern_s / 1e9 / HBM_PEAK_GBPS if launches else None,
+                                "note": "SURVEY 8(d)'s algorithmic price, 111.6 B/visit x 463 x batch visits per launch, divided by kernel time.  NOT a bound "
+                                        "for this kernel: those bytes are served from LDS, so the ratio exceeds 1; the HBM traffic actually measured is `traffic`"},
+            "traffic_source": {k: tr.get(k) for k in ("source", "commit", "batch")} if tr else None,
+            "timing_note": "kernel_avg_us: HIP start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL) of every "
+                           "prof-stride-th launch on the kernel's stream -- the kernel's own begin/end timestamps, what rocprofv3 "
+                           "reports as its duration; kernel_avg_us_device_clock: first workgroup start -> last workgroup end on the "
+                           "100 MHz device clock, every launch of the timed regions (launch ramp and end-of-kernel write-back excluded)",
+        }
         out = {
-            "metric": "MiniScopa infoset-traversals/sec", "value": visits / elapsed, "unit": "infoset-traversals/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+            "metric": "MiniScopa infoset-traversals/sec", "value": visits_per_region / med, "unit": "infoset-traversals/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * med / args.steps,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": "BASELINE configs[1]: external-sampling MCCFR on MiniScopa (seed-42 deal, 738 infosets), "
                                    f"{args.batch} parallel traversals per traverser per GPU per iteration, tables frozen per iteration",
                        "batch_per_gpu": args.batch, "global_batch": batch_total, "iterations": args.steps,
                        "parallelism": f"dp{world}" + ((" + 1 all-reduce of 29520 B per iteration (" + {"p2p": "one-shot peer-memory exchange over xGMI, rank-ordered sum", "rccl": "RCCL via torch.distributed"}.get(ctx.exchange, ctx.exchange) + ")") if use_dist else ""),
-                       "exchange": ctx.exchange if use_dist else None, "exchange_note": ctx.exchange_note if use_dist else None,
+                       "exchange": ctx.exchange if use_dist else None, "exchange_form": ctx.exchange_form if use_dist else None,
+                       "exchange_note": ctx.exchange_note if use_dist else None,
                        "replicas_bit_identical": replicas_identical, "sharded_10_iterations_match_one_gpu": sharded_check,
+                       "shared_gpu_rehearsal": bool(args.share_gpu),
                        "rng": "Philox4x32-10 keyed by (seed, path code, global traversal id, iteration, traverser)"},
-            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": (achieved / HBM_PEAK_GBPS) if achieved else None, "traffic": traffic,
-                         "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
-                         "kernel_avg_us_device_clock": 1e3 * (dev_ms1 - dev_ms0) / max(dev_n1 - dev_n0, 1), "launches_device_clock": dev_n1 - dev_n0,
-                         "timing_note": "kernel_avg_us: HIP start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL) of every "
-                                        "prof-stride-th launch on the kernel's stream -- the kernel's own begin/end timestamps, what rocprofv3 "
-                                        "reports as its duration; kernel_avg_us_device_clock: first workgroup start -> last workgroup end on the "
-                                        "100 MHz device clock, every launch of the timed region (launch ramp and end-of-kernel write-back excluded)",
-                         "algorithmic_bytes_per_launch": visits_per_launch * ALG_BYTES_PER_VISIT,
-                         "note": "algorithmic bytes = 111.6 B/visit x 463 x batch visits per launch (SURVEY 8d); the working set "
-                                 "(tables, tree) is LDS-resident by design, so HBM traffic is far below the algorithmic bytes"},
+            "timing": {"protocol": f"pre-phase {n_pre} iterations ({pre_s:.2f} s), then --warmup, then the --steps region timed {regions} times "
+                                   "(barrier + device sync both sides, max over ranks); value and ms_per_step are the MEDIAN region",
+                       "regions": regions, "region_ms_median": 1e3 * med, "region_ms_min": 1e3 * min(times), "region_ms_max": 1e3 * max(times),
+                       "region_ms_first": 1e3 * times[0], "ms_per_step_min": 1e3 * min(times) / args.steps, "ms_per_step_max": 1e3 * max(times) / args.steps,
+                       "pre_phase_iterations": n_pre, "pre_phase_s": pre_s},
+            "roofline": roofline,
             "decision_visits": visits,
             # the other half of BASELINE's metric ("exploitability vs iters"): where the average strategy stands after this run
             "exploitability": {"iterations": int(ctx.mccfr_iteration()), "traversals_per_iteration": 2 * batch_total,
@@ -247,14 +373,14 @@ def main():
             # the same engine at a large batch (not the headline: BASELINE configs[1] is B=4096), for the throughput ceiling
             try:
                 big = 65536
-                ctx.mccfr_iterate(big, 20)
+                ctx.mccfr_iterate(big, 200)
                 torch.cuda.synchronize()
                 c0, _ = ctx.counters()
                 tb = time.perf_counter()
-                ctx.mccfr_iterate(big, 200)
+                ctx.mccfr_iterate(big, 1000)
                 torch.cuda.synchronize()
                 dtb = time.perf_counter() - tb
-                out["large_batch"] = {"batch_per_gpu": big, "value": (ctx.counters()[0] - c0) / dtb, "ms_per_step": 1e3 * dtb / 200}
+                out["large_batch"] = {"batch_per_gpu": big, "value": (ctx.counters()[0] - c0) / dtb, "ms_per_step": 1e3 * dtb / 1000}
             except Exception as e:
                 out["large_batch"] = {"error": repr(e)}
         if saved_stdout is not None:

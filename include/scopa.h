@@ -35,7 +35,8 @@ enum {
     SCOPA_EHIP = -3,     /* a HIP runtime call failed (see last_error)     */
     SCOPA_ESTATE = -4,   /* call order violated (e.g. no deal set)         */
     SCOPA_ENOMEM = -5,
-    SCOPA_ELIMIT = -6    /* problem exceeds a compiled-in capacity         */
+    SCOPA_ELIMIT = -6,   /* problem exceeds a compiled-in capacity         */
+    SCOPA_ETIMEOUT = -7  /* a peer did not answer within the wait budget (N > 1 exchange): tables are not to be trusted */
 };
 
 /* Deal-independent shape of MiniScopa (src/envs/mini_scopa_game.py:59,127): 2 players x 4 cards,
@@ -295,11 +296,19 @@ int32_t scopa_team_random_playouts(scopa_ctx *ctx, const int64_t *h_seeds, int64
  * One process per GPU on one node.  create: allocates this rank's inbox (fine-grained device memory) and returns its 64-byte
  * hipIpc handle; the caller all-gathers the handles (torch.distributed) and passes all `world` of them to connect.
  * allreduce_delta (on the context's stream): the delta buffer of every rank becomes the sum over ranks, added in rank order on
- * every rank (bit-identical replicas).  Waits are bounded (5 s); status returns the number of waits that gave up (0 = healthy)
- * and the exchanges issued.  Replaces torch.distributed.all_reduce(delta) between scopa_mccfr_traverse and scopa_mccfr_apply. */
+ * every rank (bit-identical replicas).  Waits are bounded (5 s, scopa_p2p_set_budget): a wait that gives up is counted, makes
+ * every later wait fall through (a dead peer cannot hang a GPU) and makes allreduce_delta / iterate_sharded -- which synchronise
+ * the stream before they return -- fail with SCOPA_ETIMEOUT, on that call and on every later one until the exchange is
+ * re-created; status returns the count (0 = healthy) and the exchanges issued.  Replaces torch.distributed.all_reduce(delta)
+ * between scopa_mccfr_traverse and scopa_mccfr_apply.
+ * set_form: 0 (default) = plain stores + system-scope release fence / acquire fence (the textbook protocol); 1 = every access to an
+ * inbox line is a system-scope (sc0 sc1) access ordered by s_waitcnt alone: 4.5 us less per iteration, no cache maintenance; use
+ * it only after it has been validated against a collective on the topology at hand (scopa_amd/distributed.py does that). */
 int32_t scopa_p2p_create(scopa_ctx *ctx, int32_t rank, int32_t world, uint8_t handle_out[64]);
 int32_t scopa_p2p_connect(scopa_ctx *ctx, const uint8_t *handles /*[world][64]*/);
 int32_t scopa_p2p_allreduce_delta(scopa_ctx *ctx);
+int32_t scopa_p2p_set_form(scopa_ctx *ctx, int32_t light);
+int32_t scopa_p2p_set_budget(scopa_ctx *ctx, double seconds);   /* wait budget of later exchanges, 1 ms .. 60 s */
 /* n_iters whole iterations of this rank's slice [b0, b0+nb) of the global traversal ids, the exchange fused into the
  * reduce+apply kernel (two launches per iteration, as on one GPU); all ranks call it with the same n_iters */
 int32_t scopa_mccfr_iterate_sharded(scopa_ctx *ctx, uint32_t b0, uint32_t nb, uint32_t n_iters);

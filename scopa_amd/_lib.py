@@ -11,7 +11,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libscopa_hip.so")
 
-SCOPA_OK, SCOPA_EINVAL, SCOPA_ENODEV, SCOPA_EHIP, SCOPA_ESTATE, SCOPA_ENOMEM, SCOPA_ELIMIT = 0, -1, -2, -3, -4, -5, -6
+SCOPA_OK, SCOPA_EINVAL, SCOPA_ENODEV, SCOPA_EHIP, SCOPA_ESTATE, SCOPA_ENOMEM, SCOPA_ELIMIT, SCOPA_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 N_NODES, N_DECISION, N_TERMINAL = 2229, 1653, 576
 
 # every symbol include/scopa.h declares (tests check that the library exports all of them)
@@ -32,7 +32,7 @@ SYMBOLS = [
     "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts",
     "scopa_team_state_init", "scopa_team_state_step", "scopa_team_state_legal", "scopa_team_state_rewards_x2", "scopa_team_state_infoset_string",
     "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts",
-    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device",
+    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_set_form", "scopa_p2p_set_budget", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device",
 ]
 
 
@@ -155,6 +155,8 @@ def lib():
         "scopa_p2p_create": (i32, [vp, i32, i32, vp]),
         "scopa_p2p_connect": (i32, [vp, vp]),
         "scopa_p2p_allreduce_delta": (i32, [vp]),
+        "scopa_p2p_set_form": (i32, [vp, i32]),
+        "scopa_p2p_set_budget": (i32, [vp, C.c_double]),
         "scopa_p2p_status": (i32, [vp, C.POINTER(i32), C.POINTER(u64)]),
         "scopa_p2p_destroy": (i32, [vp]),
         "scopa_team_state_init": (i32, [vp, vp]),
@@ -447,6 +449,13 @@ class Context:
         t, n = C.c_int32(), C.c_uint64()
         self._ck(self._L.scopa_p2p_status(self._h, C.byref(t), C.byref(n)), "scopa_p2p_status")
         return t.value, n.value
+
+    def p2p_set_form(self, light):
+        """False (default): plain accesses + system-scope fences; True: sc0 sc1 accesses ordered by s_waitcnt (validate first)"""
+        self._ck(self._L.scopa_p2p_set_form(self._h, 1 if light else 0), "scopa_p2p_set_form")
+
+    def p2p_set_budget(self, seconds):
+        self._ck(self._L.scopa_p2p_set_budget(self._h, float(seconds)), "scopa_p2p_set_budget")
 
     def p2p_destroy(self):
         self._ck(self._L.scopa_p2p_destroy(self._h), "scopa_p2p_destroy")

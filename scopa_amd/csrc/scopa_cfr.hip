@@ -146,12 +146,7 @@ static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, 
     const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 3;
     const size_t static_lds = 1656 * 2 + kTerminal + sizeof(uint32_t) * kDecision + 256;
     const int use_lds = lds + static_lds <= (size_t)ctx->lds_limit ? 1 : 0;
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cfr_exact), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        ctx->lds_limit - (int)static_lds));
-        attr_set = true;
-    }
+    SC_LDS_ATTR(ctx, scopa::kLdsCfrExact, k_cfr_exact, ctx->lds_limit - (int)static_lds);
     hipLaunchKernelGGL(k_cfr_exact, dim3(1), dim3(256), use_lds ? lds : 0, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                        ctx->d_regret, ctx->d_strat, ctx->d_local, ctx->n_infosets, n_traversals, first_traverser,
                        ctx->d_scratch, ctx->d_counters, use_lds, ctx->d_visit, ctx->d_meta, start_depth, start_idx, r0, r1);

@@ -71,6 +71,7 @@ struct scopa_ctx {
 
     int lds_limit = 160 * 1024;
     int n_cus = 256;
+    uint32_t lds_attr_done = 0;  // kernels whose dynamic-LDS cap was raised on THIS context's device (scopa::ensure_lds_attr)
 };
 
 namespace scopa {
@@ -95,6 +96,21 @@ inline int32_t fail(scopa_ctx *ctx, int32_t code, const char *what, hipError_t e
     } while (0)
 
 int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
+
+// hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, so the "already raised" flag lives in the
+// context (one context = one device), not in a process-wide static: a second context on another device raises it again.
+enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 2u, kLdsCfrExact = 4u, kLdsExploit = 8u, kLdsCfrSync = 16u, kLdsSdcfr = 32u, kLdsMulti = 64u };
+inline int32_t ensure_lds_attr(scopa_ctx *ctx, uint32_t kernel_bit, const void *fn, int bytes) {
+    if (ctx->lds_attr_done & kernel_bit) return SCOPA_OK;
+    SC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
+    ctx->lds_attr_done |= kernel_bit;
+    return SCOPA_OK;
+}
+#define SC_LDS_ATTR(ctx, bit, kernel, bytes)                                                                     \
+    do {                                                                                                         \
+        const int32_t rc__ = scopa::ensure_lds_attr((ctx), (bit), reinterpret_cast<const void *>(kernel), (bytes)); \
+        if (rc__ != SCOPA_OK) return rc__;                                                                       \
+    } while (0)
 // (start, stop) events to attach to a sampled launch of the dominant kernel when profiling is on
 bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 void p2p_release(scopa_ctx *ctx);

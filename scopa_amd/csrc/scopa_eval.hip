@@ -122,12 +122,7 @@ extern "C" int32_t scopa_exploitability(scopa_ctx *ctx, const double *h_policy, 
     if (h_policy) SC_HIP(ctx, hipMemcpyAsync(d_pin, h_policy, pol_bytes, hipMemcpyHostToDevice, ctx->stream));
     const size_t lds = pol_bytes * 2 + sizeof(double) * kNodes * 2 + sizeof(int) * (size_t)I + 1656 * 2;
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_exploitability: tables do not fit in LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_exploitability), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        ctx->lds_limit));
-        attr_set = true;
-    }
+    SC_LDS_ATTR(ctx, scopa::kLdsExploit, k_exploitability, ctx->lds_limit);
     hipLaunchKernelGGL(k_exploitability, dim3(1), dim3(1024), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key,
                        ctx->d_strat, h_policy ? d_pin : nullptr, I, d_out, h_policy_out ? d_pout : nullptr, (const int32_t *)nullptr);
     SC_HIP(ctx, hipGetLastError());
@@ -267,11 +262,7 @@ int32_t scopa_cfr_sync_iterate(scopa_ctx *ctx, int32_t n_iters) {
     SC_HIP(ctx, hipSetDevice(ctx->device));
     const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 2 + sizeof(double) * kNodes * 3 + 1656 * 2;
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_cfr_sync_iterate: tables do not fit in LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_cfr_sync), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
-        attr_set = true;
-    }
+    SC_LDS_ATTR(ctx, scopa::kLdsCfrSync, k_cfr_sync, ctx->lds_limit);
     hipLaunchKernelGGL(k_cfr_sync, dim3(1), dim3(1024), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_regret,
                        ctx->d_strat, ctx->n_infosets, (int)n_iters, ctx->d_counters, ctx->d_visit, ctx->d_meta);
     SC_HIP(ctx, hipGetLastError());

@@ -65,6 +65,7 @@ const char *scopa_strerror(int32_t status) {
         case SCOPA_ESTATE: return "call order violated";
         case SCOPA_ENOMEM: return "out of memory";
         case SCOPA_ELIMIT: return "problem exceeds a compiled-in capacity";
+        case SCOPA_ETIMEOUT: return "a peer did not answer within the wait budget";
         default: return "unknown status";
     }
 }

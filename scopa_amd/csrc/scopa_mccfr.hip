@@ -804,12 +804,7 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     const int threads = waves * 64;
     const size_t lds = traverse_lds_bytes(ctx->n_infosets, waves);
     SC_REQUIRE(ctx, lds + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_traverse),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - kStaticLds));
-        attr_set = true;
-    }
+    SC_LDS_ATTR(ctx, scopa::kLdsTraverse, k_mccfr_traverse, ctx->lds_limit - kStaticLds);
     const uint32_t n_passes = (nb + waves - 1) / waves;  // one traversal pair per wavefront pass
     const uint32_t grid = n_passes < (uint32_t)ctx->n_cus ? n_passes : (uint32_t)ctx->n_cus;
     const int n_cells = ctx->n_infosets * 5;
@@ -875,7 +870,7 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
     };
     while (waves > 1 && need(waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
     SC_REQUIRE(ctx, need(waves) + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
-    SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_multi), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - kStaticLds));
+    SC_LDS_ATTR(ctx, scopa::kLdsMulti, k_mccfr_multi, ctx->lds_limit - kStaticLds);
     hipLaunchKernelGGL(k_mccfr_multi, dim3(n_deals), dim3(waves * 64), need(waves), ctx->stream, d_infoset, d_payoff, d_key, d_regret, d_strat,
                        d_meta, d_visit, d_counters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, n_iters, batch);
     SC_HIP(ctx, hipGetLastError());
@@ -981,7 +976,9 @@ int32_t scopa_mccfr_iterate_sharded(scopa_ctx *ctx, uint32_t b0, uint32_t nb, ui
         const int32_t rc = launch_traverse(ctx, ctx->iteration, b0, nb, /*fuse_apply=*/true, /*exchange=*/true);
         if (rc != SCOPA_OK) return rc;
     }
-    return SCOPA_OK;
+    // a peer that never answered must not go unnoticed: the launches above applied whatever their bounded waits were left with
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return scopa::p2p_check(ctx, "scopa_mccfr_iterate_sharded");
 }
 
 int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_uniforms, int64_t n_uniforms, int64_t *consumed) {
@@ -993,13 +990,7 @@ int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_unif
     long long *d_consumed = reinterpret_cast<long long *>(ctx->d_scratch);
     double *d_u = ctx->d_scratch + 8;
     if (n_uniforms) SC_HIP(ctx, hipMemcpyAsync(d_u, h_uniforms, ubytes, hipMemcpyHostToDevice, ctx->stream));
-    {
-        static bool attr_set = false;
-        if (!attr_set) {
-            SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_mccfr_replay), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit - 12 * 1024));
-            attr_set = true;
-        }
-    }
+    SC_LDS_ATTR(ctx, scopa::kLdsReplay, k_mccfr_replay, ctx->lds_limit - 12 * 1024);
     hipLaunchKernelGGL(k_mccfr_replay, dim3(1), dim3(256), (size_t)ctx->n_infosets * 64, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_key,
                        ctx->d_regret, ctx->d_strat, d_u, (long long)n_uniforms, (int)n_iters, ctx->d_counters, d_consumed,
                        ctx->d_visit, ctx->d_meta);

@@ -20,6 +20,8 @@ constexpr int kP2PLineDoubles = 8;
 struct P2PArgs {
     double *inbox[kP2PMaxWorld];   // every rank's inbox as mapped in this process ([rank] = the local one)
     unsigned int *err;             // waits that gave up (device word; non-zero makes all later waits fall through)
+    unsigned int *err_host;        // the same verdict in pinned host memory: the host reads it after a stream sync, without a copy
+    int light;                     // 0: plain accesses + system-scope fences; 1: sc0 sc1 accesses ordered by s_waitcnt (see below)
     unsigned long long seq;        // sequence number of this exchange (1, 2, ...); parity selects the line set
     unsigned long long budget;     // wait budget in 100 MHz wall-clock ticks
     int rank, world;
@@ -35,16 +37,14 @@ __device__ __forceinline__ double *p2p_line(double *inbox, int par, int world, i
 // [kP2PMaxWorld][5] of the lane's row.  On return d is the sum over ranks, added in rank order (identical bits on every
 // rank), in all 16 lanes of the row.  Must be called by all 64 lanes of the wavefront.
 //
-// Two forms of the same protocol.  kP2PLight = false is the textbook one: plain stores, __threadfence_system() (L2
-// write-back + invalidate at system scope), release-store of the sequence word; poll, system-scope acquire fence, plain
-// loads.  kP2PLight = true makes every access to the line a system-scope (sc0 sc1) access -- inbox memory is fine-grained,
-// such accesses go to memory, not through this XCD's L2 -- ordered by s_waitcnt alone: the sequence word is issued only
-// after the data stores of the same line were acknowledged (vmcnt(0)), and the data loads are issued only after the
-// sequence word was seen.  No cache maintenance, so the kernel's L2 contents (slabs, tables) are left alone.
-#ifndef SCOPA_P2P_LIGHT
-#define SCOPA_P2P_LIGHT 1
-#endif
-constexpr bool kP2PLight = SCOPA_P2P_LIGHT != 0;
+// Two forms of the same protocol, chosen per exchange by P2PArgs.light (wave-uniform).  light = 0 is the textbook one and
+// the library's default: plain stores, __threadfence_system() (L2 write-back + invalidate at system scope), release-store of
+// the sequence word; poll, system-scope acquire fence, plain loads.  light = 1 makes every access to the line a system-scope
+// (sc0 sc1) access -- inbox memory is fine-grained, such accesses go to memory, not through this XCD's L2 -- ordered by
+// s_waitcnt alone: the sequence word is issued only after the data stores of the same line were acknowledged (vmcnt(0)),
+// and the data loads are issued only after the sequence word was seen.  No cache maintenance, so the kernel's L2 contents
+// (slabs, tables) are left alone; it relies on the fabric acknowledging a remote store only once it is visible at its
+// destination, which is why callers switch it on only after validating it on their topology (scopa_p2p_set_form).
 
 typedef double p2p_v2f64 __attribute__((ext_vector_type(2)));
 
@@ -54,7 +54,7 @@ __device__ __forceinline__ void p2p_exchange_wave4(const P2PArgs &a, int row, bo
         double *out = p2p_line(a.inbox[q], par, a.world, a.rank, row);        // my row, in peer q's inbox
         const double *in = p2p_line(a.inbox[a.rank], par, a.world, q, row);   // sender q's row, in my inbox
         double v[5];
-        if constexpr (kP2PLight) {
+        if (a.light) {
             for (int k = 0; k < 5; k++) __hip_atomic_store(out + k, d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                  // the write-through stores are acknowledged (gfx9: vmcnt counts stores)
             __hip_atomic_store(reinterpret_cast<unsigned long long *>(out + 5), a.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -68,10 +68,14 @@ __device__ __forceinline__ void p2p_exchange_wave4(const P2PArgs &a, int row, bo
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(reinterpret_cast<const unsigned long long *>(in + 5), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) < a.seq) {
             if (__hip_atomic_load(a.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;   // an earlier wait already gave up
-            if (wall_clock64() - t0 > a.budget) { atomicAdd(a.err, 1u); break; }
+            if (wall_clock64() - t0 > a.budget) {
+                atomicAdd(a.err, 1u);
+                __hip_atomic_store(a.err_host, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+                break;
+            }
             __builtin_amdgcn_s_sleep(1);
         }
-        if constexpr (kP2PLight) {
+        if (a.light) {
             p2p_v2f64 lo, hi;
             double last;
             asm volatile("global_load_dwordx4 %0, %3, off sc0 sc1\n\t"
@@ -101,5 +105,7 @@ __device__ __forceinline__ void p2p_exchange_wave4(const P2PArgs &a, int row, bo
 
 // host side (scopa_p2p.hip): arguments of the NEXT exchange (increments the sequence number); false if not connected
 bool p2p_next_args(struct ::scopa_ctx *ctx, P2PArgs *out);
+// host side, after a stream sync: SCOPA_ETIMEOUT (and ctx->err) if any wait of the context's exchange ever gave up
+int32_t p2p_check(struct ::scopa_ctx *ctx, const char *where);
 
 }  // namespace scopa

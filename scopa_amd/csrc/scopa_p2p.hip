@@ -34,6 +34,10 @@ struct scopa_p2p {
     size_t bytes = 0;
     unsigned long long seq = 0;
     unsigned int *d_err = nullptr;
+    unsigned int *h_err = nullptr;          // pinned host word, set by the first wait that gives up ...
+    unsigned int *h_err_dev = nullptr;      // ... and its device-side address
+    unsigned long long budget = 500000000ull;  // 5 s of the 100 MHz wall clock
+    int light = 0;
     bool connected = false;
 };
 
@@ -58,8 +62,20 @@ void p2p_release(scopa_ctx *ctx) {
     for (int r = 0; r < p->world; r++) if (p->opened[r] && p->peer[r]) (void)hipIpcCloseMemHandle(p->peer[r]);
     if (p->local) (void)hipFree(p->local);
     if (p->d_err) (void)hipFree(p->d_err);
+    if (p->h_err) (void)hipHostFree(p->h_err);
     delete p;
     ctx->p2p = nullptr;
+}
+
+// after the stream has been synchronised: did any wait of this exchange object give up?
+int32_t p2p_check(scopa_ctx *ctx, const char *where) {
+    scopa_p2p *p = ctx->p2p;
+    if (p && p->h_err && *static_cast<volatile unsigned int *>(p->h_err) != 0u) {
+        snprintf(ctx->err, sizeof ctx->err, "%s: a peer did not answer within %.3f s; sums were applied without it -- the tables of this "
+                 "context are invalid (re-create the exchange and restore the tables)", where, (double)p->budget * 1e-8);
+        return SCOPA_ETIMEOUT;
+    }
+    return SCOPA_OK;
 }
 
 bool p2p_next_args(scopa_ctx *ctx, P2PArgs *out) {
@@ -67,8 +83,10 @@ bool p2p_next_args(scopa_ctx *ctx, P2PArgs *out) {
     if (!p || !p->connected) return false;
     for (int r = 0; r < kP2PMaxWorld; r++) out->inbox[r] = static_cast<double *>(r < p->world ? p->peer[r] : nullptr);
     out->err = p->d_err;
+    out->err_host = p->h_err_dev;
+    out->light = p->light;
     out->seq = ++p->seq;
-    out->budget = 500000000ull;  // 5 s of the 100 MHz wall clock
+    out->budget = p->budget;
     out->rank = p->rank; out->world = p->world;
     return true;
 }
@@ -89,6 +107,9 @@ int32_t scopa_p2p_create(scopa_ctx *ctx, int32_t rank, int32_t world, uint8_t ha
     hipError_t e = hipExtMallocWithFlags(&p->local, p->bytes, hipDeviceMallocFinegrained);
     if (e != hipSuccess) { scopa::p2p_release(ctx); return fail(ctx, SCOPA_EHIP, "scopa_p2p_create: hipExtMallocWithFlags(fine-grained)", e); }
     if ((e = hipMalloc(&p->d_err, 64)) != hipSuccess) { scopa::p2p_release(ctx); return fail(ctx, SCOPA_EHIP, "scopa_p2p_create: hipMalloc", e); }
+    if ((e = hipHostMalloc(reinterpret_cast<void **>(&p->h_err), 64, hipHostMallocMapped)) != hipSuccess) { scopa::p2p_release(ctx); return fail(ctx, SCOPA_EHIP, "scopa_p2p_create: hipHostMalloc", e); }
+    memset(p->h_err, 0, 64);
+    if ((e = hipHostGetDevicePointer(reinterpret_cast<void **>(&p->h_err_dev), p->h_err, 0)) != hipSuccess) { scopa::p2p_release(ctx); return fail(ctx, SCOPA_EHIP, "scopa_p2p_create: hipHostGetDevicePointer", e); }
     if ((e = hipMemsetAsync(p->local, 0, p->bytes, ctx->stream)) != hipSuccess || (e = hipMemsetAsync(p->d_err, 0, 64, ctx->stream)) != hipSuccess ||
         (e = hipStreamSynchronize(ctx->stream)) != hipSuccess) { scopa::p2p_release(ctx); return fail(ctx, SCOPA_EHIP, "scopa_p2p_create: clearing the inbox", e); }
     hipIpcMemHandle_t h;
@@ -125,6 +146,21 @@ int32_t scopa_p2p_allreduce_delta(scopa_ctx *ctx) {
     scopa::p2p_next_args(ctx, &a);
     hipLaunchKernelGGL(k_p2p_rows, dim3((ctx->n_infosets + 3) / 4), dim3(64), 0, ctx->stream, a, ctx->d_delta, ctx->n_infosets);
     SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return scopa::p2p_check(ctx, "scopa_p2p_allreduce_delta");
+}
+
+int32_t scopa_p2p_set_form(scopa_ctx *ctx, int32_t light) {
+    if (!ctx || (light != 0 && light != 1)) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->p2p != nullptr, SCOPA_ESTATE, "scopa_p2p_set_form: no exchange");
+    ctx->p2p->light = light;
+    return SCOPA_OK;
+}
+
+int32_t scopa_p2p_set_budget(scopa_ctx *ctx, double seconds) {
+    if (!ctx || !(seconds >= 1e-3 && seconds <= 60.0)) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->p2p != nullptr, SCOPA_ESTATE, "scopa_p2p_set_budget: no exchange");
+    ctx->p2p->budget = (unsigned long long)(seconds * 1e8);
     return SCOPA_OK;
 }
 

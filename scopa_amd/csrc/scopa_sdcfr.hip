@@ -624,11 +624,7 @@ extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser,
     const int threads = waves * 64;
     const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
     SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
-    static bool attr_set = false;
-    if (!attr_set) {
-        SC_HIP(ctx, hipFuncSetAttribute(reinterpret_cast<const void *>(k_sdcfr_traverse), hipFuncAttributeMaxDynamicSharedMemorySize, ctx->lds_limit));
-        attr_set = true;
-    }
+    SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse, ctx->lds_limit);
     const int passes = (batch + waves - 1) / waves;
     const int grid = passes < ctx->n_cus ? passes : ctx->n_cus;
     hipLaunchKernelGGL(k_sdcfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_states, ctx->d_payoff, d_weights, (int)traverser,

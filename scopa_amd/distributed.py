@@ -46,12 +46,15 @@ class ShardedMCCFR:
             self.iteration(batch_total)
 
 
-def connect_peer_exchange(ctx, rank, world, device, rounds=3):
+def connect_peer_exchange(ctx, rank, world, device, rounds=32, form="auto"):
     """Set up the library's one-shot peer-memory all-reduce (scopa_p2p_*, include/scopa.h) between the `world` ranks of an
     initialised torch.distributed group (one process per GPU, one node) and PROVE it before use: `rounds` exchanges of
     rank-distinct random payloads must equal, bit for bit, the rank-ordered sum computed from an all-gather through
-    torch.distributed (RCCL), on every rank, with no wait timing out.  Returns (ok, reason); every rank returns the same
-    answer (the verdict itself is all-reduced), so the ranks switch paths together."""
+    torch.distributed (RCCL), on every rank, with no wait timing out.  form: "fenced" = the textbook protocol (system-scope
+    release / acquire fences), "light" = sc0 sc1 accesses ordered by s_waitcnt alone (4.5 us less per iteration), "auto" =
+    light if it passes the validation on this topology, else fenced (validated the same way).  Returns (ok, reason); every
+    rank returns the same answer (each verdict is itself all-reduced), so the ranks switch paths together; the form in
+    use is left in ctx.exchange_form."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -65,61 +68,79 @@ def connect_peer_exchange(ctx, rank, world, device, rounds=3):
             dist.all_reduce(f, op=dist.ReduceOp.MIN)
         return bool(f.item())
 
-    reason, handle = "", np.zeros(64, np.uint8)
-    try:
-        handle = ctx.p2p_create(rank, world)
-        ok = True
-    except _lib.ScopaError as e:
-        ok, reason = False, f"create: {e}"
-    mine = torch.from_numpy(handle.copy()).to(device)
-    parts = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
-    if world > 1:
-        dist.all_gather(parts, mine)
-    else:
-        parts = [mine]
-    if not agree(ok):
-        return False, reason or "a peer could not create its inbox"
-    try:
-        ctx.p2p_connect(np.stack([p.cpu().numpy() for p in parts]))
-    except _lib.ScopaError as e:
-        ok, reason = False, f"connect: {e}"
-    if not agree(ok):
-        ctx.p2p_destroy()
-        return False, reason or "a peer could not map the inboxes"
-    n = ctx.n_infosets * 5
-    for k in range(rounds):
-        x = np.random.RandomState(1000 * k + rank).standard_normal(n) * 10.0 ** np.random.RandomState(k).randint(-6, 7)
-        got = None
-        try:                                   # a local failure must not skip the collectives below (the peers are in them)
-            ctx.mccfr_delta_set(x.reshape(-1, 5))
-            ctx.p2p_allreduce_delta()
-            got = ctx.mccfr_delta_get().reshape(-1)
+    def create_and_connect():
+        reason, handle, ok = "", np.zeros(64, np.uint8), True
+        try:
+            handle = ctx.p2p_create(rank, world)
         except _lib.ScopaError as e:
-            ok, reason = False, f"round {k}: {e}"
-        xs = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(world)]
+            ok, reason = False, f"create: {e}"
+        mine = torch.from_numpy(handle.copy()).to(device)
+        parts = [torch.zeros(64, dtype=torch.uint8, device=device) for _ in range(world)]
         if world > 1:
-            dist.all_gather(xs, torch.from_numpy(x).to(device))
+            dist.all_gather(parts, mine)
         else:
-            xs = [torch.from_numpy(x).to(device)]
-        want = xs[0].cpu().numpy().copy()
-        for r in range(1, world):
-            want = want + xs[r].cpu().numpy()          # rank order, one rounding per add: what p2p_exchange_row does
-        if got is not None and not np.array_equal(got, want):
-            ok, reason = False, f"round {k}: sum differs from the rank-ordered reference"
-    try:
-        timeouts, _ = ctx.p2p_status()
-        if timeouts:
-            ok, reason = False, f"{timeouts} wait(s) timed out"
-        ctx.mccfr_delta_set(np.zeros((ctx.n_infosets, 5)))
-    except _lib.ScopaError as e:
-        ok, reason = False, f"status: {e}"
-    if not agree(ok):
+            parts = [mine]
+        if not agree(ok):
+            return False, reason or "a peer could not create its inbox"
+        try:
+            ctx.p2p_connect(np.stack([p.cpu().numpy() for p in parts]))
+        except _lib.ScopaError as e:
+            ok, reason = False, f"connect: {e}"
+        if not agree(ok):
+            ctx.p2p_destroy()
+            return False, reason or "a peer could not map the inboxes"
+        return True, ""
+
+    def validate():
+        ok, reason = True, ""
+        n = ctx.n_infosets * 5
+        ctx.p2p_set_budget(2.0)
+        for k in range(rounds):
+            x = np.random.RandomState(1000 * k + rank).standard_normal(n) * 10.0 ** np.random.RandomState(k).randint(-6, 7)
+            got = None
+            try:                                   # a local failure must not skip the collectives below (the peers are in them)
+                ctx.mccfr_delta_set(x.reshape(-1, 5))
+                ctx.p2p_allreduce_delta()          # raises on a wait that gave up (SCOPA_ETIMEOUT)
+                got = ctx.mccfr_delta_get().reshape(-1)
+            except _lib.ScopaError as e:
+                ok, reason = False, f"round {k}: {e}"
+            xs = [torch.zeros(n, dtype=torch.float64, device=device) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(xs, torch.from_numpy(x).to(device))
+            else:
+                xs = [torch.from_numpy(x).to(device)]
+            want = xs[0].cpu().numpy().copy()
+            for r in range(1, world):
+                want = want + xs[r].cpu().numpy()          # rank order, one rounding per add: what p2p_exchange_wave4 does
+            if got is not None and not np.array_equal(got, want):
+                ok, reason = False, f"round {k}: sum differs from the rank-ordered reference"
+        try:
+            timeouts, _ = ctx.p2p_status()
+            if timeouts:
+                ok, reason = False, f"{timeouts} wait(s) timed out"
+            ctx.mccfr_delta_set(np.zeros((ctx.n_infosets, 5)))
+            ctx.p2p_set_budget(5.0)
+        except _lib.ScopaError as e:
+            ok, reason = False, f"status: {e}"
+        return ok, reason
+
+    why = ""
+    for light in {"light": [True], "fenced": [False], "auto": [True, False]}[form]:
+        ok, why = create_and_connect()
+        if not ok:
+            return False, why
+        ctx.p2p_set_form(light)
+        ok, why = validate()
+        name = "light" if light else "fenced"
+        if agree(ok):
+            ctx.exchange_form = name
+            return True, f"validated: {name} form, {rounds} exchanges bit-equal to the rank-ordered sum of an all-gather"
+        why = f"{name} form: " + (why or "a peer failed validation")
         ctx.p2p_destroy()
-        return False, reason or "a peer failed validation"
-    return True, "validated"
+    return False, why
 
 
-def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl"):
+def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl", exchange_form="auto"):
     """Context on `local_rank` launching on a dedicated torch stream, with a torch-owned delta tensor bound as the
     all-reduce payload.  Returns (ctx, delta_tensor, stream, all_reduce).  exchange: "rccl" = torch.distributed.all_reduce;
     "p2p" = the library's one-shot peer-memory all-reduce (raises if it cannot be validated); "auto" = p2p if it validates on
@@ -141,9 +162,9 @@ def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl"):
         with torch.cuda.stream(stream):
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)
 
-    ctx.exchange, ctx.exchange_note = ("rccl" if world > 1 else "none"), ""
+    ctx.exchange, ctx.exchange_note, ctx.exchange_form = ("rccl" if world > 1 else "none"), "", None
     if world > 1 and exchange in ("auto", "p2p"):
-        ok, why = connect_peer_exchange(ctx, rank, dist.get_world_size(), torch.device(f"cuda:{local_rank}"))
+        ok, why = connect_peer_exchange(ctx, rank, dist.get_world_size(), torch.device(f"cuda:{local_rank}"), form=exchange_form)
         ctx.exchange_note = why
         if ok:
             ctx.exchange = "p2p"

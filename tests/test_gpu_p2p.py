@@ -46,8 +46,8 @@ def test_odd_sized_delta_is_exchanged_whole(ctx, sl):
     ctx.set_deal(sl.deal_py_seed(42))
 
 
-def _run_ranks(tmp_path, world, batch_total, iters, mode, port):
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+def _run_ranks(tmp_path, world, batch_total, iters, mode, port, form="auto"):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", SCOPA_TEST_P2P_FORM=form)
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "p2p_worker.py"), str(r), str(world), str(port),
                                str(tmp_path), str(batch_total), str(iters), mode], env=env) for r in range(world)]
     try:
@@ -60,7 +60,8 @@ def _run_ranks(tmp_path, world, batch_total, iters, mode, port):
     res = [np.load(tmp_path / f"rank{r}.npz") for r in range(world)]
     assert all(bool(r["ok"]) for r in res), [str(r["why"]) for r in res]
     assert [int(r["timeouts"]) for r in res] == [0] * world
-    assert [int(r["exchanges"]) for r in res] == [3 + iters] * world           # 3 validation rounds + the run
+    assert [int(r["exchanges"]) for r in res] == [32 + iters] * world          # 32 validation rounds + the run
+    assert len({str(r["form"]) for r in res}) == 1 and str(res[0]["form"]) in (("light", "fenced") if form == "auto" else (form,))
     for r in res[1:]:                                    # rank-ordered sums: replicas are bit-identical
         assert np.array_equal(r["R"], res[0]["R"]) and np.array_equal(r["S"], res[0]["S"])
     assert sum(int(r["visits"]) for r in res) == 463 * batch_total * iters
@@ -83,6 +84,32 @@ def test_two_ranks_free_running_fused_and_split(ctx, sl, tmp_path):
     # the same global traversal ids in one process: equal up to the summation order of the partial deltas
     R, S = _single_process(ctx, sl, batch_total, iters)
     assert np.allclose(res[0]["R"], R, rtol=1e-12, atol=1e-12) and np.allclose(res[0]["S"], S, rtol=1e-12, atol=1e-12)
+
+
+def test_two_ranks_free_running_fenced_form(ctx, sl, tmp_path):
+    """The library's default protocol form (plain accesses + system-scope release/acquire fences), forced."""
+    batch_total, iters = 515, 4
+    res = _run_ranks(tmp_path, 2, batch_total, iters, "free", 29614, form="fenced")
+    R, S = _single_process(ctx, sl, batch_total, iters)
+    assert np.allclose(res[0]["R"], R, rtol=1e-12, atol=1e-12) and np.allclose(res[0]["S"], S, rtol=1e-12, atol=1e-12)
+
+
+def test_absent_peer_is_reported_not_applied_silently(tmp_path):
+    """A peer that never answers: the bounded waits give up (no hang) and scopa_p2p_allreduce_delta / scopa_mccfr_iterate_sharded
+    / ShardedMCCFR.run all fail with SCOPA_ETIMEOUT, on that call and on every later one."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "tools", "p2p_worker.py"), str(r), "2", "29615", str(tmp_path), "64", "1", "timeout"],
+                              env=env) for r in range(2)]
+    try:
+        for p in procs:
+            assert p.wait(timeout=180) == 0
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    r0 = np.load(tmp_path / "rank0.npz")
+    assert bool(r0["ok"]), str(r0["why"])
+    assert list(r0["statuses"]) == [-7, -7, -7] and int(r0["timeouts"]) > 0
 
 
 def test_three_ranks_lockstep_rank_ordered_sum(ctx, sl, tmp_path):

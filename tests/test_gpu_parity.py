@@ -173,6 +173,81 @@ def test_mccfr_batched_split_invariance(ctx, sl):
     np.testing.assert_allclose(parts[:, :4], whole[:, :4], rtol=1e-12, atol=1e-12)
 
 
+@pytest.mark.parametrize("b0,nb", [(5 * 32768, 32768), (0, 65536)])
+def test_mccfr_config2_rank_shard_vs_oracle(ctx, sl, oracle, b0, nb):
+    """BASELINE configs[2]'s per-rank shape: rank 5 of 8 owns traversal ids [5*32768, 6*32768) of the 262144-id iteration (and the
+    65536-pair launch of bench.py's large-batch figure).  nb > 4096 means every wavefront walks SEVERAL pairs and reuses its scratch
+    (the multi-pass loop of k_mccfr_traverse): the whole launch is compared with the oracle -- visit counts exact, regret deltas to
+    1e-12 -- plus split invariance over the shard (the same ids in three launches of other geometry)."""
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    R, S, L = t.tables()
+    t.cfr_exact(R, S, L, 3)
+    ctx.tables_set(regret=R)
+    seed, it = 0x5C09A, 7
+    ctx.mccfr_seed(seed)
+    ctx.mccfr_traverse(it, b0, nb)
+    d = ctx.mccfr_delta_get()
+    dR, dS, dv, tv = t.mccfr_batched_delta(R, seed, it, b0, nb)
+    assert np.array_equal(d[:, 4], np.rint(dS.sum(1)))
+    assert d[:, 4].sum() == 172 * nb and d[0, 4] == nb
+    scale = max(1.0, np.abs(dR).max())
+    np.testing.assert_allclose(d[:, :4], dR, rtol=1e-12, atol=1e-12 * scale)
+    assert ctx.counters() == (dv, tv) == (463 * nb, 240 * nb)
+    ctx.mccfr_delta_set(np.zeros_like(d))
+    for o, n in ((0, 4097), (4097, 20000), (24097, nb - 24097)):
+        ctx.mccfr_traverse(it, b0 + o, n)
+    parts = ctx.mccfr_delta_get()
+    assert np.array_equal(parts[:, 4], d[:, 4])
+    np.testing.assert_allclose(parts[:, :4], d[:, :4], rtol=1e-12, atol=1e-12 * scale)
+    # a sub-range on its own (ids b0 .. b0+255) is the oracle's delta of exactly those ids
+    ctx.mccfr_delta_set(np.zeros_like(d))
+    ctx.mccfr_traverse(it, b0, 256)
+    sub = ctx.mccfr_delta_get()
+    sR, sS, _, _ = t.mccfr_batched_delta(R, seed, it, b0, 256)
+    assert np.array_equal(sub[:, 4], np.rint(sS.sum(1)))
+    np.testing.assert_allclose(sub[:, :4], sR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(sR).max()))
+
+
+def test_two_contexts_are_independent(sl, oracle):
+    """include/scopa.h: distinct contexts are independent.  Every entry point whose kernel needs more than the default 64 KB of
+    dynamic LDS (the cap is raised per context = per device, not once per process) runs on a first AND on a second context."""
+    try:
+        a, b = sl.Context(0), sl.Context(0)
+    except sl.ScopaError as e:
+        if e.status == sl.SCOPA_ENODEV:
+            pytest.skip("no GPU on this box")
+        raise
+    t = oracle.Tree(seed=42)
+    try:
+        out = []
+        for c in (a, b):
+            c.set_deal(sl.deal_py_seed(42))
+            c.cfr_exact_iterate(2)                                   # k_cfr_exact
+            Rc, Sc, Lc = c.tables_get()
+            e1 = c.exploitability()["exploitability"]                # k_exploitability
+            c.tables_reset()
+            c.cfr_sync_iterate(2)                                    # k_cfr_sync
+            c.tables_reset()
+            u = np.random.RandomState(0).random_sample(463 * 2)
+            assert c.mccfr_replay(2, u) == 463 * 2                   # k_mccfr_replay
+            c.tables_reset()
+            c.mccfr_seed(3)
+            c.mccfr_iterate(96, 2)                                   # k_mccfr_traverse
+            Rm, Sm, _ = c.tables_get()
+            out.append((Rc, Sc, Lc, e1, Rm, Sm))
+        Ro, So, Lo = t.tables()
+        t.cfr_exact(Ro, So, Lo, 2)
+        for Rc, Sc, Lc, e1, Rm, Sm in out:
+            assert np.array_equal(Rc, Ro) and np.array_equal(Sc, So) and np.array_equal(Lc, Lo)
+            assert e1 == t.exploitability(t.average_policy(So))[0]
+        np.testing.assert_allclose(out[0][4], out[1][4], rtol=1e-12, atol=1e-12)
+        np.testing.assert_allclose(out[0][5], out[1][5], rtol=1e-12, atol=1e-12)
+    finally:
+        a.close()
+        b.close()
+
+
 def test_mccfr_full_size_properties(ctx, sl):
     """BASELINE configs[1] size (4096 traversals per traverser): size-independent invariants."""
     ctx.set_deal(sl.deal_py_seed(42))

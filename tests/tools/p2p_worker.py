@@ -27,9 +27,23 @@ def main():
         def refuse2(*a, **k):
             raise _lib.ScopaError(-3, "scopa_p2p_connect (simulated failure)")
         ctx.p2p_connect = refuse2
-    ok, why = connect_peer_exchange(ctx, rank, world, torch.device("cuda:0"))
-    res = dict(ok=ok, why=why)
-    if ok:
+    form = os.environ.get("SCOPA_TEST_P2P_FORM", "auto")
+    ok, why = connect_peer_exchange(ctx, rank, world, torch.device("cuda:0"), rounds=32, form=form)
+    res = dict(ok=ok, why=why, form=str(getattr(ctx, "exchange_form", None)))
+    if ok and mode == "timeout":
+        # rank 1 never takes part in the next exchange: rank 0's bounded waits give up, and the library must SAY so -- on the call
+        # that timed out and on every later one (the tables have had partial sums applied)
+        statuses = []
+        if rank == 0:
+            ctx.p2p_set_budget(0.05)
+            for call in (ctx.p2p_allreduce_delta, lambda: ctx.mccfr_iterate_sharded(0, 64, 1), lambda: ShardedMCCFR(ctx, 0, world, fused_exchange=True).run(128, 2)):
+                try:
+                    call()
+                    statuses.append(0)
+                except _lib.ScopaError as e:
+                    statuses.append(e.status)
+        res.update(statuses=np.array(statuses), timeouts=ctx.p2p_status()[0])
+    elif ok:
         if mode == "free":
             # first half: the fused form (exchange inside the reduce+apply kernel, in-library loop); second half: the split form
             # (traverse+reduce, stand-alone row exchange, apply) -- both are product paths over the same inbox protocol
