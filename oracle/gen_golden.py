@@ -15,6 +15,8 @@ Fixtures (consumers: tests/, oracle pinning):
   playouts.json       random action strings incl. ILLEGAL actions (silent no-op)  (mini_scopa_game.py:140-167)
   vanilla_cfr.npz     CFRTrainer tables after 1,2,5,50,200 iterations             (vanilla_cfr.py:56-120)
   mccfr.npz           MCCFRTrainer tables under np.random.seed(k)                 (mc_cfr.py:37-99)
+  MiniScopa_MCCFR_data.reference.json  the reference's committed 10-run MCCFR experiment output (experiment_tracker.py:82-158)
+  mccfr_frozen.npz    MCCFRTrainer._sample driven with frozen strategies and path-keyed draws: batched-MCCFR deltas (mc_cfr.py:37-86)
   evaluate.json       evaluate_agent results under np.random.seed(k)              (vanilla_cfr.py:157-216, mc_cfr.py:146-206)
   sdcfr.npz           DeepCFR features/masks/traversal rows with saved weights    (deep_cfr.py:213-365)
 """
@@ -256,6 +258,127 @@ def gen_mccfr(ns):
 
 
 # ----------------------------------------------------------------------------------
+def _philox4x32_10(ctr, key):
+    """Philox4x32-10 (Salmon et al., SC'11; Random123 constants), plain Python integers."""
+    c0, c1, c2, c3 = ctr
+    k0, k1 = key
+    M = 0xFFFFFFFF
+    for _ in range(10):
+        p0, p1 = 0xD2511F53 * c0, 0xCD9E8D57 * c2
+        c0, c1, c2, c3 = ((p1 >> 32) ^ c1 ^ k0) & M, p1 & M, ((p0 >> 32) ^ c3 ^ k1) & M, p0 & M
+        k0, k1 = (k0 + 0x9E3779B9) & M, (k1 + 0xBB67AE85) & M
+    return c0, c1, c2, c3
+
+
+def gen_mccfr_frozen(ns):
+    """Batched MCCFR = B traversals of the reference's own MCCFRTrainer._sample (mc_cfr.py:37-86) against tables FROZEN for the
+    iteration, with path-keyed draws.  The reference's recursion, its regret/strategy update lines and its InfoNode.current_strategy
+    run unmodified; only two things are supplied from outside, by subclassing -- nothing of the reference is edited or restated:
+      * nodes: current_strategy() is answered by a plain reference InfoNode holding the FROZEN regret row, while the node object
+        that _sample updates (`node.regret_sum += ...`, `node.strategy_sum += ...`) starts at zero, i.e. accumulates the DELTA;
+      * np.random.choice(legal, p=sigma) is replaced for the duration of a traversal by numpy's own inverse-cdf arithmetic
+        (cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')) on u = the build's path-keyed Philox uniform of the node at
+        hand: block Philox4x32-10(key = seed; ctr = (ntl + 16 * sum(digit_k << 3k), traversal id, iteration, traverser)), words
+        0,1 at an opponent node, words 2,3 at a traverser node; digit 0 = the sampled child of a traverser node, i+1 = the
+        re-expansion of legal action i, ntl = traverser nodes above.  The node's path is read off the recursion itself."""
+    import pyspiel
+    mc = ns.mc
+    game = pyspiel.load_game("mini_scopa")
+
+    class DeltaNode(mc.InfoNode):
+        def current_strategy(self):
+            return self.frozen_src.current_strategy()
+
+    class FrozenTrainer(mc.MCCFRTrainer):
+        def __init__(self, game, frozen):
+            super().__init__(game)
+            self.frozen, self.stack, self.trace = frozen, [], []
+
+        def _get_node(self, key, legal_actions):
+            if key not in self.info_sets:
+                nd = DeltaNode(np.array(legal_actions))
+                nd.frozen_src = mc.InfoNode(np.array(legal_actions))
+                if key in self.frozen:
+                    nd.frozen_src.regret_sum = self.frozen[key].copy()
+                self.info_sets[key] = nd
+            return self.info_sets[key]
+
+        def _sample(self, state, traversing_player, reach_probs, sampling_probs):
+            if self.stack:
+                par = self.stack[-1]
+                if par["is_trav"]:
+                    digits = par["digits"] + (par["calls"],)
+                    par["calls"] += 1
+                else:
+                    digits = par["digits"]
+            else:
+                digits = ()
+            self.stack.append(dict(digits=digits, calls=0, is_trav=(not state.is_terminal()) and state.current_player() == traversing_player))
+            try:
+                return super()._sample(state, traversing_player, reach_probs, sampling_probs)
+            finally:
+                self.stack.pop()
+
+    def run_case(frozen, seed, iteration, b0, nb):
+        tr = FrozenTrainer(game, frozen)
+        cur = dict(b=0, trav=0)
+
+        def choice(legal, p=None):
+            fr = tr.stack[-1]
+            ntl = len(fr["digits"])
+            code = sum(d << (3 * k) for k, d in enumerate(fr["digits"]))
+            o = _philox4x32_10((ntl + 16 * code, cur["b"], iteration, cur["trav"]), (seed & 0xFFFFFFFF, seed >> 32))
+            a, b = (o[2], o[3]) if fr["is_trav"] else (o[0], o[1])
+            u = ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0
+            cdf = np.asarray(p, np.float64).cumsum()
+            cdf /= cdf[-1]
+            idx = int(cdf.searchsorted(u, side="right"))
+            tr.trace.append(int(legal[idx]))
+            return legal[idx]
+
+        real = np.random.choice
+        np.random.choice = choice
+        try:
+            for b in range(b0, b0 + nb):
+                for p in range(game.num_players()):
+                    cur["b"], cur["trav"] = b, p
+                    tr._sample(game.new_initial_state(), p, np.ones(2), np.ones(2))
+        finally:
+            np.random.choice = real
+        keys = list(tr.info_sets.keys())
+        dR, dS = np.zeros((len(keys), 4)), np.zeros((len(keys), 4))
+        for i, k in enumerate(keys):
+            nd = tr.info_sets[k]
+            dR[i, :nd.regret_sum.size] = nd.regret_sum
+            dS[i, :nd.strategy_sum.size] = nd.strategy_sum
+        return [f"{p}|{s}" for p, s in keys], dR, dS, np.array(tr.trace, np.int8)
+
+    # frozen table A: the reference's own sequential MCCFR after 50 iterations (mixed-sign regrets, some infosets unvisited = zero rows)
+    np.random.seed(3)
+    ref = mc.MCCFRTrainer(game)
+    for _ in range(50):
+        ref.iteration()
+    frozenA = {k: nd.regret_sum.copy() for k, nd in ref.info_sets.items()}
+    out = {}
+    fk = list(frozenA.keys())
+    FR = np.zeros((len(fk), 4))
+    for i, k in enumerate(fk):
+        FR[i, :frozenA[k].size] = frozenA[k]
+    out["frozenA_keys"] = np.array([f"{p}|{s}" for p, s in fk])
+    out["frozenA_regret"] = FR
+    cases = [("A", frozenA, 0x5C09A, 0, 0, 24), ("A", frozenA, 12345678901234567, 7, 5 * 32768, 12), ("Z", {}, 1, 3, 5, 12)]
+    meta = []
+    for n, (tab, frozen, seed, it, b0, nb) in enumerate(cases):
+        keys, dR, dS, trace = run_case(frozen, seed, it, b0, nb)
+        out[f"c{n}_keys"], out[f"c{n}_dregret"], out[f"c{n}_dstrategy"], out[f"c{n}_actions"] = np.array(keys), dR, dS, trace
+        meta.append(dict(table=tab, seed=str(seed), iteration=it, b0=b0, nb=nb))
+        assert trace.size == 463 * nb, trace.size
+        print("mccfr_frozen case", n, meta[-1], "infosets touched", len(keys))
+    out["cases"] = np.array(json.dumps(meta))
+    np.savez_compressed(os.path.join(OUT, "mccfr_frozen.npz"), **out)
+
+
+# ----------------------------------------------------------------------------------
 def gen_evaluate(ns):
     import pyspiel
     game = pyspiel.load_game("mini_scopa")
@@ -493,7 +616,19 @@ def gen_team(ns):
           "max table", max(len(t["table"]) for c in cases for t in c["trail"]))
 
 
-ALL = dict(team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+def gen_tracker(ns):
+    """The reference's committed experiment output (src/experiments/experiments/results/MiniScopa_MCCFR_data.json: 10 MCCFR runs x
+    500 iterations, written by ExperimentTracker.save_data_for_plotting, experiment_tracker.py:82-158) as a fixture: a data file,
+    re-dumped compactly.  tests/test_tracker.py feeds its `runs` to the build's tracker and expects the whole document back."""
+    src = "/root/reference/src/experiments/experiments/results/MiniScopa_MCCFR_data.json"
+    with open(src) as f:
+        d = json.load(f)
+    with open(os.path.join(OUT, "MiniScopa_MCCFR_data.reference.json"), "w") as f:
+        json.dump(d, f, separators=(",", ":"))
+    print("tracker: runs", d["num_runs"], "eval points", len(d["runs"][0]["eval_iterations"]))
+
+
+ALL = dict(tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

@@ -41,6 +41,12 @@ class DeviceMemory:
     def advance(self, rows):
         self.total += rows
 
+    def append(self, feat, regret, mask):
+        """One row at the deque's append position (the ring slot the traversal kernels would write next)."""
+        r = self.write_base
+        self.feat[r], self.regret[r], self.mask[r] = feat, regret, mask
+        self.total += 1
+
     def logical_to_physical(self, idx):
         """deque index (0 = oldest) -> ring row."""
         start = self.total % self.capacity if self.total > self.capacity else 0
@@ -86,6 +92,17 @@ class AdvantageNetwork:
                 x, m = x.unsqueeze(0), m.unsqueeze(0)
             adv = self.net(x)
             return (adv * m - 1e6 * (1 - m)).cpu().numpy()
+
+    def add_experience(self, state_features, advantages, legal_actions_mask):
+        """deep_cfr.py:70-75 for callers that fill the memory themselves: the advantages are divided by max|adv| + 1e-8 when that
+        maximum is positive (float32 arithmetic, as numpy does on the reference's float32 arrays) and the row is appended to the
+        device-resident FIFO ring -- the same ring the traversal kernels write."""
+        adv = torch.as_tensor(np.asarray(advantages), dtype=torch.float32, device=self.device).reshape(-1)
+        peak = adv.abs().max()
+        if float(peak) > 0:
+            adv = adv / (peak + torch.tensor(1e-8, dtype=torch.float32, device=self.device))
+        self.buffer.append(torch.as_tensor(np.asarray(state_features), dtype=torch.float32, device=self.device).reshape(-1), adv,
+                           torch.as_tensor(np.asarray(legal_actions_mask), dtype=torch.float32, device=self.device).reshape(-1))
 
     def sample_indices(self, n, batch_size):
         """The reference's `random.sample(self.buffer, batch_size)` (:88).  There the global `random` stream was last

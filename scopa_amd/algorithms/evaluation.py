@@ -12,6 +12,52 @@ import numpy as np
 from .. import _lib
 
 
+# ---- host evaluator shared by vanilla_cfr.evaluate_agent and mc_cfr.evaluate_agent ---------------------------------------
+class MatchTally:
+    """Running means of a head-to-head match from the trained agent's point of view: reward, scopas of either side.  `result`
+    gives the reference evaluators' return shape (vanilla_cfr.py:157-216): (avg_reward, reward history, scopa_stats)."""
+
+    def __init__(self):
+        self.sums = np.zeros(3)          # reward, trained scopas, opponent scopas
+        self.curves = ([], [], [], [])   # running means of: reward, trained scopas, opponent scopas, scopa difference
+
+    def add(self, reward, own_scopas, opp_scopas):
+        self.sums += (reward, own_scopas, opp_scopas)
+        n = len(self.curves[0]) + 1
+        w, t, o = (x / n for x in self.sums.tolist())
+        for curve, x in zip(self.curves, (w, t, o, (self.sums[1] - self.sums[2]) / n)):
+            curve.append(x)
+
+    def result(self, num_episodes):
+        w, t, o = (x / num_episodes for x in self.sums.tolist())
+        rewards, trained, opponent, diff = self.curves
+        return w, rewards, {"trained_avg": t, "opponent_avg": o, "difference": t - o,
+                            "history": {"trained": trained, "opponent": opponent, "diff": diff},
+                            "data_collected": len(trained) > 0}
+
+
+def play_out(state, seat_policies, choose):
+    """Advance `state` to the end: at every ply the seat's policy gives {action: probability} and `choose(actions, p=probs)`
+    picks (np.random.choice in the reference-compatible evaluators: ONE draw per ply, so a seeded match reproduces the reference's)."""
+    while not state.is_terminal():
+        dist = seat_policies[state.current_player()].action_probabilities(state)
+        state.apply_action(choose(tuple(dist.keys()), p=tuple(dist.values())))
+    return state
+
+
+def head_to_head(game, trained_policy, opponent_policy, num_episodes, choose=None):
+    """`num_episodes` games of trained vs opponent, the trained agent in seat 0 for the first half and in seat 1 afterwards."""
+    choose = np.random.choice if choose is None else choose
+    tally = MatchTally()
+    for episode in range(num_episodes):
+        seat = 0 if episode < num_episodes / 2 else 1
+        lineup = (trained_policy, opponent_policy) if seat == 0 else (opponent_policy, trained_policy)
+        end = play_out(game.new_initial_state(), lineup, choose)
+        scopas = [p.scopas for p in end.env.game.players]
+        tally.add(end.rewards()[seat], scopas[seat], scopas[1 - seat])
+    return tally.result(num_episodes)
+
+
 def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16):
     """-> (avg_reward, scopa_stats) for `trainer`'s average policy (or an explicit [n_infosets][4] table)."""
     import torch

@@ -123,5 +123,5 @@ def evaluate_agent(game, trained_policy, opponent_policy, num_episodes=10000):
     """mc_cfr.py:146-206 (identical to the vanilla evaluator plus the two-player check)."""
     if game.num_players() != 2:
         raise ValueError("evaluate_agent only supports 2-player games")
-    from .vanilla_cfr import evaluate_agent as _eval
-    return _eval(game, trained_policy, opponent_policy, num_episodes)
+    from .evaluation import head_to_head
+    return head_to_head(game, trained_policy, opponent_policy, num_episodes)

@@ -141,40 +141,7 @@ class RandomPolicy(_Policy):
 
 
 def evaluate_agent(game, trained_policy, opponent_policy, num_episodes=10000):
-    """Trained policy vs opponent, seats swapped at half time; same np.random.choice stream as the reference
-    (vanilla_cfr.py:157-216), so a seeded run reproduces its numbers."""
-    total_winnings = 0
-    avg_reward_history = []
-    trained_scopas = 0
-    opponent_scopas = 0
-    scopa_history = {"trained": [], "opponent": [], "diff": []}
-    for episode in range(num_episodes):
-        if episode < num_episodes / 2:
-            agent_seat, policies = 0, [trained_policy, opponent_policy]
-        else:
-            agent_seat, policies = 1, [opponent_policy, trained_policy]
-        state = game.new_initial_state()
-        while not state.is_terminal():
-            player = state.current_player()
-            action_probs = policies[player].action_probabilities(state)
-            actions, probs = zip(*action_probs.items())
-            action = np.random.choice(actions, p=probs)
-            state.apply_action(action)
-        total_winnings += state.rewards()[agent_seat]
-        avg_reward_history.append(total_winnings / (episode + 1))
-        players = state.env.game.players
-        trained_scopas += players[agent_seat].scopas
-        opponent_scopas += players[1 - agent_seat].scopas
-        scopa_history["trained"].append(trained_scopas / (episode + 1))
-        scopa_history["opponent"].append(opponent_scopas / (episode + 1))
-        scopa_history["diff"].append((trained_scopas - opponent_scopas) / (episode + 1))
-    avg_trained_scopas = trained_scopas / num_episodes
-    avg_opponent_scopas = opponent_scopas / num_episodes
-    scopa_stats = {
-        "trained_avg": avg_trained_scopas,
-        "opponent_avg": avg_opponent_scopas,
-        "difference": avg_trained_scopas - avg_opponent_scopas,
-        "history": scopa_history,
-        "data_collected": len(scopa_history["trained"]) > 0,
-    }
-    return total_winnings / num_episodes, avg_reward_history, scopa_stats
+    """-> (avg_reward, running-mean reward history, scopa_stats), the return shape of vanilla_cfr.py:157-216; draws come from the
+    global np.random stream exactly as there (one np.random.choice per ply), so a seeded run reproduces the reference's numbers."""
+    from .evaluation import head_to_head
+    return head_to_head(game, trained_policy, opponent_policy, num_episodes)

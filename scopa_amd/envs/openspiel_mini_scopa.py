@@ -3,7 +3,9 @@
 `MiniScopaState` offers the pyspiel.State surface the reference's solvers and evaluators use --
 current_player, legal_actions, apply_action, is_terminal, is_chance_node, chance_outcomes, rewards, returns,
 information_state_string, clone, history_str -- without needing pyspiel; `load_game("mini_scopa")` stands in for
-pyspiel.load_game.  When pyspiel IS importable the game is also registered with it under the same short name.
+pyspiel.load_game.  Nothing is registered with pyspiel itself (openspiel_mini_scopa.py:166-186 registers a pyspiel.Game
+subclass; these are plain Python classes, and pyspiel is not installed where this package is built and tested): callers
+switch the one `pyspiel.load_game` line to `scopa_amd.envs.load_game`.
 """
 import ctypes as C
 

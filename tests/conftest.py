@@ -73,3 +73,18 @@ def unpack_state(s):
                 table=[(table >> (4 * i)) & 15 for i in range(nt)],
                 ncap=[int(g("ncap")[0]), int(g("ncap")[1])], scopas=[int(g("scopas")[0]), int(g("scopas")[1])],
                 step=int(g("step")))
+
+
+def frozen_case(golden, t_strings, n):
+    """Case n of tests/golden/mccfr_frozen.npz (the reference's own MCCFRTrainer._sample driven with frozen strategies and the
+    build's path-keyed draws, oracle/gen_golden.py:gen_mccfr_frozen) re-indexed by the tree's infoset ids."""
+    g = golden.npz("mccfr_frozen.npz")
+    meta = json.loads(str(g["cases"]))[n]
+    I = len(t_strings)
+    R = np.zeros((I, 4))
+    if meta["table"] == "A":
+        R[[t_strings.index(k.split("|", 1)[1]) for k in g["frozenA_keys"]]] = g["frozenA_regret"]
+    idx = [t_strings.index(k.split("|", 1)[1]) for k in g[f"c{n}_keys"]]
+    dR, dS = np.zeros((I, 4)), np.zeros((I, 4))
+    dR[idx], dS[idx] = g[f"c{n}_dregret"], g[f"c{n}_dstrategy"]
+    return R, int(meta["seed"]), meta["iteration"], meta["b0"], meta["nb"], dR, dS, idx, g[f"c{n}_actions"]

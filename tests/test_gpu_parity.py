@@ -6,7 +6,7 @@ the reference's float64 tables bit-for-bit; the batched (frozen-table) MCCFR mat
 import numpy as np
 import pytest
 
-from conftest import unpack_state
+from conftest import frozen_case, unpack_state
 
 pytestmark = pytest.mark.gpu
 
@@ -124,6 +124,30 @@ def test_mccfr_replay_bit_exact_vs_reference(ctx, sl, golden, seed, iters):
     idx = [keys.index(k.split("|", 1)[1]) for k in m[tag + "_keys"]]
     assert np.array_equal(R[idx], m[tag + "_regret"]) and np.array_equal(S[idx], m[tag + "_strategy"])
     assert ctx.counters() == (463 * iters, 240 * iters)
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_mccfr_batched_delta_vs_reference_sample(ctx, sl, golden, case):
+    """k_mccfr_traverse against the REFERENCE: tests/golden/mccfr_frozen.npz holds the deltas that the reference's own
+    MCCFRTrainer._sample (mc_cfr.py:37-86) accumulates when driven with frozen strategies and the path-keyed Philox draws
+    (oracle/gen_golden.py:gen_mccfr_frozen).  Visit counts exact, strategy deltas = count x sigma(frozen) and regret deltas to 1e-12
+    (the kernel adds the pairs' increments in another order)."""
+    ctx.set_deal(sl.deal_py_seed(42))
+    keys = [sl.key_to_string(k) for k in ctx.tree_export()["infoset_key"]]
+    R, seed, it, b0, nb, dR, dS, idx, _ = frozen_case(golden, keys, case)
+    ctx.tables_set(regret=R, strategy=np.zeros_like(R))
+    ctx.mccfr_seed(seed)
+    ctx.mccfr_traverse(it, b0, nb)
+    d = ctx.mccfr_delta_get()
+    assert np.array_equal(d[:, 4], np.rint(dS.sum(1)))           # every traverser visit adds a probability vector: row sums = visit counts
+    np.testing.assert_allclose(d[:, :4], dR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(dR).max()))
+    assert ctx.counters() == (463 * nb, 240 * nb)
+    ctx.mccfr_apply()                                            # strategy_sum += count * sigma(frozen regret): the reference's `+= 1.0 * sigma` per visit
+    Rn, Sn, _ = ctx.tables_get()
+    np.testing.assert_allclose(Sn, dS, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(Rn, R + dR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(dR).max()))
+    seen = ctx.visited_get() != 0
+    assert set(np.flatnonzero(seen)) == set(idx)                 # exactly the reference's dict keys exist afterwards
 
 
 @pytest.mark.parametrize("batch", [1, 7, 64, 1000])

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 pytestmark = pytest.mark.gpu
-ATOL = 2e-5
+import os
+ATOL = float(os.environ.get("SCOPA_SDCFR_ATOL", "2e-5"))
 
 
 @pytest.fixture()
@@ -239,3 +240,35 @@ def test_fused_traversal_replay_matches_reference(dcfr, trav):
     assert np.array_equal(f.cpu().numpy(), g[f"trav{trav}_row_feat"])
     assert np.array_equal(m.cpu().numpy(), g[f"trav{trav}_row_mask"])
     np.testing.assert_allclose(r.cpu().numpy(), g[f"trav{trav}_row_regret"], atol=ATOL, rtol=0)
+
+
+def test_add_experience_normalises_and_appends_like_the_reference(dcfr):
+    """AdvantageNetwork.add_experience (deep_cfr.py:70-75): advantages / (max|adv| + 1e-8) when the maximum is positive, the
+    row appended at the deque's tail -- here the device ring the traversal kernels write, so kernel rows and caller rows interleave."""
+    import torch
+    d, g = dcfr
+    a = d.advantage_nets[0]
+    rng = np.random.RandomState(4)
+    rows = []
+    for k in range(5):
+        f = rng.randint(0, 2, 34).astype(np.float32)
+        adv = (rng.standard_normal(16) * 10.0 ** rng.randint(-3, 3)).astype(np.float32) if k != 2 else np.zeros(16, np.float32)
+        m = rng.randint(0, 2, 16).astype(np.float32)
+        a.add_experience(f, adv, m)
+        want = adv / (np.max(np.abs(adv)) + 1e-8) if np.max(np.abs(adv)) > 0 else adv     # the reference's lines on float32 arrays
+        rows.append((f, want.astype(np.float32), m))
+    assert len(a.buffer) == 5
+    for k, (f, r, m) in enumerate(rows):
+        bf, br, bm = a.buffer[k]
+        assert np.array_equal(bf, f) and np.array_equal(bm, m) and np.array_equal(br, r)
+    d._traverse_batch(0, 2)                                              # kernel rows land behind the caller's rows
+    assert len(a.buffer) == 5 + 2 * 41
+    assert np.array_equal(a.buffer[4][0], rows[4][0])
+    a.add_experience(rows[0][0], rows[0][1] * 3, rows[0][2])
+    assert len(a.buffer) == 5 + 2 * 41 + 1 and np.array_equal(a.buffer[5 + 82][0], rows[0][0])
+    assert a.train(epochs=1) >= 0.0                                      # and the memory trains
+    # FIFO: a full ring drops the oldest row
+    small = type(a)(34, 16, device="cuda:0", memory_size=3)
+    for k in range(4):
+        small.add_experience(np.full(34, k, np.float32), np.ones(16, np.float32), np.ones(16, np.float32))
+    assert len(small.buffer) == 3 and [int(small.buffer[i][0][0]) for i in range(3)] == [1, 2, 3]

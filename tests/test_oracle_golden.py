@@ -5,6 +5,8 @@ float64 tables: the reference is bit-deterministic)."""
 import numpy as np
 import pytest
 
+from conftest import frozen_case
+
 
 def test_philox_known_answers(oracle):
     # Random123 kat_vectors, philox4x32-10
@@ -95,6 +97,25 @@ def test_mccfr_replay_bit_exact(oracle, golden, seed, iters):
     rest = np.ones(t.n_infosets, bool)
     rest[idx] = False
     assert not R[rest].any() and not S[rest].any()
+
+
+@pytest.mark.parametrize("case", [0, 1, 2])
+def test_batched_mccfr_is_the_references_sample_with_frozen_tables(oracle, golden, case):
+    """Pins the batched (frozen-table, path-keyed) MCCFR semantics to the reference: og_mccfr_batched_delta reproduces, BIT FOR BIT,
+    the regret and strategy deltas that the reference's own _sample recursion accumulates when its nodes answer current_strategy()
+    from a frozen table and np.random.choice is fed the path-keyed Philox uniforms -- same traversal order, same float64 operations."""
+    t = oracle.Tree(seed=42)
+    R, seed, it, b0, nb, dR, dS, idx, actions = frozen_case(golden, t.infoset_strings, case)
+    oR, oS, dv, tv = t.mccfr_batched_delta(R, seed, it, b0, nb)
+    assert (dv, tv) == (463 * nb, 240 * nb)
+    assert np.array_equal(oR, dR) and np.array_equal(oS, dS)
+    # the sampled actions themselves, node by node in the reference's DFS order, for every traversal of the case
+    tr = []
+    for b in range(b0, b0 + nb):
+        for p in (0, 1):
+            nodes, acts = t.mccfr_batched_trace(R, seed, it, b, p)
+            tr.extend(int(t.legal[n][a]) for n, a in zip(nodes, acts))
+    assert np.array_equal(np.array(tr, np.int8), actions)
 
 
 def test_uniform_value_and_exploitability_invariants(oracle, golden):
