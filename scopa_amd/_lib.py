@@ -9,7 +9,9 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libscopa_hip.so")
+# SCOPA_HIP_LIBRARY: another build of the same sources (the host-only AddressSanitizer/UBSan build of `make -C tests/tools asan`);
+# never a fallback -- a path that does not exist fails exactly like the default one
+LIB_PATH = os.environ.get("SCOPA_HIP_LIBRARY") or os.path.join(_HERE, "libscopa_hip.so")
 
 SCOPA_OK, SCOPA_EINVAL, SCOPA_ENODEV, SCOPA_EHIP, SCOPA_ESTATE, SCOPA_ENOMEM, SCOPA_ELIMIT, SCOPA_ETIMEOUT = 0, -1, -2, -3, -4, -5, -6, -7
 N_NODES, N_DECISION, N_TERMINAL = 2229, 1653, 576
