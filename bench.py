@@ -122,6 +122,135 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def cpu_baseline_sdcfr(nets, target_s=10.0):
+    """The oracle's SDCFR traversal (og_sdcfr_traverse: one traversal after the other, a batch-1 MLP forward per node, as the
+    reference does) with the SAME weights on one host core, bounded sample."""
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    import oracle as O
+    t = O.Tree(seed=42)
+    visits, n, t0 = 0, 0, time.perf_counter()
+    while time.perf_counter() - t0 < target_s:
+        for trav in (0, 1):
+            visits += t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=n, b0=0, nb=64)[4]
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": visits / dt, "unit": "infoset-traversals/s", "cores": 1, "kind": "port",
+            "sample": f"{n} x 64 traversals per player of the same SDCFR traversal with the same weights (oracle/scopa_oracle.c og_sdcfr_traverse, "
+                      f"{visits} visits in {dt:.1f} s); traversal only, no training",
+            "reference_python_visits_per_s": "930-2900 (BASELINE.md section 2: reference DeepCFR._external_sampling_cfr, 1 Xeon core)"}
+
+
+def main_sdcfr(args):
+    """--workload sdcfr: BASELINE configs[3] (N = 1) / configs[4] (N > 1).  A step is one iteration of DeepCFR.train
+    (deep_cfr.py:431-495) without its evaluation: per player, `batch` external-sampling traversals in one launch of
+    k_sdcfr_traverse filling the device-resident memory ring, then the advantage net's Adam epochs on PyTorch-ROCm
+    (N > 1: traversal ids sharded by rank, one flat gradient all-reduce per optimiser step)."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        sys.exit("bench.py needs a GPU: the solver path has no CPU fallback")
+    torch.cuda.set_device(local)
+    saved_stdout = None
+    if world > 1:
+        sys.stdout.flush()
+        saved_stdout = os.dup(1)
+        os.dup2(2, 1)
+        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+    batch = args.batch
+    torch.manual_seed(0)
+    _so = os.dup(1)
+    os.dup2(2, 1)                                              # the constructor prints the reference's "Estimated input dimension" line
+    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=batch, rank=rank, world=world, graph_training=(world == 1))
+    sys.stdout.flush()
+    os.dup2(_so, 1)
+    ctx = d._engine.ctx
+    epochs = args.sdcfr_epochs
+
+    def step():
+        for p in range(2):
+            d._traverse_batch(p, batch)
+            with torch.cuda.stream(d._stream):
+                d.advantage_nets[p].train(epochs=epochs)
+            d._stream.synchronize()
+        d._iteration += 1
+
+    def fence():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    # pre-phase: at least 20 iterations and (single GPU) at least PRE_PHASE_S -- a fixed count where ranks must stay in step
+    n_pre, t0 = 0, time.perf_counter()
+    while n_pre < 20 or (world == 1 and time.perf_counter() - t0 < PRE_PHASE_S):
+        step()
+        n_pre += 1
+    for _ in range(args.warmup):
+        step()
+    fence()
+    v0 = ctx.sdcfr_visits()
+    d.kernel_events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tm = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        elapsed = float(tm.item())
+    visits = (ctx.sdcfr_visits() - v0) * world
+    assert visits == (105 + 82) * batch * args.steps * world
+    kern_ms = [a.elapsed_time(b) for a, b in d.kernel_events]
+    d.kernel_events = None
+    if rank == 0:
+        kern_s = 1e-3 * sum(kern_ms) / max(len(kern_ms), 1)              # one launch = one player's batch
+        v_launch = (105 + 82) / 2.0 * batch                              # visits per launch, averaged over the two traversers
+        flop_visit = 2.0 * (34 * 128 + 128 * 64 + 64 * 16)               # one MLP forward (27 136 FLOP) ...
+        fwd_launch = (81 + 58) / 2.0 * batch                             # ... per visit that needs one: the 24 single-action opponent nodes of plies 6/7 are forced, the kernel skips them
+        alg_b = 412.0
+        bounds = {"mfma-f32": {"achieved": flop_visit * fwd_launch / kern_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                               "how": "27 136 FLOP (one 34-128-64-16 forward) x forward passes per launch (81 / 58 of the 105 / 82 visits of a traversal) / kernel time "
+                                      "against the f32 matrix peak (v_mfma_f32_4x4x1 runs at the f32 vector rate)"},
+                  "hbm-algorithmic": {"achieved": alg_b * v_launch / kern_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "how": "SURVEY 8(d): 412 B per visit (state, features, mask, advantages, memory rows) x visits per launch / kernel time"}}
+        for b in bounds.values():
+            b["frac"] = b["achieved"] / b["peak"]
+        top = max(bounds, key=lambda k: bounds[k]["frac"])
+        nets = np.stack([np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in a.net.state_dict().values()]) for a in d.advantage_nets])
+        out = {"metric": "MiniScopa infoset-traversals/sec", "value": visits / elapsed, "unit": "infoset-traversals/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "config": {"workload": f"BASELINE configs[{3 if world == 1 else 4}]: SDCFR on MiniScopa, {batch} external-sampling traversals per player per iteration per GPU "
+                                      f"(k_sdcfr_traverse fills the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch 128 per player on PyTorch-ROCm",
+                          "batch_per_gpu": batch, "global_batch": batch * world, "iterations": args.steps,
+                          "parallelism": f"dp{world}" + (" + 1 gradient all-reduce of 55104 B per optimiser step (RCCL)" if world > 1 else ""),
+                          "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)"},
+               "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms)},
+               "roofline": {"bound": top, "achieved": bounds[top]["achieved"], "peak": bounds[top]["peak"], "unit": bounds[top]["unit"], "frac": bounds[top]["frac"],
+                            "traffic": None, "kernel": "k_sdcfr_traverse", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,
+                            "note": "kernel time from events recorded on the kernel's stream around each launch; both nets (2 x 55 KB) and the per-wavefront frontier "
+                                    "live in LDS, HBM sees the 41 x 264 B memory rows per traversal; the kernel is bound by dependent MFMA / LDS latency at 2.5 waves per SIMD"},
+               "decision_visits": visits}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline_sdcfr(nets)
+            out["gpu_over_cpu_1core_traversal_only"] = out["traversal_only"]["visits_per_s_per_gpu"] / out["cpu_baseline"]["value"]
+        if saved_stdout is not None:
+            sys.stdout.flush()
+            os.dup2(saved_stdout, 1)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def load_profile_json(name):
     path = os.path.join(ROOT, "profiles", name)
     try:
@@ -134,9 +263,12 @@ def load_profile_json(name):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=2000)
-    ap.add_argument("--warmup", type=int, default=100)
+    ap.add_argument("--workload", choices=["mccfr", "sdcfr"], default="mccfr",
+                    help="mccfr = BASELINE configs[1]/[2] (the headline); sdcfr = configs[3]/[4] (HIP traversal kernel + PyTorch-ROCm advantage MLP)")
+    ap.add_argument("--steps", type=int, default=None, help="timed iterations (default 2000 for mccfr, 30 for sdcfr)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed iterations (default 100 for mccfr, 3 for sdcfr)")
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
+    ap.add_argument("--sdcfr-epochs", type=int, default=5, help="Adam steps per player per iteration (sdcfr workload)")
     ap.add_argument("--regions", type=int, default=REGIONS, help="how many times the --steps region is timed (median reported)")
     ap.add_argument("--prof-stride", type=int, default=0, help="bracket every n-th traversal launch with HIP events (0 = so that >= 64 launches are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -149,8 +281,14 @@ def main():
                     help="rehearsal on a box with fewer GPUs than ranks: all ranks use device 0, the process group is gloo (RCCL refuses two ranks on one device)")
     args = ap.parse_args()
 
+    if args.steps is None:
+        args.steps = 2000 if args.workload == "mccfr" else 30
+    if args.warmup is None:
+        args.warmup = 100 if args.workload == "mccfr" else 3
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
+    if args.workload == "sdcfr":
+        return main_sdcfr(args)
 
     import numpy as np
     import torch

@@ -16,6 +16,7 @@ Fixtures (consumers: tests/, oracle pinning):
   vanilla_cfr.npz     CFRTrainer tables after 1,2,5,50,200 iterations             (vanilla_cfr.py:56-120)
   mccfr.npz           MCCFRTrainer tables under np.random.seed(k)                 (mc_cfr.py:37-99)
   MiniScopa_MCCFR_data.reference.json  the reference's committed 10-run MCCFR experiment output (experiment_tracker.py:82-158)
+  mccfr_experiment_runs.json  24 seeded runs of the reference's published experiment (run_mccfr_experiment.py:64-137) + exact EV of each final policy
   mccfr_frozen.npz    MCCFRTrainer._sample driven with frozen strategies and path-keyed draws: batched-MCCFR deltas (mc_cfr.py:37-86)
   evaluate.json       evaluate_agent results under np.random.seed(k)              (vanilla_cfr.py:157-216, mc_cfr.py:146-206)
   sdcfr.npz           DeepCFR features/masks/traversal rows with saved weights    (deep_cfr.py:213-365)
@@ -616,6 +617,58 @@ def gen_team(ns):
           "max table", max(len(t["table"]) for c in cases for t in c["trail"]))
 
 
+def _experiment_run(k):
+    """One seeded run of the reference's published experiment, in a worker process."""
+    import contextlib
+    import importlib
+    import io
+    ns = refshim.import_reference()
+    exp = importlib.import_module("experiments.run_mccfr_experiment")
+    made = []
+
+    class Recording(ns.mc.MCCFRTrainer):          # the reference's trainer, only remembered so that its final tables can be read
+        def __init__(self, *a, **kw):
+            super().__init__(*a, **kw)
+            made.append(self)
+
+    exp.MCCFRTrainer = Recording
+    np.random.seed(7000 + k)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = exp.run_single_mccfr_experiment(k, iterations=500, eval_interval=5, final_eval_episodes=5000)
+    tr = made[-1]
+    # exact expected reward of the final average policy against uniform play, both seats (tree enumeration by the oracle)
+    import oracle as O
+    t = O.Tree(seed=42)
+    S = np.zeros((t.n_infosets, 4))
+    for (p, key), nd in tr.info_sets.items():
+        S[t.infoset_strings.index(key), :nd.strategy_sum.size] = nd.strategy_sum
+    P, U = t.average_policy(S), t.average_policy(np.zeros_like(S))
+    is_p0 = (np.asarray(t.infoset_player) == 0)[:, None]
+    ev = 0.5 * (t.policy_value(np.where(is_p0, P, U)) - t.policy_value(np.where(is_p0, U, P)))
+    return dict(seed=7000 + k, final_reward=m.final_reward, final_scopa_trained=m.final_scopa_trained, final_scopa_random=m.final_scopa_random,
+                num_info_sets=m.num_info_sets, exact_ev_vs_uniform=ev, eval_iterations=m.eval_iterations, eval_rewards=m.eval_rewards,
+                eval_scopas_trained=m.eval_scopas_trained, eval_scopas_random=m.eval_scopas_random)
+
+
+def gen_experiment(ns, n_runs=24):
+    """The reference's only published experiment (run_mccfr_experiment.py:64-137: 500 MCCFR iterations, evaluate_policy_quick every 5,
+    evaluate_agent with 5000 episodes at the end) re-run HERE by the reference's own code under np.random.seed(7000 + k), k < n_runs.
+    Two uses: (1) run 0's evaluation curve is replayed bit for bit by the build (training AND evaluation share the global numpy
+    stream); (2) the spread of the final reward over freshly seeded reference runs, beside the exact expected reward of each final
+    policy, says whether the reference's committed 10-run mean (1.1545) and the build's 100-run mean (1.244) differ by more than
+    the reference's own run-to-run noise."""
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(6) as pool:
+        runs = pool.map(_experiment_run, range(n_runs))
+    fr, ev = np.array([r["final_reward"] for r in runs]), np.array([r["exact_ev_vs_uniform"] for r in runs])
+    summary = dict(n_runs=n_runs, final_reward_mean=float(fr.mean()), final_reward_std=float(fr.std()), final_reward_sem=float(fr.std(ddof=1) / np.sqrt(n_runs)),
+                   exact_ev_mean=float(ev.mean()), exact_ev_std=float(ev.std()), exact_ev_sem=float(ev.std(ddof=1) / np.sqrt(n_runs)),
+                   info_sets_min=int(min(r["num_info_sets"] for r in runs)), info_sets_max=int(max(r["num_info_sets"] for r in runs)))
+    with open(os.path.join(OUT, "mccfr_experiment_runs.json"), "w") as f:
+        json.dump(dict(summary=summary, runs=runs), f, separators=(",", ":"))
+    print("experiment:", summary)
+
+
 def gen_tracker(ns):
     """The reference's committed experiment output (src/experiments/experiments/results/MiniScopa_MCCFR_data.json: 10 MCCFR runs x
     500 iterations, written by ExperimentTracker.save_data_for_plotting, experiment_tracker.py:82-158) as a fixture: a data file,
@@ -628,7 +681,7 @@ def gen_tracker(ns):
     print("tracker: runs", d["num_runs"], "eval points", len(d["runs"][0]["eval_iterations"]))
 
 
-ALL = dict(tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+ALL = dict(experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

@@ -205,6 +205,20 @@ class Tree:
                                          int(traverser), _p(nodes), _p(acts), 512)
         return nodes[:n].copy(), acts[:n].copy()
 
+    def sdcfr_traverse(self, nets, traverser, seed=0, iteration=0, b0=0, nb=1, uniforms=None):
+        """nets: float32 [2][13776] (two torch state dicts flattened in their own order) -> (feat, regret, mask rows, values, visits)"""
+        w = np.ascontiguousarray(nets, np.float32).reshape(2, -1)
+        assert w.shape[1] == 13776
+        feat, reg, mask = np.zeros((nb * 41, 34), np.float32), np.zeros((nb * 41, 16), np.float32), np.zeros((nb * 41, 16), np.float32)
+        vals, vis = np.zeros(nb, np.float32), C.c_uint64(0)
+        u = None if uniforms is None else np.ascontiguousarray(uniforms, np.float64)
+        L = lib()
+        L.og_sdcfr_traverse.restype = C.c_int64
+        rows = L.og_sdcfr_traverse(self.h, _p(w), int(traverser), C.c_uint64(seed), C.c_uint32(iteration), C.c_uint32(b0), C.c_uint32(nb),
+                                   _p(u), C.c_int64(0 if u is None else u.size), _p(feat), _p(reg), _p(mask), _p(vals), C.byref(vis))
+        assert rows == nb * 41
+        return feat, reg, mask, vals, vis.value
+
     def average_policy(self, S):
         P = np.zeros_like(S)
         lib().og_average_policy(self.h, _p(S), _p(P))

@@ -574,6 +574,108 @@ int og_mccfr_batched_trace(const og_tree *t, const double *regret, uint64_t seed
     return c.tr_n;
 }
 
+/* ===== Single Deep CFR traversal (src/algorithms/deep_cfr/deep_cfr.py:284-365) ===== */
+/* One net = torch state dict in its own order and layout: W1[128][34] b1[128] W2[64][128] b2[64] W3[16][64] b3[16]
+ * (FlexibleNet(mode="mlp"), nets.py:296-331: Linear -> ReLU -> Linear -> ReLU -> Linear), float32. */
+enum { SD_IN = 34, SD_H1 = 128, SD_H2 = 64, SD_OUT = 16, SD_NET = SD_H1 * SD_IN + SD_H1 + SD_H2 * SD_H1 + SD_H2 + SD_OUT * SD_H2 + SD_OUT };
+
+static void sd_forward(const float *w, const float *x, float *out) {
+    const float *W1 = w, *b1 = W1 + SD_H1 * SD_IN, *W2 = b1 + SD_H1, *b2 = W2 + SD_H2 * SD_H1, *W3 = b2 + SD_H2, *b3 = W3 + SD_OUT * SD_H2;
+    float h1[SD_H1], h2[SD_H2];
+    for (int o = 0; o < SD_H1; o++) { float a = b1[o]; for (int k = 0; k < SD_IN; k++) a += W1[o * SD_IN + k] * x[k]; h1[o] = a > 0.0f ? a : 0.0f; }
+    for (int o = 0; o < SD_H2; o++) { float a = b2[o]; for (int k = 0; k < SD_H1; k++) a += W2[o * SD_H1 + k] * h1[k]; h2[o] = a > 0.0f ? a : 0.0f; }
+    for (int o = 0; o < SD_OUT; o++) { float a = b3[o]; for (int k = 0; k < SD_H2; k++) a += W3[o * SD_H2 + k] * h2[k]; out[o] = a; }
+}
+
+typedef struct {
+    const og_tree *t; const float *nets; /* [2][SD_NET] */
+    int trav; uint64_t seed; uint32_t iter, b;
+    const double *uniforms; int64_t upos, n_uniforms;   /* replay: one per opponent visit, DFS order; NULL: Philox */
+    float *row_feat, *row_regret, *row_mask; int64_t rows; /* appended in the reference's order (DFS post-order) */
+    uint64_t dvis;
+} sdctx;
+
+/* _state_to_features (:213-275) for the player to move, _get_legal_actions_mask (:277-282) */
+static void sd_features(const og_state *s, int p, float *f, float *m) {
+    for (int c = 0; c < 34; c++) f[c] = 0.0f;
+    for (int c = 0; c < 16; c++) m[c] = 0.0f;
+    for (int k = 0; k < s->nh[p]; k++) { f[s->hand[p][k]] = 1.0f; m[s->hand[p][k]] = 1.0f; }
+    for (int k = 0; k < s->nt; k++) f[16 + s->table[k]] = 1.0f;
+    f[32] = 1.0f; /* float(player == state.current_player()) */
+}
+
+static float sd_rec(sdctx *c, int node, int ply, uint32_t slot) {
+    const og_tree *t = c->t;
+    if (t->term[node]) return 0.5f * (float)t->r2[node * 2 + c->trav];           /* float(rewards[player]) (:286-293) */
+    c->dvis++;
+    const og_state *s = &t->state[node];
+    const int p = t->player[node], nl = t->nlegal[node];
+    float feat[34], mask[16], adv[16], pol[16];
+    sd_features(s, p, feat, mask);
+    sd_forward(c->nets + (size_t)p * SD_NET, feat, adv);                            /* get_advantages (:54-67) */
+    /* positive_regret_policy (nets.py:93-101) on adv*mask - 1e6*(1-mask): relu(.)*mask / clamp_min(sum, 1e-8) */
+    float z = 0.0f;
+    for (int a = 0; a < 16; a++) { pol[a] = (mask[a] != 0.0f && adv[a] > 0.0f) ? adv[a] : 0.0f; z += pol[a]; }
+    const float zc = z > 1e-8f ? z : 1e-8f;
+    for (int a = 0; a < 16; a++) pol[a] = pol[a] / zc;
+    if (p == c->trav) {                                                             /* (:320-346) */
+        float value = 0.0f, cfv[16];
+        for (int a = 0; a < 16; a++) cfv[a] = 0.0f;
+        for (int k = 0; k < nl; k++) {
+            const int a = t->legal[node * 4 + k];
+            const float av = sd_rec(c, t->child[node * 4 + k], ply + 1, slot * (uint32_t)nl + (uint32_t)k);
+            value += pol[a] * av;                                                    /* float32 under NEP 50 */
+            cfv[a] = av;
+        }
+        float reg[16], mx = 0.0f;
+        for (int a = 0; a < 16; a++) { reg[a] = cfv[a] - value; const float x = fabsf(reg[a]); if (x > mx) mx = x; }   /* illegal slots: -value */
+        if (mx > 0.0f) { const float den = mx + 1e-8f; for (int a = 0; a < 16; a++) reg[a] = reg[a] / den; }          /* add_experience (:70-75) */
+        if (c->row_feat) {
+            memcpy(c->row_feat + c->rows * 34, feat, sizeof feat);
+            memcpy(c->row_regret + c->rows * 16, reg, sizeof reg);
+            memcpy(c->row_mask + c->rows * 16, mask, sizeof mask);
+        }
+        c->rows++;
+        return value;
+    }
+    /* opponent: sample one action (:347-365) */
+    float ap[4], sum = 0.0f;
+    for (int k = 0; k < nl; k++) { ap[k] = pol[t->legal[node * 4 + k]]; sum = k ? sum + ap[k] : ap[0]; }
+    double u;
+    if (c->uniforms) { u = c->upos < c->n_uniforms ? c->uniforms[c->upos] : 0.0; c->upos++; }
+    else {  /* the build's draw: Philox block keyed by (frontier slot + 1024*ply, traversal id, iteration, 4 + traverser) */
+        uint32_t ctr[4] = {slot + 1024u * (uint32_t)ply, c->b, c->iter, 4u + (uint32_t)c->trav};
+        uint32_t key[2] = {(uint32_t)c->seed, (uint32_t)(c->seed >> 32)}, o[4];
+        og_philox4x32_10(ctr, key, o);
+        u = u53(o[0], o[1]);
+    }
+    int a;
+    if (sum == 0.0f) { a = (int)(u * (double)nl); if (a > nl - 1) a = nl - 1; }     /* np.random.choice(legal_actions): uniform */
+    else {                                                                          /* p = float32 action_probs / sum; cdf in float64 */
+        double pd[4];
+        for (int k = 0; k < nl; k++) pd[k] = (double)(ap[k] / sum);
+        a = np_choice(pd, nl, u);
+    }
+    return sd_rec(c, t->child[node * 4 + a], ply + 1, slot);
+}
+
+int64_t og_sdcfr_traverse(const og_tree *t, const float *nets, int traverser, uint64_t seed, uint32_t iteration, uint32_t b0,
+                          uint32_t nb, const double *uniforms, int64_t n_uniforms, float *row_feat, float *row_regret,
+                          float *row_mask, float *values, uint64_t *decision_visits) {
+    sdctx c;
+    memset(&c, 0, sizeof c);
+    c.t = t; c.nets = nets; c.trav = traverser; c.seed = seed; c.iter = iteration;
+    c.uniforms = uniforms; c.n_uniforms = n_uniforms;
+    c.row_feat = row_feat; c.row_regret = row_regret; c.row_mask = row_mask;
+    for (uint32_t b = 0; b < nb; b++) {
+        c.b = b0 + b;
+        const float v = sd_rec(&c, 0, 0, 0);
+        if (values) values[b] = v;
+    }
+    if (decision_visits) *decision_visits += c.dvis;
+    return c.rows;
+}
+
 /* ===== synchronous CFR (build-defined) ============================================= */
 static double sync_rec(const og_tree *t, const double *sig, double *dR, double *dS, int node, double r0, double r1,
                        double *v1_out) {

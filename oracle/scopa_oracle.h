@@ -110,6 +110,15 @@ int  og_mccfr_batched_trace(const og_tree *t, const double *regret, uint64_t see
 void   og_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
 double og_philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3);
 
+/* Single Deep CFR: nb external-sampling traversals for `traverser` (deep_cfr.py:284-365), one after the other as the reference
+ * runs them, with the advantage nets given as two torch state dicts flattened in their own order (float32, [2][13776]).
+ * Opponent draws: `uniforms` (one per opponent visit in DFS order -- what np.random.choice consumes) or, if NULL, the build's
+ * Philox block keyed by (frontier slot + 1024*ply, traversal id, iteration, 4 + traverser).  Rows (features[34], normalised
+ * regrets[16], mask[16]) are written in the reference's append order, 41 per traversal; returns the number of rows. */
+int64_t og_sdcfr_traverse(const og_tree *t, const float *nets, int traverser, uint64_t seed, uint32_t iteration, uint32_t b0,
+                          uint32_t nb, const double *uniforms, int64_t n_uniforms, float *row_feat, float *row_regret,
+                          float *row_mask, float *values, uint64_t *decision_visits);
+
 /* Synchronous ("frozen strategy") CFR, build-defined: sigma = RM(regret) frozen over the
  * whole iteration, both players updated from one sweep. */
 void og_cfr_sync(const og_tree *t, double *regret, double *strat, int n_iters);

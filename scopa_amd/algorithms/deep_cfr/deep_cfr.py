@@ -320,9 +320,16 @@ class DeepCFR:
                 for ply, t in uniforms.items():
                     wd = t.numel() // batch
                     u[:, ply, :wd] = t.view(batch, wd)
+            timed = getattr(self, "kernel_events", None)      # bench.py: [(start, stop)] torch events around the kernel launch itself
+            if timed is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(self._stream)
             ctx.sdcfr_traverse_fused(player, batch, w.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), mem.mask.data_ptr(),
                                      mem.capacity, mem.write_base, vals.data_ptr(), u.data_ptr() if u is not None else 0,
                                      self._iteration, self.rank * batch)
+            if timed is not None:
+                e1.record(self._stream)
+                timed.append((e0, e1))
             mem.advance(batch * ROWS_PER_TRAVERSAL)
         self._stream.synchronize()
         return vals

@@ -88,3 +88,8 @@ def frozen_case(golden, t_strings, n):
     dR, dS = np.zeros((I, 4)), np.zeros((I, 4))
     dR[idx], dS[idx] = g[f"c{n}_dregret"], g[f"c{n}_dstrategy"]
     return R, int(meta["seed"]), meta["iteration"], meta["b0"], meta["nb"], dR, dS, idx, g[f"c{n}_actions"]
+
+
+def sdcfr_nets(g):
+    """The fixture's two advantage nets as the oracle takes them: each torch state dict flattened in its own order."""
+    return np.stack([np.concatenate([g[f"net{p}__{k}"].astype(np.float32).reshape(-1) for k in g[f"net{p}_names"]]) for p in range(2)])

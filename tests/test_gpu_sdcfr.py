@@ -271,3 +271,26 @@ def test_add_experience_normalises_and_appends_like_the_reference(dcfr):
     for k in range(4):
         small.add_experience(np.full(34, k, np.float32), np.ones(16, np.float32), np.ones(16, np.float32))
     assert len(small.buffer) == 3 and [int(small.buffer[i][0][0]) for i in range(3)] == [1, 2, 3]
+
+
+@pytest.mark.parametrize("trav", [0, 1])
+def test_traversal_batch_with_device_draws_vs_oracle(dcfr, oracle, trav):
+    """A batch of traversals with the product's own (Philox) draws, fused kernel and ply-by-ply kernels, against the oracle's
+    restatement of _external_sampling_cfr (itself pinned to the reference run in tests/test_oracle_golden.py): the same 41 x B
+    rows in the same order -- features / masks exact, normalised regrets and root values to 1e-5 -- at a non-zero iteration key."""
+    import torch
+    d, g = dcfr
+    B = 96
+    d._iteration = 3
+    nets = np.stack([np.concatenate([v.cpu().numpy().reshape(-1) for v in d.advantage_nets[p].net.state_dict().values()]) for p in range(2)])
+    t = oracle.Tree(seed=42)
+    feat, reg, mask, ovals, visits = t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=3, b0=0, nb=B)
+    assert visits == (105, 82)[trav] * B
+    for fused in (True, False):
+        mem = d.advantage_nets[trav].buffer
+        base = len(mem)
+        vals = d._traverse_batch(trav, B, fused=fused)
+        f, r, m = mem.rows(torch.arange(base, base + 41 * B, device="cuda:0"))
+        assert np.array_equal(f.cpu().numpy(), feat) and np.array_equal(m.cpu().numpy(), mask), fused
+        np.testing.assert_allclose(r.cpu().numpy(), reg, atol=ATOL, rtol=0)
+        np.testing.assert_allclose(vals.cpu().numpy(), ovals, atol=ATOL, rtol=0)

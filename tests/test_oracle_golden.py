@@ -5,7 +5,7 @@ float64 tables: the reference is bit-deterministic)."""
 import numpy as np
 import pytest
 
-from conftest import frozen_case
+from conftest import frozen_case, sdcfr_nets
 
 
 def test_philox_known_answers(oracle):
@@ -141,3 +141,36 @@ def test_batched_mccfr_shape_and_split_invariance(oracle):
     b = t.mccfr_batched_delta(R, 7, 0, 3, 5)
     assert np.allclose(a[0] + b[0], dR, rtol=0, atol=1e-12) and np.allclose(a[1] + b[1], dS, rtol=0, atol=1e-12)
     assert np.array_equal(np.rint((a[1] + b[1]).sum(1)), np.rint(dS.sum(1)))
+
+
+@pytest.mark.parametrize("trav", [0, 1])
+def test_sdcfr_traversal_follows_the_reference(oracle, golden, trav):
+    """og_sdcfr_traverse against the reference's own DeepCFR._external_sampling_cfr run with saved weights (tests/golden/sdcfr.npz):
+    the draws np.random.choice consumed are replayed; every sampled action, the 41 memory rows in append order (features and masks
+    exact, normalised regrets to 1e-5 -- the MLP forward sums in another order than the reference's BLAS), the traversal value."""
+    g = golden.npz("sdcfr.npz")
+    t = oracle.Tree(seed=42)
+    n_draws = len(g[f"trav{trav}_draw_action"])
+    u = np.random.RandomState(100 + trav).random_sample(n_draws)
+    feat, reg, mask, vals, visits = t.sdcfr_traverse(sdcfr_nets(g), trav, uniforms=u)
+    assert visits == (105, 82)[trav] == len(g[f"trav{trav}_visit_player"])
+    assert np.array_equal(feat, g[f"trav{trav}_row_feat"]) and np.array_equal(mask, g[f"trav{trav}_row_mask"])
+    np.testing.assert_allclose(reg, g[f"trav{trav}_row_regret"], atol=1e-5, rtol=0)
+    assert abs(float(vals[0]) - float(g[f"trav{trav}_value"][0])) < 1e-5
+
+
+def test_reference_experiment_spread_and_exact_values(oracle, golden):
+    """24 seeded runs of the reference's published experiment, by the reference itself (oracle/gen_golden.py:gen_experiment), beside
+    the EXACT expected reward of each run's final policy against uniform play (tree enumeration).  What it settles: the final reward
+    the reference measures with 5000 episodes is an unbiased estimate of that exact value (mean difference within 3 standard errors,
+    per-run differences within evaluation noise), so the evaluators agree; and the run-to-run spread (std 0.13) is what separates the
+    reference's committed 10-run mean (1.1545, src/experiments/experiments/results/MiniScopa_MCCFR_data.json) from this 24-run mean."""
+    d = golden.json("mccfr_experiment_runs.json")
+    runs, summ = d["runs"], d["summary"]
+    fr, ev = np.array([r["final_reward"] for r in runs]), np.array([r["exact_ev_vs_uniform"] for r in runs])
+    assert len(runs) == summ["n_runs"] == 24 and abs(fr.mean() - summ["final_reward_mean"]) < 1e-12 and abs(ev.mean() - summ["exact_ev_mean"]) < 1e-12
+    diff = fr - ev                                     # evaluation noise of 5000 episodes: sd of one game's reward ~3 -> ~0.045 per run
+    assert abs(diff.mean()) < 3 * diff.std(ddof=1) / np.sqrt(len(runs)) and np.abs(diff).max() < 0.2
+    ref10 = golden.json("MiniScopa_MCCFR_data.reference.json")["statistics"]["final_metrics"]
+    sem = np.hypot(ref10["reward_std"] / np.sqrt(10 - 1), summ["final_reward_sem"])
+    assert abs(ref10["reward_mean"] - fr.mean()) < 3 * sem      # the committed mean sits inside the reference's own run-to-run noise
