@@ -388,8 +388,8 @@ def main():
     regions = max(3, min(args.regions, int(20.0 / max(per_step * args.steps, 1e-9)))) if args.regions > 3 else max(1, args.regions)
     stride = args.prof_stride if args.prof_stride > 0 else max(1, (args.steps * regions) // 64)
     d0, _ = ctx.counters()
-    dev_n0, dev_ms0 = ctx.prof_device()
     ctx.prof_enable(stride)
+    dev_n0, dev_ms0 = 0, 0.0
     times = []
     for _ in range(regions):
         fence()
@@ -399,6 +399,7 @@ def main():
         times.append(all_max(time.perf_counter() - t0))
     launches, kernel_ms = ctx.prof_read()
     dev_n1, dev_ms1 = ctx.prof_device()
+    phases = ctx.prof_phases()
     ctx.prof_enable(0)
     d1, _ = ctx.counters()
     med = sorted(times)[len(times) // 2]
@@ -459,6 +460,7 @@ def main():
             "unit": bounds[top]["unit"] if top else None, "frac": bounds[top]["frac"] if top else None, "traffic": traffic,
             "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
             "kernel_avg_us_device_clock": 1e3 * (dev_ms1 - dev_ms0) / max(dev_n1 - dev_n0, 1), "launches_device_clock": dev_n1 - dev_n0,
+            "workgroup_phase_us": {"prologue": phases[0], "walks": phases[1], "epilogue": phases[2]},
             "bounds": bounds,
             "bound_note": "the kernel's working set (frozen strategy rows, delta table, tree maps) is LDS-resident by design, so the resources that can "
                           "bound it are VALU issue and the LDS array; `bound` is whichever of the candidate ceilings the kernel sits closest to.  Per-pair "

@@ -323,10 +323,12 @@ int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *term
  * synchronises and returns the number of sampled launches and their summed kernel milliseconds since enable. */
 int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride);
 int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
-/* the same kernel timed by ITSELF: per launch, first workgroup start -> last workgroup end on the 100 MHz device-wide clock,
- * every launch since the context was created (take differences); no events, no dispatch latency: comparable with a profiler's
- * kernel durations */
+/* the same kernel timed by ITSELF: per sampled launch (the ones scopa_prof_enable's stride selects), first workgroup start ->
+ * last workgroup end on the 100 MHz device-wide clock, summed over the samples held (the last 2048 at most) since scopa_prof_enable;
+ * no events, no dispatch latency: launch ramp and end-of-kernel write-back are outside it */
 int32_t scopa_prof_device(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
+/* after scopa_prof_device: mean microseconds a workgroup of the sampled launches spent in (prologue, traversal walks, epilogue) */
+int32_t scopa_prof_phases(scopa_ctx *ctx, double out_us[3]);
 
 #ifdef __cplusplus
 }

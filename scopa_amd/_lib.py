@@ -34,7 +34,7 @@ SYMBOLS = [
     "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts",
     "scopa_team_state_init", "scopa_team_state_step", "scopa_team_state_legal", "scopa_team_state_rewards_x2", "scopa_team_state_infoset_string",
     "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts",
-    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_set_form", "scopa_p2p_set_budget", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device",
+    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_set_form", "scopa_p2p_set_budget", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device", "scopa_prof_phases",
 ]
 
 
@@ -173,6 +173,7 @@ def lib():
         "scopa_prof_enable": (i32, [vp, i32]),
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
         "scopa_prof_device": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
+        "scopa_prof_phases": (i32, [vp, C.POINTER(C.c_double * 3)]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -488,6 +489,12 @@ class Context:
         n, ms = C.c_int64(), C.c_double()
         self._ck(self._L.scopa_prof_read(self._h, C.byref(n), C.byref(ms)), "scopa_prof_read")
         return n.value, ms.value
+
+    def prof_phases(self):
+        """after prof_device(): mean us per workgroup of the sampled launches in (prologue, walks, epilogue)"""
+        out = (C.c_double * 3)()
+        self._ck(self._L.scopa_prof_phases(self._h, C.byref(out)), "scopa_prof_phases")
+        return tuple(out)
 
     def prof_device(self):
         """-> (traversal launches, their summed milliseconds by the kernel's own 100 MHz clock) since the context was created"""

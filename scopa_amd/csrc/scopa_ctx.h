@@ -21,7 +21,7 @@
 //    d_regret, d_strat, d_local
 //  batched MCCFR:
 //    d_delta    [kDecision][5] float64: 4 regret deltas + traverser-visit count (the all-reduce payload)
-//    d_slabs    [n_cus][n_infosets][5] float64: per-workgroup partial deltas, summed in fixed order into d_delta
+//    d_groups   [8][5][kDecision] float64: group tables the traversal launches add their partial deltas into (memory-side atomics)
 struct scopa_p2p;  // scopa_p2p.hip
 
 struct scopa_ctx {
@@ -40,7 +40,6 @@ struct scopa_ctx {
     uint64_t *d_key = nullptr;
     int32_t *d_meta = nullptr;  // [0] = n_infosets, [1] = first-visit sequence counter
     uint32_t *d_visit = nullptr;  // [kDecision] first-visit sequence number per infoset (0 = unvisited)
-    uint8_t *d_seen_slabs = nullptr;  // [n_cus][kDecision] per-workgroup 'infoset seen' flags of one batched launch
 
     double *d_regret = nullptr, *d_strat = nullptr, *d_local = nullptr;
     double *d_delta = nullptr;        // buffer in use (internal or caller-bound)
@@ -48,8 +47,10 @@ struct scopa_ctx {
     double *d_scratch = nullptr;  // root values / uniforms staging
     double *d_sigcdf = nullptr;   // [kDecision][8] sigma | cdf rows of the frozen regret table
     bool sigcdf_valid = false;    // false whenever d_regret changed outside k_mccfr_apply
-    double *d_slabs = nullptr;    // [workgroups][n_infosets][5] per-workgroup partial deltas of one traversal launch
-    size_t slab_bytes = 0;
+    double *d_groups = nullptr;   // [8 group tables][5][kDecision] float64: where traversal launches add their deltas (scopa_mccfr.hip); all-zero between launches' applies
+    unsigned long long *d_clock = nullptr;   // [2048 sampled launches][512 workgroups][4] phase stamps on the 100 MHz device clock (allocated by scopa_prof_enable)
+    uint16_t clock_grid[2048] = {0};         // workgroups of each sampled launch
+    double prof_phase_us[3] = {0.0, 0.0, 0.0};   // mean (prologue, walks, epilogue) per workgroup of the samples last folded by scopa_prof_device
     size_t scratch_bytes = 0;
 
     unsigned long long *d_counters = nullptr;  // [0] decision visits, [1] terminal visits, [2] aux
@@ -76,6 +77,11 @@ struct scopa_ctx {
 
 namespace scopa {
 
+// group tables of the batched-MCCFR delta (scopa_mccfr.hip): 8 cell-major tables of [5][kDecision] float64 per context
+constexpr int kDeltaGroups = 8;
+constexpr size_t kDeltaTable = (size_t)kDecision * 5;              // doubles per group table
+constexpr int kClockSamples = 2048, kClockStride = 2048;           // sampled launches kept / uint64 per sample (512 workgroups x 4 phase stamps)
+
 inline int32_t fail(scopa_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess) {
     if (ctx) {
         if (e != hipSuccess) snprintf(ctx->err, sizeof ctx->err, "%s: %s", what, hipGetErrorString(e));
@@ -99,7 +105,7 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, so the "already raised" flag lives in the
 // context (one context = one device), not in a process-wide static: a second context on another device raises it again.
-enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 2u, kLdsCfrExact = 4u, kLdsExploit = 8u, kLdsCfrSync = 16u, kLdsSdcfr = 32u, kLdsMulti = 64u };
+enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u };
 inline int32_t ensure_lds_attr(scopa_ctx *ctx, uint32_t kernel_bit, const void *fn, int bytes) {
     if (ctx->lds_attr_done & kernel_bit) return SCOPA_OK;
     SC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

@@ -102,7 +102,7 @@ int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
               hipMalloc(&ctx->d_meta, sizeof(int32_t) * 8) == hipSuccess &&
               hipMalloc(&ctx->d_visit, sizeof(uint32_t) * kDecision) == hipSuccess &&
               hipMalloc(&ctx->d_sigcdf, (size_t)kDecision * 8 * sizeof(double)) == hipSuccess &&
-              hipMalloc(&ctx->d_seen_slabs, (size_t)1024 * kDecision) == hipSuccess &&
+              hipMalloc(&ctx->d_groups, scopa::kDeltaGroups * scopa::kDeltaTable * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_regret, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_strat, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_local, rows * 4 * sizeof(double)) == hipSuccess &&
@@ -110,7 +110,8 @@ int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
               hipMalloc(&ctx->d_counters, (8 + 2 * 1024) * sizeof(unsigned long long)) == hipSuccess;  // [0..7] totals, then per-workgroup pairs
     ctx->d_delta = ctx->d_delta_own;
     if (ok) ok = hipMemsetAsync(ctx->d_counters, 0, (8 + 2 * 1024) * sizeof(unsigned long long), ctx->stream) == hipSuccess &&
-                 hipMemsetAsync(ctx->d_delta, 0, rows * 5 * sizeof(double), ctx->stream) == hipSuccess;
+                 hipMemsetAsync(ctx->d_delta, 0, rows * 5 * sizeof(double), ctx->stream) == hipSuccess &&
+                 hipMemsetAsync(ctx->d_groups, 0, scopa::kDeltaGroups * scopa::kDeltaTable * sizeof(double), ctx->stream) == hipSuccess;   // invariant: all-zero between calls
     if (!ok) { scopa_ctx_destroy(ctx); return SCOPA_ENOMEM; }
     *out = ctx;
     return SCOPA_OK;
@@ -123,7 +124,7 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     scopa::p2p_release(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
-                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_slabs, ctx->d_visit, ctx->d_seen_slabs, ctx->d_sigcdf};
+                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_visit, ctx->d_sigcdf, ctx->d_groups, ctx->d_clock};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
@@ -302,23 +303,53 @@ int32_t scopa_visited_get(scopa_ctx *ctx, uint32_t *h_seq) {
 // ---- counters / profiling --------------------------------------------------------------------------------------
 int32_t scopa_counters(scopa_ctx *ctx, uint64_t *decision_visits, uint64_t *terminal_visits) {
     if (!ctx) return SCOPA_EINVAL;
-    unsigned long long h[2] = {0, 0};
-    SC_HIP(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
+    // [0], [1]: totals the single-workgroup solvers add to; [8 + 2w], [9 + 2w]: the slot workgroup w of the batched traversal
+    // kernel accumulates in (one plain read-modify-write per launch instead of 256 same-address atomics)
+    static_assert(sizeof(unsigned long long) == 8, "counter layout");
+    std::vector<unsigned long long> h(8 + 2 * 1024);
+    SC_HIP(ctx, hipMemcpyAsync(h.data(), ctx->d_counters, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (decision_visits) *decision_visits = h[0];
-    if (terminal_visits) *terminal_visits = h[1];
+    unsigned long long d = h[0], t = h[1];
+    for (int w = 0; w < 1024; w++) { d += h[8 + 2 * w]; t += h[9 + 2 * w]; }
+    if (decision_visits) *decision_visits = d;
+    if (terminal_visits) *terminal_visits = t;
     return SCOPA_OK;
 }
 
 int32_t scopa_prof_device(scopa_ctx *ctx, int64_t *launches, double *kernel_ms) {
-    // the traversal kernel's own clock: per launch, first workgroup start -> last workgroup end on the 100 MHz device-wide
-    // counter (s_memrealtime), summed on device since the context was created; every launch is counted, nothing is bracketed
+    // the traversal kernel's own clock: per SAMPLED launch (scopa_prof_enable), first workgroup start -> last workgroup end on
+    // the 100 MHz device-wide counter (s_memrealtime), summed over the samples still held (the last 2048): no events, no
+    // dispatch latency, nothing folded on the device
     if (!ctx) return SCOPA_EINVAL;
-    unsigned long long h[5] = {0, 0, 0, 0, 0};
-    SC_HIP(ctx, hipMemcpyAsync(h, ctx->d_counters, sizeof h, hipMemcpyDeviceToHost, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (launches) *launches = (int64_t)h[4];
-    if (kernel_ms) *kernel_ms = (double)h[3] * 1e-5;   // 10 ns ticks
+    const int64_t n = ctx->d_clock ? (ctx->prof_launches < scopa::kClockSamples ? ctx->prof_launches : scopa::kClockSamples) : 0;
+    unsigned long long ticks = 0;
+    if (n > 0) {
+        std::vector<unsigned long long> h((size_t)n * scopa::kClockStride);
+        SC_HIP(ctx, hipMemcpy(h.data(), ctx->d_clock, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        double ph[3] = {0.0, 0.0, 0.0};
+        long long wgs = 0;
+        for (int64_t s = 0; s < n; s++) {
+            unsigned long long t0 = ~0ull, t1 = 0ull;
+            for (int w = 0; w < ctx->clock_grid[s]; w++) {
+                const unsigned long long *q = &h[(size_t)s * scopa::kClockStride + 4 * w];
+                t0 = q[0] < t0 ? q[0] : t0; t1 = q[3] > t1 ? q[3] : t1;
+                for (int k = 0; k < 3; k++) ph[k] += (double)(q[k + 1] - q[k]);
+                wgs++;
+            }
+            if (t1 > t0) ticks += t1 - t0;
+        }
+        for (int k = 0; k < 3; k++) ctx->prof_phase_us[k] = wgs ? ph[k] * 1e-2 / (double)wgs : 0.0;   // 10 ns ticks -> us, mean over workgroups
+    }
+    if (launches) *launches = n;
+    if (kernel_ms) *kernel_ms = (double)ticks * 1e-5;   // 10 ns ticks
+    return SCOPA_OK;
+}
+
+int32_t scopa_prof_phases(scopa_ctx *ctx, double out_us[3]) {
+    // mean over the sampled launches' workgroups of (prologue, walks, epilogue) on the device clock; call after scopa_prof_device
+    if (!ctx || !out_us) return SCOPA_EINVAL;
+    for (int k = 0; k < 3; k++) out_us[k] = ctx->prof_phase_us[k];
     return SCOPA_OK;
 }
 
@@ -331,6 +362,8 @@ int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride) {
     ctx->ev_used = 0;
     ctx->prof_launches = 0;
     ctx->prof_ms = 0.0;
+    if (ctx->prof_on && !ctx->d_clock)
+        SC_HIP(ctx, hipMalloc(&ctx->d_clock, (size_t)scopa::kClockSamples * scopa::kClockStride * sizeof(unsigned long long)));
     return SCOPA_OK;
 }
 

@@ -307,20 +307,27 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
     wave_lds_sync();  // the next pair overwrites this wave's scratch
 }
 
-// per-workgroup records behind the 8 context totals: [0, 1024) visit-count pairs, [1024, 2048) (start, end) clock pairs
-namespace { constexpr int kWgTimeOff = 1024; }
-
+// Where a launch leaves its result.  A workgroup's partial delta table (regret increments + traverser-visit counts, LDS) is added
+// to a GROUP table in HBM with memory-side float64 atomics: workgroup b adds into table b % kDeltaGroups.  A group table is
+// [5][kDecision] float64 -- cell-major: dR0 of every infoset, dR1, dR2, dR3, counts -- so that a lane per cell adds, and a thread per
+// infoset row later reads, with consecutive lanes on consecutive addresses.  Only non-zero cells are added (~125 of 3690 per
+// workgroup once the strategies have sharpened).  Why groups: such an atomic costs ~20 ns per (workgroup, 64-byte line) request
+// on the SAME line while different lines proceed in parallel, and with peaked strategies every workgroup touches the same ~100
+// rows -- 256 workgroups on one table would queue 256 deep on every hot line (+2.5 .. 5 us at the end of the launch,
+// benchmarks/micro/atomic_flush.hip), 8 tables make that 32 deep (+0.6 us).  k_mccfr_apply (one small launch) then sums the 8 tables
+// in table order, applies the sum and prepares the next iteration's rows.  This replaced per-workgroup SLABS (256 x 29.5 KB
+// written per launch, read back by a reduce kernel that took 8.3 us of a 22 us iteration).
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
-                 const double *__restrict__ g_sigcdf, double *__restrict__ g_slabs,
+                 const double *__restrict__ g_sigcdf, double *__restrict__ g_groups,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
-                 unsigned long long *__restrict__ g_wg_counts, uint8_t *__restrict__ g_seen_slabs) {
+                 unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     __shared__ uint32_t s_c0[128];
-    const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's life span, for scopa_prof_device
+    const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
     const int I = n_infosets;
-    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | cdf thresholds[4] | pad
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | cdf thresholds[3]
     double *s_dR = s_sigcdf + (size_t)I * kRow + (I & 1);                        // [I][4] (16-byte aligned)
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));  // [I] traverser visits
@@ -328,17 +335,16 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);                    // [576]
     uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);            // [I]
 
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
     if (tid < kDrawItems) s_c0[tid] = draw_counter0(tid);
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
-    // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue instead
-    // of one per loop iteration), the LDS zeroing runs underneath them, then the loaded pieces are stored.
+    // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue),
+    // the LDS zeroing runs underneath them, then the loaded pieces are stored.
+    const uint32_t *gi = reinterpret_cast<const uint32_t *>(g_infoset), *gp = reinterpret_cast<const uint32_t *>(g_payoff);
     {
         constexpr int kSig = 7;                                                   // pieces per thread held in registers: covers I <= 1653 at 1024 threads
-        const int nthr = blockDim.x;
         const double2 *g2 = reinterpret_cast<const double2 *>(g_sigcdf);
-        const uint32_t *gi = reinterpret_cast<const uint32_t *>(g_infoset), *gp = reinterpret_cast<const uint32_t *>(g_payoff);
         auto put = [&](int idx, double2 x) {                                      // 16-byte piece idx of the [I][8] rows -> the 7-double LDS rows
             const int row = idx >> 2, piece = idx & 3;                            // pieces 0,1: sigma[4]; 2: thresholds 0,1; 3: threshold 2 (| unused)
             s_sigcdf[row * kRow + piece * 2] = x.x;
@@ -361,15 +367,15 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
             const int idx = tid + j * nthr;
             if (idx < I * 4) put(idx, v[j]);
         }
+        for (int idx = tid + kSig * nthr; idx < I * 4; idx += nthr) put(idx, g2[idx]);  // narrower workgroups (many infosets): the rest, plainly
         if (tid < kDecision / 2) reinterpret_cast<uint32_t *>(s_inf)[tid] = wi;
         if (tid == 0) s_inf[kDecision - 1] = last_inf;
         if (tid < kTerminal / 4) reinterpret_cast<uint32_t *>(s_pay)[tid] = wp;
-        // narrower workgroups (deals with many infosets leave room for fewer wavefronts): the rest, plainly
-        for (int idx = tid + kSig * nthr; idx < I * 4; idx += nthr) put(idx, g2[idx]);
-        for (int i = tid + nthr; i < kDecision / 2; i += nthr) reinterpret_cast<uint32_t *>(s_inf)[i] = gi[i];
-        for (int i = tid + nthr; i < kTerminal / 4; i += nthr) reinterpret_cast<uint32_t *>(s_pay)[i] = gp[i];
     }
+    for (int i = tid + nthr; i < kDecision / 2; i += nthr) reinterpret_cast<uint32_t *>(s_inf)[i] = gi[i];
+    for (int i = tid + nthr; i < kTerminal / 4; i += nthr) reinterpret_cast<uint32_t *>(s_pay)[i] = gp[i];
     __syncthreads();
+    const unsigned long long t_pro = wall_clock64();
 
     WaveScratch &ws = s_wave[wave];
     unsigned int my_dvis = 0, my_tvis = 0;
@@ -379,26 +385,36 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     }
     __syncthreads();
 
-    // ---- epilogue: this workgroup's partial delta table -> its slab, [n_infosets][5] like the delta buffer ----------
+    // ---- epilogue: this workgroup's non-zero cells -> its group table (one lane per cell: a wavefront covers 512 contiguous
+    // bytes; float64 atomics execute at the memory side and return nothing) ------------------------------------------------------
+    const unsigned long long t_walk = wall_clock64();
     {
-        double *slab = g_slabs + (size_t)blockIdx.x * ((size_t)I * 5);
-        for (int c = tid; c < I * 5; c += blockDim.x) {
-            const int r = c / 5, k = c - r * 5;
-            // streamed: nothing on this XCD reads the slab again, and lines already on their way to memory shorten the end-of-kernel write-back
-            __builtin_nontemporal_store(k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r], &slab[c]);
-        }
-        uint8_t *seen = g_seen_slabs + (size_t)blockIdx.x * kDecision;
-        for (int r = tid; r < I; r += blockDim.x) seen[r] = s_seen[r];
+        // infosets first seen by this launch: the loads go out first, their answers are used after the atomics have been issued
+        bool first[2] = {false, false};
+        for (int r = tid, j = 0; r < I && j < 2; r += nthr, j++) first[j] = s_seen[r] && g_visit[r] == 0u;
+        double *tab = g_groups + (size_t)(blockIdx.x % kDeltaGroups) * kDeltaTable;
+        for (int k = 0; k < 5; k++)
+            for (int r = tid; r < I; r += nthr) {
+                const double v = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
+                if (v != 0.0) atomicAdd(&tab[(size_t)k * kDecision + r], v);
+            }
+        for (int r = tid, j = 0; r < I && j < 2; r += nthr, j++)
+            if (first[j]) g_visit[r] = 0x40000000u + (uint32_t)r;            // racing writers store the same value
+        for (int r = tid + 2 * nthr; r < I; r += nthr)                       // narrow workgroups (many infosets): the rest, plainly
+            if (s_seen[r] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
     }
-    // exact visit counters: wave reduce -> LDS -> ONE plain store per workgroup, summed by k_mccfr_reduce
+    // exact visit counters: wave reduce -> LDS -> this workgroup's own slot (a no-return atomic on a word nobody else adds to;
+    // scopa_counters() adds the slots up
     for (int off = 32; off > 0; off >>= 1) {
         my_dvis += __shfl_down(my_dvis, off);
         my_tvis += __shfl_down(my_tvis, off);
     }
     if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
     __syncthreads();
-    if (tid < 2) g_wg_counts[blockIdx.x * 2 + tid] = s_vis[tid];
-    if (tid == 0) { g_wg_counts[kWgTimeOff + blockIdx.x * 2] = t_start; g_wg_counts[kWgTimeOff + blockIdx.x * 2 + 1] = wall_clock64(); }
+    if (tid < 2) atomicAdd(&g_wg_counts[blockIdx.x * 2 + tid], (unsigned long long)s_vis[tid]);   // its own slot: no contention, nothing to wait for
+    if (g_clock && tid == 0) {   // sampled launches: this workgroup's phase stamps (start | prologue done | walks done | end)
+        g_clock[blockIdx.x * 4] = t_start; g_clock[blockIdx.x * 4 + 1] = t_pro; g_clock[blockIdx.x * 4 + 2] = t_walk; g_clock[blockIdx.x * 4 + 3] = wall_clock64();
+    }
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -467,226 +483,115 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     if (tid < 2) g_counters[tid] += s_vis[tid];
 }
 
-// delta[c] += sum over slabs, in slab order (deterministic).  A workgroup owns 16 consecutive cells; thread
-// (chunk = tid / 16, cell = tid % 16) adds slabs chunk, chunk+16, ... so that 16 lanes read 128 contiguous bytes of
-// one slab; the 16 partial sums per cell are then combined in chunk order through LDS.
-// fold the per-workgroup records of a traversal launch: wavefront shuffles first, then ONE LDS atomic per wavefront and
-// quantity (256 same-address LDS atomics serialise and made this workgroup the kernel's critical path)
-__device__ __forceinline__ void wg_record_fold(unsigned long long d, unsigned long long t, unsigned long long t0, unsigned long long t1,
-                                               unsigned long long *s_tot, unsigned long long *s_span) {
-    for (int off = 32; off > 0; off >>= 1) {
-        d += __shfl_down(d, off); t += __shfl_down(t, off);
-        const unsigned long long a = __shfl_down(t0, off), b = __shfl_down(t1, off);
-        t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
-    }
-    if ((threadIdx.x & 63) == 0) {
-        atomicAdd(&s_tot[0], d); atomicAdd(&s_tot[1], t);
-        atomicMin(&s_span[0], t0); atomicMax(&s_span[1], t1);
-    }
-}
-
+// Split path, after a traversal launch: delta[r][0..4] += the 8 group tables in table order; the group tables are cleared.
+// (The all-reduce payload stays the compact [n_infosets][5] table the caller may have bound.)
 __global__ void __launch_bounds__(256)
-k_mccfr_reduce(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_cells,
-               const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters,
-               const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit) {
-    __shared__ double part[16][17];
-    __shared__ unsigned long long s_tot[2], s_span[2];
-    if (blockIdx.x == gridDim.x - 1) {  // the extra, last workgroup owns no cells: it folds the launch's per-workgroup records
-        if (threadIdx.x < 2) { s_tot[threadIdx.x] = 0ull; s_span[threadIdx.x] = threadIdx.x ? 0ull : ~0ull; }
-        __syncthreads();
-        unsigned long long d = 0ull, t = 0ull;
-        unsigned long long t0 = ~0ull, t1 = 0ull;
-        for (int w = threadIdx.x; w < n_slabs; w += blockDim.x) {
-            d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1];
-            const unsigned long long a = g_wg_counts[kWgTimeOff + w * 2], b = g_wg_counts[kWgTimeOff + w * 2 + 1];
-            t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
+k_mccfr_fold(double *__restrict__ g_groups, double *__restrict__ g_delta, int n_infosets) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_infosets) return;
+    double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int g = 0; g < kDeltaGroups; g++)
+        for (int k = 0; k < 5; k++) {
+            double *q = g_groups + (size_t)g * kDeltaTable + (size_t)k * kDecision + r;
+            d[k] += *q;
+            *q = 0.0;
         }
-        wg_record_fold(d, t, t0, t1, s_tot, s_span);
-        __syncthreads();
-        if (threadIdx.x < 2) g_counters[threadIdx.x] += s_tot[threadIdx.x];
-        if (threadIdx.x == 2) { g_counters[3] += s_span[1] - s_span[0]; g_counters[4] += 1ull; }   // traversal kernel: first start -> last end, launches
-    }
-    {   // infosets first seen by this launch: 16 per workgroup, 16 lanes OR the slabs' flags
-        const int r = blockIdx.x * 16 + (threadIdx.x & 15);
-        const int n_rows = n_cells / 5;
-        unsigned int any = 0u;
-        if (r < n_rows)
-            for (int w = threadIdx.x >> 4; w < n_slabs; w += 16) any |= g_seen_slabs[(size_t)w * kDecision + r];
-        if (any && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;  // racing writers store the same value
-    }
-    const int cell_l = threadIdx.x & 15, chunk = threadIdx.x >> 4;
-    const int c = blockIdx.x * 16 + cell_l;
-    double acc = 0.0;
-    if (c < n_cells) {
-        // all loads of a batch are issued before the first add (16 independent requests in flight per lane; the
-        // dependent load->add form of v1 took 35 us for 7.5 MB), then summed in slab order
-        for (int base = chunk; base < n_slabs; base += 256) {
-            double v[16];
-#pragma unroll
-            for (int j = 0; j < 16; j++) {
-                const int sl = base + 16 * j;
-                v[j] = sl < n_slabs ? __builtin_nontemporal_load(&g_slabs[(size_t)sl * n_cells + c]) : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < 16; j++) acc += v[j];
-        }
-    }
-    part[chunk][cell_l] = acc;
-    __syncthreads();
-    if (chunk == 0 && c < n_cells) {
-        double t = part[0][cell_l];
-        for (int k = 1; k < 16; k++) t += part[k][cell_l];
-        g_delta[c] += t;
-    }
+    for (int k = 0; k < 5; k++) g_delta[r * 5 + k] += d[k];
 }
 
-// Single-GPU fusion of k_mccfr_reduce + k_mccfr_apply: a workgroup owns 4 infoset rows = 20 contiguous cells of every
-// slab.  Thread (chunk = tid / 10, pair = tid % 10) owns two adjacent cells (one 16-byte load per slab) and the slabs
-// chunk, chunk+24, ... (<= 11 at 256 slabs); all its loads are issued before the first add.  The 24 partial sums per cell
-// are combined in chunk order through LDS, then 4 lanes apply their rows exactly as k_mccfr_apply does.
-// The order of every float64 sum in THIS kernel is fixed by n_slabs, not by timing (the slabs themselves come from LDS float64
-// atomics whose order inside a workgroup is not: two runs agree to rounding, ~1e-15 relative).
-namespace {
-// measured: 4 rows x 24 chunks 8.3 us; 2 rows x 51 chunks 10.5 us (the serial 51-term combine); 16 rows x 6 chunks slower still
-constexpr int kRaRows = 4, kRaCells = kRaRows * 5, kRaPairs = kRaCells / 2, kRaChunks = 24;
-constexpr int kRaUnroll = 12;  // slabs in flight per lane and batch: kRaChunks * kRaUnroll >= 256 covers the usual launch in one batch
-static_assert(kRaRows <= 4 && (kRaCells % 2) == 0 && kRaChunks * kRaPairs <= 256, "reduce_apply tiling");
+// One infoset row of the apply step: regret += delta; strategy_sum += count * sigma(frozen regret) (mc_cfr.py:83-84 with the
+// iteration's frozen sigma); the next iteration's sigma | cdf row (what k_mccfr_prepare would compute).  The row's table values are
+// passed in: the callers load them together with the delta so that the kernel pays ONE memory round trip, not three.
+struct ApplyRow { double R[4], S[4], sg[4]; int n; };   // regret, strategy_sum, the frozen sigma the launch sampled with, legal actions
+
+__device__ __forceinline__ ApplyRow apply_row_load(int r, const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret,
+                                                   const double *__restrict__ g_strat, const double *__restrict__ g_sigcdf) {
+    ApplyRow a;
+    const double2 r0 = *reinterpret_cast<const double2 *>(g_regret + r * 4), r1 = *reinterpret_cast<const double2 *>(g_regret + r * 4 + 2);
+    const double2 s0 = *reinterpret_cast<const double2 *>(g_strat + r * 4), s1 = *reinterpret_cast<const double2 *>(g_strat + r * 4 + 2);
+    const double2 g0 = *reinterpret_cast<const double2 *>(g_sigcdf + r * 8), g1 = *reinterpret_cast<const double2 *>(g_sigcdf + r * 8 + 2);
+    a.n = (int)((g_key[r] >> 1) & 7);
+    a.R[0] = r0.x; a.R[1] = r0.y; a.R[2] = r1.x; a.R[3] = r1.y;
+    a.S[0] = s0.x; a.S[1] = s0.y; a.S[2] = s1.x; a.S[3] = s1.y;
+    a.sg[0] = g0.x; a.sg[1] = g0.y; a.sg[2] = g1.x; a.sg[3] = g1.y;   // = mc_sigma(R): written by the previous apply / prepare
+    return a;
 }
 
-// XCHG (N > 1): between "the 4 rows' deltas of THIS rank are known" and "apply them", each row is exchanged with the
-// peers (scopa_p2p.h) and becomes the rank-ordered sum over ranks -- the whole multi-GPU step stays two launches.
-template <bool XCHG>
-__global__ void __launch_bounds__(256)
-k_mccfr_reduce_apply(const double *__restrict__ g_slabs, int n_slabs, double *__restrict__ g_delta, int n_infosets,
-                     const unsigned long long *__restrict__ g_wg_counts, unsigned long long *__restrict__ g_counters,
-                     const uint8_t *__restrict__ g_seen_slabs, uint32_t *__restrict__ g_visit, const uint64_t *__restrict__ g_key,
-                     double *__restrict__ g_regret, double *__restrict__ g_strat, double *__restrict__ g_sigcdf, scopa::P2PArgs xa) {
-    __shared__ double part[kRaChunks][kRaCells];
-    __shared__ unsigned int s_any[kRaRows];
-    __shared__ unsigned long long s_tot[2], s_span[2];
-    const int tid = threadIdx.x, n_cells = n_infosets * 5;
-    if (tid < kRaRows) s_any[tid] = 0u;
-    if (blockIdx.x == gridDim.x - 1) {  // the extra, last workgroup owns no rows: it folds the launch's per-workgroup records
-        if (tid < 2) { s_tot[tid] = 0ull; s_span[tid] = tid ? 0ull : ~0ull; }
-        __syncthreads();
-        unsigned long long d = 0ull, t = 0ull;
-        unsigned long long t0 = ~0ull, t1 = 0ull;
-        for (int w = tid; w < n_slabs; w += blockDim.x) {
-            d += g_wg_counts[w * 2]; t += g_wg_counts[w * 2 + 1];
-            const unsigned long long a = g_wg_counts[kWgTimeOff + w * 2], b = g_wg_counts[kWgTimeOff + w * 2 + 1];
-            t0 = a < t0 ? a : t0; t1 = b > t1 ? b : t1;
-        }
-        wg_record_fold(d, t, t0, t1, s_tot, s_span);
-        __syncthreads();
-        if (tid < 2) g_counters[tid] += s_tot[tid];
-        if (tid == 2) { g_counters[3] += s_span[1] - s_span[0]; g_counters[4] += 1ull; }   // traversal kernel: first start -> last end, launches
-    }
-    __syncthreads();
-    const int row0 = blockIdx.x * kRaRows;
-    // the applying lanes (lane 0 of each 16-lane row group of wavefront 0) fetch their table rows now, under the slab loads
-    double pre_R[4] = {0.0, 0.0, 0.0, 0.0}, pre_d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    int pre_n = 0;
-    if (tid < 16 * kRaRows && (tid & 15) == 0 && row0 + (tid >> 4) < n_infosets) {
-        const int r = row0 + (tid >> 4);
-        pre_n = (int)((g_key[r] >> 1) & 7);
-        for (int k = 0; k < 4; k++) pre_R[k] = g_regret[r * 4 + k];
-        for (int k = 0; k < 5; k++) pre_d[k] = g_delta[r * 5 + k];   // whatever earlier launches of this iteration left there
-    }
-    {   // infosets first seen by this launch: 4 rows x 64 lanes OR the slabs' flags
-        const int rl = tid % kRaRows, r = row0 + rl;
-        unsigned int any = 0u;
-        if (r < n_infosets)
-            for (int w = tid / kRaRows; w < n_slabs; w += 256 / kRaRows) any |= g_seen_slabs[(size_t)w * kDecision + r];
-        if (any) s_any[rl] = 1u;  // benign race
-    }
-    const int chunk = tid / kRaPairs, pr = tid - chunk * kRaPairs;
-    const int c = row0 * 5 + pr * 2;  // even: row0*5 is a multiple of 20
-    if (tid < kRaChunks * kRaPairs) {
-        double2 acc = make_double2(0.0, 0.0);
-        if (c < n_cells) {
-            const bool has2 = c + 1 < n_cells;
-            for (int base = chunk; base < n_slabs; base += kRaChunks * kRaUnroll) {
-                double2 v[kRaUnroll];
-#pragma unroll
-                for (int q = 0; q < kRaUnroll; q++) {
-                    const int sl = base + kRaChunks * q;
-                    v[q] = make_double2(0.0, 0.0);
-                    if (sl < n_slabs) {
-                        const size_t off = (size_t)sl * n_cells + c;
-                        if (has2 && (off & 1) == 0) v[q] = *reinterpret_cast<const double2 *>(g_slabs + off);
-                        else { v[q].x = g_slabs[off]; if (has2) v[q].y = g_slabs[off + 1]; }
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < kRaUnroll; q++) { acc.x += v[q].x; acc.y += v[q].y; }
-            }
-        }
-        part[chunk][pr * 2] = acc.x;
-        part[chunk][pr * 2 + 1] = acc.y;
-    }
-    __syncthreads();
-    if (tid < 64) {  // wavefront 0: lane = 16 * row + peer; the 16 lanes of a row hold the same delta, lane 0 of each row applies it
-        const int rl = tid >> 4, q = tid & 15;
-        const int r = row0 + rl;
-        const bool valid = rl < kRaRows && r < n_infosets;
-        double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-        if (valid) {
-            for (int k = 0; k < 5; k++) {
-                double t = __shfl(pre_d[k], tid & 48);         // the row's lane 0 fetched it
-                for (int c2 = 0; c2 < kRaChunks; c2++) t += part[c2][rl * 5 + k];
-                d[k] = t;
-            }
-        }
-        if constexpr (XCHG) {
-            // the exchange scratch [4 rows][16 ranks][5] reuses `part`: only this wavefront is still running, and its reads of
-            // `part` above are complete (LDS operations of one wavefront are performed in order)
-            static_assert(sizeof(double) * 4 * scopa::kP2PMaxWorld * 5 <= sizeof(part), "exchange scratch must fit in part[][]");
-            __builtin_amdgcn_s_waitcnt(0xc07f);  // lgkmcnt(0)
-            __builtin_amdgcn_wave_barrier();
-            double (*xch)[5] = reinterpret_cast<double (*)[5]>(&part[0][0]) + rl * scopa::kP2PMaxWorld;
-            scopa::p2p_exchange_wave4(xa, r, valid, q, d, xch);
-        }
-        if (valid && q == 0) {
-            if (s_any[rl] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
-            const int n = pre_n;
-            double R[4], sg[4], cd[4];
-            for (int k = 0; k < 4; k++) R[k] = pre_R[k];
-            mc_sigma(R, n, sg);
-            for (int k = 0; k < n; k++) {
-                R[k] += d[k];
-                g_regret[r * 4 + k] = R[k];
-                g_strat[r * 4 + k] += d[4] * sg[k];
-            }
-            for (int k = 0; k < 5; k++) g_delta[r * 5 + k] = 0.0;
-            mc_sigma(R, n, sg);
-            choice_cdf(sg, n, cd);
-            for (int k = 0; k < 4; k++) { g_sigcdf[r * 8 + k] = sg[k]; g_sigcdf[r * 8 + 4 + k] = cd[k]; }
-        }
-    }
+__device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double (&d)[5], double *__restrict__ g_regret,
+                                                double *__restrict__ g_strat, double *__restrict__ g_sigcdf) {
+    for (int c = 0; c < 4; c++)
+        if (c < a.n) { a.R[c] += d[c]; a.S[c] += d[4] * a.sg[c]; }
+    *reinterpret_cast<double2 *>(g_regret + r * 4) = make_double2(a.R[0], a.R[1]);
+    *reinterpret_cast<double2 *>(g_regret + r * 4 + 2) = make_double2(a.R[2], a.R[3]);
+    *reinterpret_cast<double2 *>(g_strat + r * 4) = make_double2(a.S[0], a.S[1]);
+    *reinterpret_cast<double2 *>(g_strat + r * 4 + 2) = make_double2(a.S[2], a.S[3]);
+    double sg[4], cd[4];
+    mc_sigma(a.R, a.n, sg);
+    choice_cdf(sg, a.n, cd);
+    double2 *out = reinterpret_cast<double2 *>(g_sigcdf + r * 8);
+    out[0] = make_double2(sg[0], sg[1]); out[1] = make_double2(sg[2], sg[3]); out[2] = make_double2(cd[0], cd[1]); out[3] = make_double2(cd[2], cd[3]);
 }
 
-// regret += delta; strategy_sum += count * sigma(frozen regret); delta <- 0
-__global__ void __launch_bounds__(256)
+// The apply step, one thread per infoset row.  GROUPS = true (single GPU, after every traversal launch): delta = the 8 group tables
+// summed in table order, cleared on the way.  GROUPS = false (split path): delta = the [I][5] buffer the caller all-reduced, cleared.
+// The launch must find d_sigcdf current (it holds the sigma the traversal sampled with).
+template <bool GROUPS>
+__global__ void __launch_bounds__(64)
 k_mccfr_apply(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret, double *__restrict__ g_strat,
               double *__restrict__ g_delta, int n_infosets, double *__restrict__ g_sigcdf) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_infosets) return;
-    const int n = (int)((g_key[r] >> 1) & 7);
-    double R[4], sg[4];
-    for (int c = 0; c < 4; c++) R[c] = g_regret[r * 4 + c];
-    mc_sigma(R, n, sg);
-    const double cnt = g_delta[r * 5 + 4];
-    for (int c = 0; c < n; c++) {
-        R[c] += g_delta[r * 5 + c];
-        g_regret[r * 4 + c] = R[c];
-        g_strat[r * 4 + c] += cnt * sg[c];
+    double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if constexpr (GROUPS) {
+        double v[kDeltaGroups][5];
+#pragma unroll
+        for (int g = 0; g < kDeltaGroups; g++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) v[g][k] = g_delta[(size_t)g * kDeltaTable + (size_t)k * kDecision + r];   // all 40 loads in flight, coalesced over rows
+        ApplyRow a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);
+#pragma unroll
+        for (int g = 0; g < kDeltaGroups; g++)
+#pragma unroll
+            for (int k = 0; k < 5; k++) {
+                d[k] += v[g][k];                                                                                   // table order
+                if (v[g][k] != 0.0) g_delta[(size_t)g * kDeltaTable + (size_t)k * kDecision + r] = 0.0;
+            }
+        apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
+    } else {
+        for (int k = 0; k < 5; k++) d[k] = g_delta[r * 5 + k];
+        ApplyRow a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);
+        for (int k = 0; k < 5; k++) g_delta[r * 5 + k] = 0.0;
+        apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
     }
-    for (int c = 0; c < 5; c++) g_delta[r * 5 + c] = 0.0;
-    // next iteration's frozen strategy rows (what k_mccfr_prepare would compute)
-    double cd[4];
-    mc_sigma(R, n, sg);
-    choice_cdf(sg, n, cd);
-    for (int c = 0; c < 4; c++) { g_sigcdf[r * 8 + c] = sg[c]; g_sigcdf[r * 8 + 4 + c] = cd[c]; }
+}
+
+// N > 1, after a traversal launch: this rank's delta of an infoset row (its 8 group tables summed in table order, then cleared)
+// is exchanged with the peers (scopa_p2p.h), becomes the rank-ordered sum over ranks (identical bits on every rank) and is applied
+// -- the whole multi-GPU iteration stays two launches.  One wavefront per 4 rows, lane = 16 * row + peer; lane 0 of a row applies it.
+__global__ void __launch_bounds__(64)
+k_mccfr_exchange_apply(scopa::P2PArgs xa, double *__restrict__ g_groups, const uint64_t *__restrict__ g_key, double *__restrict__ g_regret,
+                       double *__restrict__ g_strat, double *__restrict__ g_sigcdf, int n_infosets) {
+    __shared__ double xch[4][scopa::kP2PMaxWorld][5];
+    const int rl = threadIdx.x >> 4, q = threadIdx.x & 15;
+    const int r = blockIdx.x * 4 + rl;
+    const bool valid = r < n_infosets;
+    double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+    if (valid) {
+        for (int g = 0; g < kDeltaGroups; g++) {
+            const double *p = g_groups + (size_t)g * kDeltaTable + r;
+            for (int k = 0; k < 5; k++) d[k] += p[(size_t)k * kDecision];   // the 16 lanes of a row compute the same sum
+        }
+    }
+    // every lane has loaded before any lane of this wavefront stores (one instruction stream), and no other wavefront touches the row
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    if (valid && q == 0)
+        for (int g = 0; g < kDeltaGroups; g++)
+            for (int k = 0; k < 5; k++) g_groups[(size_t)g * kDeltaTable + (size_t)k * kDecision + r] = 0.0;
+    ApplyRow a{};
+    if (valid && q == 0) a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);   // under the exchange's waits
+    scopa::p2p_exchange_wave4(xa, r, valid, q, d, xch[rl]);
+    if (valid && q == 0) apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -796,7 +701,9 @@ static size_t traverse_lds_bytes(int n_infosets, int waves) {
     return (b + 15) & ~(size_t)15;
 }
 
-static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb, bool fuse_apply = false, bool exchange = false) {
+// One traversal launch of `nb` traversal pairs [b0, b0 + nb) of iteration `iteration` against the rows in d_sigcdf; the launch
+// adds its deltas into the context's 8 group tables (all-zero whenever no launch's result is pending).
+static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
     // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~870 infosets), fewer for deals
     // with more infosets (the tables alone fit up to 1653, the maximum)
     int waves = 16;
@@ -807,53 +714,26 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     SC_LDS_ATTR(ctx, scopa::kLdsTraverse, k_mccfr_traverse, ctx->lds_limit - kStaticLds);
     const uint32_t n_passes = (nb + waves - 1) / waves;  // one traversal pair per wavefront pass
     const uint32_t grid = n_passes < (uint32_t)ctx->n_cus ? n_passes : (uint32_t)ctx->n_cus;
-    const int n_cells = ctx->n_infosets * 5;
-    const size_t slab_bytes = (size_t)grid * n_cells * sizeof(double);
-    if (slab_bytes > ctx->slab_bytes) {
-        SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        if (ctx->d_slabs) SC_HIP(ctx, hipFree(ctx->d_slabs));
-        ctx->d_slabs = nullptr; ctx->slab_bytes = 0;
-        const size_t want = (size_t)ctx->n_cus * kDecision * 5 * sizeof(double);  // worst case, allocated once (16.9 MB)
-        SC_HIP(ctx, hipMalloc(&ctx->d_slabs, want > slab_bytes ? want : slab_bytes));
-        ctx->slab_bytes = want > slab_bytes ? want : slab_bytes;
-    }
+    SC_REQUIRE(ctx, grid <= 1024u, SCOPA_ELIMIT, "mccfr traverse: more than 1024 compute units");
+    static_assert(kClockStride >= 4 * 512, "clock sample stride");
     if (!ctx->sigcdf_valid) {  // tables were changed by another entry point since the last apply
         hipLaunchKernelGGL(k_mccfr_prepare, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
         SC_HIP(ctx, hipGetLastError());
         ctx->sigcdf_valid = true;
     }
-    {
-        hipEvent_t ev0, ev1;
-        if (prof_events(ctx, &ev0, &ev1))
-            hipExtLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ev0, ev1, 0, ctx->d_infoset, ctx->d_payoff,
-                                  ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                                  iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
-        else
-            hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
-                               ctx->d_sigcdf, ctx->d_slabs, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                               iteration, b0, nb, ctx->d_counters + 8, ctx->d_seen_slabs);
-    }
-    SC_HIP(ctx, hipGetLastError());
-    if (fuse_apply) {  // reduce (+ exchange with the peers) + apply in one kernel
-        scopa::P2PArgs xa{};
-        if (exchange) {
-            SC_REQUIRE(ctx, scopa::p2p_next_args(ctx, &xa), SCOPA_ESTATE, "mccfr sharded iteration: peer exchange not connected");
-            hipLaunchKernelGGL(k_mccfr_reduce_apply<true>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows + 1), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
-                               ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
-                               ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, xa);
-        } else {
-            hipLaunchKernelGGL(k_mccfr_reduce_apply<false>, dim3((ctx->n_infosets + kRaRows - 1) / kRaRows + 1), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
-                               ctx->d_delta, ctx->n_infosets, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit,
-                               ctx->d_key, ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, xa);
-        }
-        SC_HIP(ctx, hipGetLastError());
-        ctx->sigcdf_valid = true;
-        ctx->iteration++;
-        return SCOPA_OK;
-    }
-    hipLaunchKernelGGL(k_mccfr_reduce, dim3((n_cells + 15) / 16 + 1), dim3(256), 0, ctx->stream, ctx->d_slabs, (int)grid,
-                       ctx->d_delta, n_cells, ctx->d_counters + 8, ctx->d_counters, ctx->d_seen_slabs, ctx->d_visit);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    const bool sampled = prof_events(ctx, &ev0, &ev1);
+    unsigned long long *clock = sampled && ctx->d_clock && grid <= 512u ? ctx->d_clock + (size_t)((ctx->prof_launches - 1) % kClockSamples) * kClockStride : nullptr;
+    if (sampled) ctx->clock_grid[(ctx->prof_launches - 1) % kClockSamples] = clock ? (uint16_t)grid : (uint16_t)0;
+    if (sampled)
+        hipExtLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ev0, ev1, 0, ctx->d_infoset, ctx->d_payoff,
+                              ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
+                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock);
+    else
+        hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
+                           ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
+                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -887,12 +767,17 @@ int32_t scopa_mccfr_seed(scopa_ctx *ctx, uint64_t seed) {
 }
 
 int32_t scopa_mccfr_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
+    // split path: the launch's delta is folded into the (caller-bound) [n_infosets][5] buffer: traverse | all-reduce | apply
     if (!ctx) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_traverse: no deal set");
     SC_REQUIRE(ctx, nb <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_traverse: batch too large");
     if (nb == 0) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    return launch_traverse(ctx, iteration, b0, nb);
+    const int32_t rc = launch_traverse(ctx, iteration, b0, nb);
+    if (rc != SCOPA_OK) return rc;
+    hipLaunchKernelGGL(k_mccfr_fold, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_groups, ctx->d_delta, ctx->n_infosets);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
 }
 
 int32_t scopa_mccfr_delta_buffer(scopa_ctx *ctx, void **d_delta, size_t *bytes) {
@@ -939,7 +824,12 @@ int32_t scopa_mccfr_apply(scopa_ctx *ctx) {
     if (!ctx) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_apply: no deal set");
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_mccfr_apply, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
+    if (!ctx->sigcdf_valid) {  // no traversal since another entry point changed the tables: the rows the apply reads sigma from are stale
+        hipLaunchKernelGGL(k_mccfr_prepare, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
+                           ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
+        SC_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_mccfr_apply<false>, dim3((ctx->n_infosets + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_key,
                        ctx->d_regret, ctx->d_strat, ctx->d_delta, ctx->n_infosets, ctx->d_sigcdf);
     SC_HIP(ctx, hipGetLastError());
     ctx->sigcdf_valid = true;
@@ -954,27 +844,40 @@ int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration) {
 }
 
 int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
+    // single GPU: two launches per iteration -- the traversal, and the one-thread-per-row apply over its 8 group tables
     if (!ctx) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_iterate: no deal set");
     SC_REQUIRE(ctx, batch > 0 && batch <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_iterate: bad batch");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     for (uint32_t it = 0; it < n_iters; it++) {
-        const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch, /*fuse_apply=*/true);
+        const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch);
         if (rc != SCOPA_OK) return rc;
+        hipLaunchKernelGGL(k_mccfr_apply<true>, dim3((ctx->n_infosets + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_key,
+                           ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf);
+        SC_HIP(ctx, hipGetLastError());
+        ctx->sigcdf_valid = true;
+        ctx->iteration++;
     }
     return SCOPA_OK;
 }
 
 int32_t scopa_mccfr_iterate_sharded(scopa_ctx *ctx, uint32_t b0, uint32_t nb, uint32_t n_iters) {
     // N > 1: this rank's slice [b0, b0+nb) of every iteration's global traversal ids; the per-row exchange with the peers
-    // (scopa_p2p_create / _connect first) sits inside the reduce+apply kernel.  Every rank must call it with the same n_iters.
+    // (scopa_p2p_create / _connect first) sits inside the apply kernel.  Every rank must call it with the same n_iters.
     if (!ctx) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_iterate_sharded: no deal set");
     SC_REQUIRE(ctx, nb > 0 && nb <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_iterate_sharded: bad slice");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     for (uint32_t it = 0; it < n_iters; it++) {
-        const int32_t rc = launch_traverse(ctx, ctx->iteration, b0, nb, /*fuse_apply=*/true, /*exchange=*/true);
+        scopa::P2PArgs xa{};
+        SC_REQUIRE(ctx, scopa::p2p_next_args(ctx, &xa), SCOPA_ESTATE, "mccfr sharded iteration: peer exchange not connected");
+        const int32_t rc = launch_traverse(ctx, ctx->iteration, b0, nb);
         if (rc != SCOPA_OK) return rc;
+        hipLaunchKernelGGL(k_mccfr_exchange_apply, dim3((ctx->n_infosets + 3) / 4), dim3(64), 0, ctx->stream, xa, ctx->d_groups, ctx->d_key,
+                           ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, ctx->n_infosets);
+        SC_HIP(ctx, hipGetLastError());
+        ctx->sigcdf_valid = true;
+        ctx->iteration++;
     }
     // a peer that never answered must not go unnoticed: the launches above applied whatever their bounded waits were left with
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));

@@ -231,12 +231,14 @@ def test_device_evaluation_agrees_with_host_evaluation(game):
     assert abs(avg_u) < 0.03
 
 
-def test_device_clock_profile_counts_every_traversal_launch(ctx, sl):
+def test_device_clock_profile_of_sampled_traversal_launches(ctx, sl):
     ctx.set_deal(sl.deal_py_seed(42))
     ctx.mccfr_seed(5)
-    n0, ms0 = ctx.prof_device()
-    ctx.mccfr_iterate(512, 7)
+    assert ctx.prof_device() == (0, 0.0)                # nothing sampled yet
+    ctx.prof_enable(2)                                   # every second launch
+    ctx.mccfr_iterate(512, 14)
     n1, ms1 = ctx.prof_device()
-    assert n1 - n0 == 7
-    per_launch_us = 1e3 * (ms1 - ms0) / 7
+    assert n1 == 7 == ctx.prof_read()[0]
+    ctx.prof_enable(0)
+    per_launch_us = 1e3 * ms1 / 7
     assert 1.0 < per_launch_us < 500.0      # a 100 MHz clock span of a kernel that takes ~10 us
