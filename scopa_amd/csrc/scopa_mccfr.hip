@@ -43,11 +43,15 @@ using namespace scopa;
 namespace {
 
 // InfoNode.current_strategy, mc_cfr.py:20-24  (np.maximum, ndarray.sum left-to-right, elementwise divide)
+// (all loops over the 4 slots are unrolled with a predicate on n: indexing by a run-time n would put the arrays in scratch memory)
 __device__ __forceinline__ void mc_sigma(const double *R, int n, double *sigma) {
-    double pos[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = 0; i < n; i++) pos[i] = R[i] > 0.0 ? R[i] : 0.0;
+    double pos[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) pos[i] = (i < n && R[i] > 0.0) ? R[i] : 0.0;
     double s = pos[0];
-    for (int i = 1; i < n; i++) s += pos[i];
+#pragma unroll
+    for (int i = 1; i < 4; i++) if (i < n) s += pos[i];
+#pragma unroll
     for (int i = 0; i < 4; i++) sigma[i] = i < n ? (s == 0.0 ? 1.0 / (double)n : pos[i] / s) : 0.0;
 }
 
@@ -59,8 +63,10 @@ __device__ __forceinline__ void choice_cdf(const double *sigma, int n, double *c
     double cdf[4];
     double c = sigma[0];
     cdf[0] = c;
-    for (int i = 1; i < n; i++) { c += sigma[i]; cdf[i] = c; }
-    const double last = cdf[n - 1];
+#pragma unroll
+    for (int i = 1; i < 4; i++) { if (i < n) c += sigma[i]; cdf[i] = c; }
+    const double last = c;   // = cdf[n - 1]
+#pragma unroll
     for (int i = 0; i < 4; i++) {
         const unsigned long long t = i < n ? (unsigned long long)ceil((cdf[i] / last) * 9007199254740992.0) : ~0ull;  // padding never counts
         cdf_bits[i] = __longlong_as_double((long long)t);
@@ -390,16 +396,16 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const unsigned long long t_walk = wall_clock64();
     {
         // infosets first seen by this launch: the loads go out first, their answers are used after the atomics have been issued
-        bool first[2] = {false, false};
-        for (int r = tid, j = 0; r < I && j < 2; r += nthr, j++) first[j] = s_seen[r] && g_visit[r] == 0u;
+        const bool first0 = tid < I && s_seen[tid] && g_visit[tid] == 0u;
+        const bool first1 = tid + nthr < I && s_seen[tid + nthr] && g_visit[tid + nthr] == 0u;
         double *tab = g_groups + (size_t)(blockIdx.x % kDeltaGroups) * kDeltaTable;
         for (int k = 0; k < 5; k++)
             for (int r = tid; r < I; r += nthr) {
                 const double v = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
                 if (v != 0.0) atomicAdd(&tab[(size_t)k * kDecision + r], v);
             }
-        for (int r = tid, j = 0; r < I && j < 2; r += nthr, j++)
-            if (first[j]) g_visit[r] = 0x40000000u + (uint32_t)r;            // racing writers store the same value
+        if (first0) g_visit[tid] = 0x40000000u + (uint32_t)tid;              // racing writers store the same value
+        if (first1) g_visit[tid + nthr] = 0x40000000u + (uint32_t)(tid + nthr);
         for (int r = tid + 2 * nthr; r < I; r += nthr)                       // narrow workgroups (many infosets): the rest, plainly
             if (s_seen[r] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
     }
@@ -519,6 +525,7 @@ __device__ __forceinline__ ApplyRow apply_row_load(int r, const uint64_t *__rest
 
 __device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double (&d)[5], double *__restrict__ g_regret,
                                                 double *__restrict__ g_strat, double *__restrict__ g_sigcdf) {
+#pragma unroll
     for (int c = 0; c < 4; c++)
         if (c < a.n) { a.R[c] += d[c]; a.S[c] += d[4] * a.sg[c]; }
     *reinterpret_cast<double2 *>(g_regret + r * 4) = make_double2(a.R[0], a.R[1]);
@@ -532,37 +539,50 @@ __device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double
     out[0] = make_double2(sg[0], sg[1]); out[1] = make_double2(sg[2], sg[3]); out[2] = make_double2(cd[0], cd[1]); out[3] = make_double2(cd[2], cd[3]);
 }
 
-// The apply step, one thread per infoset row.  GROUPS = true (single GPU, after every traversal launch): delta = the 8 group tables
-// summed in table order, cleared on the way.  GROUPS = false (split path): delta = the [I][5] buffer the caller all-reduced, cleared.
-// The launch must find d_sigcdf current (it holds the sigma the traversal sampled with).
-template <bool GROUPS>
+// one cell (k = 0..3 regret deltas, 4 = visit count) of row r's delta: its 8 group tables summed in table order; non-zero cells are cleared
+__device__ __forceinline__ double groups_cell_take(double *__restrict__ g_groups, int r, int k) {
+    double v[kDeltaGroups];
+#pragma unroll
+    for (int g = 0; g < kDeltaGroups; g++) v[g] = g_groups[(size_t)g * kDeltaTable + (size_t)k * kDecision + r];   // 8 loads in flight
+    double d = 0.0;
+#pragma unroll
+    for (int g = 0; g < kDeltaGroups; g++) {
+        d += v[g];                                                                                               // table order
+        if (v[g] != 0.0) g_groups[(size_t)g * kDeltaTable + (size_t)k * kDecision + r] = 0.0;
+    }
+    return d;
+}
+
+// The apply step after a single-GPU traversal launch: delta = the 8 group tables summed in table order, cleared on the way.  A
+// wavefront (= a workgroup: the rows spread over as many compute units as possible) takes 8 rows, lane = 8 * row + cell: five lanes
+// of a row fetch one cell of its delta each, lane 0 of the row collects them and applies the row -- one memory round trip, few
+// loads per lane.  The launch must find d_sigcdf current (it holds the sigma the traversal sampled with).
+__global__ void __launch_bounds__(64)
+k_mccfr_apply_groups(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret, double *__restrict__ g_strat,
+                     double *__restrict__ g_groups, int n_infosets, double *__restrict__ g_sigcdf) {
+    const int lane = threadIdx.x, rl = lane >> 3, k = lane & 7;
+    const int r = blockIdx.x * 8 + rl;
+    const bool valid = r < n_infosets;
+    ApplyRow a{};
+    if (valid && k == 0) a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);
+    const double mine = (valid && k < 5) ? groups_cell_take(g_groups, r, k) : 0.0;
+    double d[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) d[j] = __shfl(mine, (lane & ~7) + j);
+    if (valid && k == 0) apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
+}
+
+// Split path (traverse | all-reduce | apply): delta = the [I][5] buffer the caller all-reduced, cleared.  One thread per infoset row.
 __global__ void __launch_bounds__(64)
 k_mccfr_apply(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret, double *__restrict__ g_strat,
               double *__restrict__ g_delta, int n_infosets, double *__restrict__ g_sigcdf) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_infosets) return;
-    double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if constexpr (GROUPS) {
-        double v[kDeltaGroups][5];
-#pragma unroll
-        for (int g = 0; g < kDeltaGroups; g++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) v[g][k] = g_delta[(size_t)g * kDeltaTable + (size_t)k * kDecision + r];   // all 40 loads in flight, coalesced over rows
-        ApplyRow a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);
-#pragma unroll
-        for (int g = 0; g < kDeltaGroups; g++)
-#pragma unroll
-            for (int k = 0; k < 5; k++) {
-                d[k] += v[g][k];                                                                                   // table order
-                if (v[g][k] != 0.0) g_delta[(size_t)g * kDeltaTable + (size_t)k * kDecision + r] = 0.0;
-            }
-        apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
-    } else {
-        for (int k = 0; k < 5; k++) d[k] = g_delta[r * 5 + k];
-        ApplyRow a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);
-        for (int k = 0; k < 5; k++) g_delta[r * 5 + k] = 0.0;
-        apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
-    }
+    double d[5];
+    for (int k = 0; k < 5; k++) d[k] = g_delta[r * 5 + k];
+    ApplyRow a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);
+    for (int k = 0; k < 5; k++) g_delta[r * 5 + k] = 0.0;
+    apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
 }
 
 // N > 1, after a traversal launch: this rank's delta of an infoset row (its 8 group tables summed in table order, then cleared)
@@ -575,19 +595,10 @@ k_mccfr_exchange_apply(scopa::P2PArgs xa, double *__restrict__ g_groups, const u
     const int rl = threadIdx.x >> 4, q = threadIdx.x & 15;
     const int r = blockIdx.x * 4 + rl;
     const bool valid = r < n_infosets;
-    double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-    if (valid) {
-        for (int g = 0; g < kDeltaGroups; g++) {
-            const double *p = g_groups + (size_t)g * kDeltaTable + r;
-            for (int k = 0; k < 5; k++) d[k] += p[(size_t)k * kDecision];   // the 16 lanes of a row compute the same sum
-        }
-    }
-    // every lane has loaded before any lane of this wavefront stores (one instruction stream), and no other wavefront touches the row
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_wave_barrier();
-    if (valid && q == 0)
-        for (int g = 0; g < kDeltaGroups; g++)
-            for (int k = 0; k < 5; k++) g_groups[(size_t)g * kDeltaTable + (size_t)k * kDecision + r] = 0.0;
+    const double mine = (valid && q < 5) ? groups_cell_take(g_groups, r, q) : 0.0;       // lanes 0..4 of a row: one cell each (and clear it)
+    double d[5];
+#pragma unroll
+    for (int j = 0; j < 5; j++) d[j] = __shfl(mine, (int)(threadIdx.x & ~15u) + j);      // every lane of the row holds the row's delta
     ApplyRow a{};
     if (valid && q == 0) a = apply_row_load(r, g_key, g_regret, g_strat, g_sigcdf);   // under the exchange's waits
     scopa::p2p_exchange_wave4(xa, r, valid, q, d, xch[rl]);
@@ -829,7 +840,7 @@ int32_t scopa_mccfr_apply(scopa_ctx *ctx) {
                            ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
         SC_HIP(ctx, hipGetLastError());
     }
-    hipLaunchKernelGGL(k_mccfr_apply<false>, dim3((ctx->n_infosets + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_key,
+    hipLaunchKernelGGL(k_mccfr_apply, dim3((ctx->n_infosets + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_key,
                        ctx->d_regret, ctx->d_strat, ctx->d_delta, ctx->n_infosets, ctx->d_sigcdf);
     SC_HIP(ctx, hipGetLastError());
     ctx->sigcdf_valid = true;
@@ -852,7 +863,7 @@ int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
     for (uint32_t it = 0; it < n_iters; it++) {
         const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch);
         if (rc != SCOPA_OK) return rc;
-        hipLaunchKernelGGL(k_mccfr_apply<true>, dim3((ctx->n_infosets + 63) / 64), dim3(64), 0, ctx->stream, ctx->d_key,
+        hipLaunchKernelGGL(k_mccfr_apply_groups, dim3((ctx->n_infosets + 7) / 8), dim3(64), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf);
         SC_HIP(ctx, hipGetLastError());
         ctx->sigcdf_valid = true;

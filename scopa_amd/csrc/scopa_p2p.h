@@ -18,7 +18,8 @@ constexpr int kP2PMaxWorld = 16;
 constexpr int kP2PLineDoubles = 8;
 
 struct P2PArgs {
-    double *inbox[kP2PMaxWorld];   // every rank's inbox as mapped in this process ([rank] = the local one)
+    double *const *inbox;          // [world] device-resident table: every rank's inbox as mapped in this process ([rank] = the local one); a table in
+                                   // memory, not an array in the kernel arguments: indexing those by lane would put them in scratch
     unsigned int *err;             // waits that gave up (device word; non-zero makes all later waits fall through)
     unsigned int *err_host;        // the same verdict in pinned host memory: the host reads it after a stream sync, without a copy
     int light;                     // 0: plain accesses + system-scope fences; 1: sc0 sc1 accesses ordered by s_waitcnt (see below)

@@ -36,6 +36,7 @@ struct scopa_p2p {
     unsigned int *d_err = nullptr;
     unsigned int *h_err = nullptr;          // pinned host word, set by the first wait that gives up ...
     unsigned int *h_err_dev = nullptr;      // ... and its device-side address
+    double **d_inbox_tab = nullptr;         // peer[] on the device (P2PArgs.inbox)
     unsigned long long budget = 500000000ull;  // 5 s of the 100 MHz wall clock
     int light = 0;
     bool connected = false;
@@ -63,6 +64,7 @@ void p2p_release(scopa_ctx *ctx) {
     if (p->local) (void)hipFree(p->local);
     if (p->d_err) (void)hipFree(p->d_err);
     if (p->h_err) (void)hipHostFree(p->h_err);
+    if (p->d_inbox_tab) (void)hipFree(p->d_inbox_tab);
     delete p;
     ctx->p2p = nullptr;
 }
@@ -81,7 +83,7 @@ int32_t p2p_check(scopa_ctx *ctx, const char *where) {
 bool p2p_next_args(scopa_ctx *ctx, P2PArgs *out) {
     scopa_p2p *p = ctx->p2p;
     if (!p || !p->connected) return false;
-    for (int r = 0; r < kP2PMaxWorld; r++) out->inbox[r] = static_cast<double *>(r < p->world ? p->peer[r] : nullptr);
+    out->inbox = p->d_inbox_tab;
     out->err = p->d_err;
     out->err_host = p->h_err_dev;
     out->light = p->light;
@@ -133,6 +135,11 @@ int32_t scopa_p2p_connect(scopa_ctx *ctx, const uint8_t *handles) {
         if (e != hipSuccess) return fail(ctx, SCOPA_EHIP, "scopa_p2p_connect: hipIpcOpenMemHandle", e);
         p->peer[r] = ptr; p->opened[r] = true;
     }
+    if (!p->d_inbox_tab) SC_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_inbox_tab), kP2PMaxWorld * sizeof(double *)));
+    double *tab[kP2PMaxWorld] = {nullptr};
+    for (int r = 0; r < p->world; r++) tab[r] = static_cast<double *>(p->peer[r]);
+    SC_HIP(ctx, hipMemcpyAsync(p->d_inbox_tab, tab, sizeof tab, hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     p->connected = true;
     return SCOPA_OK;
 }
