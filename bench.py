@@ -270,6 +270,7 @@ def main():
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
     ap.add_argument("--sdcfr-epochs", type=int, default=5, help="Adam steps per player per iteration (sdcfr workload)")
     ap.add_argument("--regions", type=int, default=REGIONS, help="how many times the --steps region is timed (median reported)")
+    ap.add_argument("--pre-phase-s", type=float, default=PRE_PHASE_S, help="seconds of untimed iterations before anything is timed (0 for profiler passes that count every dispatch)")
     ap.add_argument("--prof-stride", type=int, default=0, help="bracket every n-th traversal launch with HIP events (0 = so that >= 64 launches are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--exchange", choices=["auto", "p2p", "rccl"], default="auto",
@@ -374,7 +375,7 @@ def main():
     run(100)
     fence()
     per_step = all_max((time.perf_counter() - t0) / 100)
-    n_pre = int(min(max(PRE_PHASE_S / per_step, 100), 200000))
+    n_pre = int(min(max(args.pre_phase_s / per_step, 100), 200000))
     fence()
     t0 = time.perf_counter()
     run(n_pre)

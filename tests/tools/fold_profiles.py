@@ -1,30 +1,79 @@
 #!/usr/bin/env python3
-"""Fold rocprofv3 outputs merged into gpurun_out/ into the tracked summaries under profiles/ (run in the build container).
-    python tests/tools/fold_profiles.py gpurun_out/fin_stats2 gpurun_out/fin_pmc_fetch gpurun_out/fin_pmc_write [stats_bench.json]"""
-import collections, csv, glob, json, os, statistics as st, sys
+"""Fold the rocprofv3 outputs of tests/tools/profile_round.sh (merged into gpurun_out/prof/ by gpurun) into the tracked summaries
+under profiles/ (run in the build container):
+    python tests/tools/fold_profiles.py [gpurun_out/prof] [round-tag, default r02]
+Writes  profiles/<tag>_kernel_stats.csv, <tag>_bench_n1_under_rocprof_stats.json   (kernel durations of the bench command)
+        profiles/<tag>_pmc_FETCH_SIZE.csv, <tag>_pmc_WRITE_SIZE.csv, hbm_traffic.json (HBM bytes per launch, gfx950 correction)
+        profiles/<tag>_pmc_sq_traverse_b<batch>.json, traverse_sq.json               (SQ counters of k_mccfr_traverse per pair)
+hbm_traffic.json and traverse_sq.json are what bench.py reads for roofline.traffic and the VALU / LDS ceilings; both record the
+commit of the kernel they were measured on."""
+import collections, csv, glob, json, os, statistics as st, subprocess, sys
+
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-stats, fetch, write = sys.argv[1:4]
-open(f"{R}/profiles/r01_kernel_stats.csv", "w").write(open(glob.glob(f"{stats}/*kernel_stats.csv")[0]).read())
-if len(sys.argv) > 4:
-    open(f"{R}/profiles/r01_bench_n1_under_rocprof_stats.json", "w").write(open(sys.argv[4]).read().strip().splitlines()[-1] + "\n")
-res = {}
-for d, ctr in ((fetch, "FETCH_SIZE"), (write, "WRITE_SIZE")):
-    acc = collections.defaultdict(list)
+src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "gpurun_out", "prof")
+tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+P = os.path.join(R, "profiles")
+commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_mccfr.hip"], capture_output=True, text=True).stdout.strip()
+
+
+def counters(d):
+    """{kernel short name: {counter: [value per dispatch]}}"""
+    acc = collections.defaultdict(lambda: collections.defaultdict(list))
     for r in csv.DictReader(open(glob.glob(f"{d}/*counter_collection.csv")[0])):
-        if r["Counter_Name"] == ctr:
-            acc[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
-    rows = [dict(kernel=k, counter=ctr, dispatches=len(v), mean_KB=st.mean(v), min_KB=min(v), max_KB=max(v)) for k, v in acc.items()]
-    with open(f"{R}/profiles/r01_pmc_{ctr}.csv", "w") as fh:
+        acc[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return acc
+
+
+# 1. kernel durations
+open(f"{P}/{tag}_kernel_stats.csv", "w").write(open(glob.glob(f"{src}/stats/*kernel_stats.csv")[0]).read())
+open(f"{P}/{tag}_bench_n1_under_rocprof_stats.json", "w").write(open(f"{src}/stats_bench.json").read().strip().splitlines()[-1] + "\n")
+
+# 2. HBM traffic
+res = {}
+for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+    acc = counters(f"{src}/pmc_{ctr}")
+    rows = [dict(kernel=k, counter=ctr, dispatches=len(v[ctr]), mean_KB=st.mean(v[ctr]), min_KB=min(v[ctr]), max_KB=max(v[ctr])) for k, v in acc.items() if ctr in v]
+    with open(f"{P}/{tag}_pmc_{ctr}.csv", "w") as fh:
         w = csv.DictWriter(fh, fieldnames=["kernel", "counter", "dispatches", "mean_KB", "min_KB", "max_KB"])
         w.writeheader(); w.writerows(rows)
     res[ctr] = {r["kernel"]: r for r in rows}
 f, w = res["FETCH_SIZE"]["k_mccfr_traverse"]["mean_KB"], res["WRITE_SIZE"]["k_mccfr_traverse"]["mean_KB"]
-json.dump({"kernel": "k_mccfr_traverse", "workload": "bench.py default (B=4096 per traverser, 738 infosets)",
-           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d dispatches each (profiles/r01_pmc_*.csv)" % res["FETCH_SIZE"]["k_mccfr_traverse"]["dispatches"],
+af, aw = res["FETCH_SIZE"].get("k_mccfr_apply_groups", {}).get("mean_KB"), res["WRITE_SIZE"].get("k_mccfr_apply_groups", {}).get("mean_KB")
+json.dump({"kernel": "k_mccfr_traverse", "batch": 4096, "commit": commit,
+           "workload": "bench.py default (B=4096 per traverser, 738 infosets)",
+           "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d dispatches each (profiles/%s_pmc_*.csv; tests/tools/profile_round.sh)"
+                     % (res["FETCH_SIZE"]["k_mccfr_traverse"]["dispatches"], tag),
            "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w,
-           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> read bytes doubled (an upper bound here: not all reads are 16 B/lane); WRITE_SIZE taken as is",
+           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> read bytes doubled (an upper bound here: not all reads are 16 B/lane); WRITE_SIZE taken as is (exact for float atomics: one dword per lane)",
            "bytes_per_launch": (2 * f + w) * 1e3, "bytes_per_launch_uncorrected": (f + w) * 1e3,
-           "reduce_apply_FETCH_KB_raw": res["FETCH_SIZE"].get("void k_mccfr_reduce_apply<false>", {}).get("mean_KB"),
-           "reduce_apply_WRITE_KB": res["WRITE_SIZE"].get("void k_mccfr_reduce_apply<false>", {}).get("mean_KB")},
-          open(f"{R}/profiles/hbm_traffic.json", "w"), indent=1)
-print(open(f"{R}/profiles/hbm_traffic.json").read())
+           "apply_groups_FETCH_KB_raw": af, "apply_groups_WRITE_KB": aw,
+           "iteration_bytes": (2 * f + w + 2 * (af or 0) + (aw or 0)) * 1e3},
+          open(f"{P}/hbm_traffic.json", "w"), indent=1)
+print(open(f"{P}/hbm_traffic.json").read())
+
+# 3. SQ counters of the traversal kernel
+sq_all = {}
+for batch in (4096, 65536):
+    m = {}
+    for part in ("a", "b"):
+        for c, v in counters(f"{src}/sq_{part}_{batch}")["k_mccfr_traverse"].items():
+            m[c] = st.mean(v)
+    pairs = float(batch)
+    d = {"valu_instr_per_pair": m["SQ_INSTS_VALU"] / pairs, "lds_instr_per_pair": m["SQ_INSTS_LDS"] / pairs, "salu_instr_per_pair": m["SQ_INSTS_SALU"] / pairs,
+         "valu_busy_cycles_per_pair": 4.0 * m["SQ_ACTIVE_INST_VALU"] / pairs, "lds_array_cycles_per_pair": m["SQ_LDS_IDX_ACTIVE"] / pairs,
+         "lds_bank_conflict_share_of_lds_active": m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"],
+         "wave_time_active": m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], "wave_time_waiting_any": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
+         "wave_time_waiting_on_lds_issue": m["SQ_WAIT_INST_LDS"] / m["SQ_WAVE_CYCLES"], "wave_quad_cycles_per_wave": m["SQ_WAVE_CYCLES"] / m["SQ_WAVES"]}
+    sq_all[batch] = d
+    json.dump({"kernel": "k_mccfr_traverse", "commit": commit, "workload": f"bench.py --batch {batch} ({batch} traversal pairs per launch)",
+               "source": "rocprofv3 --kernel-trace --pmc SQ_*, two passes of 8 counters (tests/tools/profile_round.sh); SQ_* cycle counters are in quad-cycles",
+               "per_launch_mean": m, "derived": d}, open(f"{P}/{tag}_pmc_sq_traverse_b{batch}.json", "w"), indent=1)
+# what bench.py prices the ceilings with: the per-pair figures of the batch that keeps every wavefront in its loop (launch-time work amortised)
+big = sq_all[65536]
+json.dump({"kernel": "k_mccfr_traverse", "commit": commit,
+           "source": f"SQ counter passes at B=65536 (profiles/{tag}_pmc_sq_traverse_b65536.json); B=4096 figures beside them",
+           "valu_instr_per_pair": big["valu_instr_per_pair"], "valu_busy_cycles_per_pair": big["valu_busy_cycles_per_pair"],
+           "lds_array_cycles_per_pair": big["lds_array_cycles_per_pair"],
+           "b4096": {k: sq_all[4096][k] for k in ("valu_instr_per_pair", "valu_busy_cycles_per_pair", "lds_array_cycles_per_pair")}},
+          open(f"{P}/traverse_sq.json", "w"), indent=1)
+print(open(f"{P}/traverse_sq.json").read())
