@@ -488,7 +488,7 @@ def main():
                        "exchange_note": ctx.exchange_note if use_dist else None,
                        "replicas_bit_identical": replicas_identical, "sharded_10_iterations_match_one_gpu": sharded_check,
                        "shared_gpu_rehearsal": bool(args.share_gpu),
-                       "rng": "Philox4x32-10 keyed by (seed, path code, global traversal id, iteration, traverser)"},
+                       "rng": "Philox4x32-10, key = seed, counter = (block of the node's (level, branch index), global traversal id, iteration, traverser); 31-bit draws"},
             "timing": {"protocol": f"pre-phase {n_pre} iterations ({pre_s:.2f} s), then --warmup, then the --steps region timed {regions} times "
                                    "(barrier + device sync both sides, max over ranks); value and ms_per_step are the MEDIAN region",
                        "regions": regions, "region_ms_median": 1e3 * med, "region_ms_min": 1e3 * min(times), "region_ms_max": 1e3 * max(times),

@@ -279,9 +279,11 @@ def gen_mccfr_frozen(ns):
         that _sample updates (`node.regret_sum += ...`, `node.strategy_sum += ...`) starts at zero, i.e. accumulates the DELTA;
       * np.random.choice(legal, p=sigma) is replaced for the duration of a traversal by numpy's own inverse-cdf arithmetic
         (cdf = p.cumsum(); cdf /= cdf[-1]; searchsorted(u, 'right')) on u = the build's path-keyed Philox uniform of the node at
-        hand: block Philox4x32-10(key = seed; ctr = (ntl + 16 * sum(digit_k << 3k), traversal id, iteration, traverser)), words
-        0,1 at an opponent node, words 2,3 at a traverser node; digit 0 = the sampled child of a traverser node, i+1 = the
-        re-expansion of legal action i, ntl = traverser nodes above.  The node's path is read off the recursion itself."""
+        hand.  A node is (ntl, j): ntl traverser nodes above it, j its branch index at that level (child of a traverser node with n
+        legal actions: j*(n+1) for the sampled child, j*(n+1) + i + 1 for the re-expansion of legal action i; an opponent node shares
+        (ntl, j) with the traverser node below it).  block = Philox4x32-10(key = seed; ctr = ((0, 1, 4, 14)[ntl] + (j >> 1), traversal
+        id, iteration, traverser)); word 2*(j & 1) at the opponent node, 2*(j & 1) + 1 at the traverser node; u = (word >> 1) * 2^-31.
+        The node's (ntl, j) is read off the recursion itself."""
     import pyspiel
     mc = ns.mc
     game = pyspiel.load_game("mini_scopa")
@@ -305,16 +307,18 @@ def gen_mccfr_frozen(ns):
             return self.info_sets[key]
 
         def _sample(self, state, traversing_player, reach_probs, sampling_probs):
+            term = state.is_terminal()
+            n = 0 if term else len(state.legal_actions(state.current_player()))
             if self.stack:
                 par = self.stack[-1]
-                if par["is_trav"]:
-                    digits = par["digits"] + (par["calls"],)
+                if par["is_trav"]:       # child of a traverser node with n legal actions: j*(n+1) + (0 = sampled child, i+1 = re-expansion of action i)
+                    ntl, j = par["ntl"] + 1, par["j"] * (par["n"] + 1) + par["calls"]
                     par["calls"] += 1
                 else:
-                    digits = par["digits"]
+                    ntl, j = par["ntl"], par["j"]
             else:
-                digits = ()
-            self.stack.append(dict(digits=digits, calls=0, is_trav=(not state.is_terminal()) and state.current_player() == traversing_player))
+                ntl, j = 0, 0
+            self.stack.append(dict(ntl=ntl, j=j, n=n, calls=0, is_trav=(not term) and state.current_player() == traversing_player))
             try:
                 return super()._sample(state, traversing_player, reach_probs, sampling_probs)
             finally:
@@ -326,11 +330,9 @@ def gen_mccfr_frozen(ns):
 
         def choice(legal, p=None):
             fr = tr.stack[-1]
-            ntl = len(fr["digits"])
-            code = sum(d << (3 * k) for k, d in enumerate(fr["digits"]))
-            o = _philox4x32_10((ntl + 16 * code, cur["b"], iteration, cur["trav"]), (seed & 0xFFFFFFFF, seed >> 32))
-            a, b = (o[2], o[3]) if fr["is_trav"] else (o[0], o[1])
-            u = ((a >> 5) * 67108864.0 + (b >> 6)) / 9007199254740992.0
+            block = (0, 1, 4, 14)[min(fr["ntl"], 3)] + (fr["j"] >> 1)
+            o = _philox4x32_10((block, cur["b"], iteration, cur["trav"]), (seed & 0xFFFFFFFF, seed >> 32))
+            u = (o[2 * (fr["j"] & 1) + (1 if fr["is_trav"] else 0)] >> 1) / 2147483648.0
             cdf = np.asarray(p, np.float64).cumsum()
             cdf /= cdf[-1]
             idx = int(cdf.searchsorted(u, side="right"))

@@ -488,12 +488,12 @@ double og_philox_uniform(uint64_t seed, uint32_t c0, uint32_t c1, uint32_t c2, u
 }
 
 /* ===== batched MCCFR (frozen tables, path-keyed RNG) ================================ */
-/* A node of one traversal's recursion tree is named by the branches taken at the traverser nodes above
- * it: digit 0 = the sampled child (mc_cfr.py:55-67), digit i+1 = the re-expansion of legal action i
- * (:72-78); `ntl` = how many traverser nodes lie above.  An opponent node and the traverser node that
- * follows it share (ntl, digits); one Philox block serves both:
- *   block = Philox4x32-10(key = seed; ctr = (ntl + 16*sum(digit_k * 8^k), traversal id, iteration, traverser))
- *   opponent node: u = u53(x0, x1)      traverser node: u = u53(x2, x3)                                   */
+/* A node of one traversal's recursion tree is named by (ntl, j): ntl = how many traverser nodes lie above it, j = its branch index at
+ * that level -- at a traverser node with n legal actions the sampled child (mc_cfr.py:55-67) is j*(n+1) and the re-expansion of legal
+ * action i (:72-78) is j*(n+1) + i + 1.  An opponent node and the traverser node that follows it share (ntl, j).  Draws:
+ *   block = Philox4x32-10(key = seed; ctr = (first block of level ntl + (j >> 1), traversal id, iteration, traverser)),
+ *           first block of level 0,1,2,3 = 0,1,4,14
+ *   word  = 2 * (j & 1) + (1 at the traverser node, 0 at the opponent node);   u = (word >> 1) * 2^-31                              */
 typedef struct {
     const og_tree *t; const double *R; double *dR, *dS;
     uint64_t seed; uint32_t iter, b; int trav;
@@ -506,27 +506,27 @@ static double u53(uint32_t a, uint32_t b) {
     return ((double)(a >> 5) * 67108864.0 + (double)(b >> 6)) / 9007199254740992.0;
 }
 
-static double mcb_rec(bctx *c, int node, uint32_t digits, int ntl, double reach_opp, double samp_trav) {
+static double mcb_rec(bctx *c, int node, uint32_t j, int ntl, double reach_opp, double samp_trav) {
+    static const uint32_t first_block[4] = {0u, 1u, 4u, 14u};
     const og_tree *t = c->t;
     if (t->term[node]) { c->tvis++; return (double)t->r2[node * 2 + c->trav] * 0.5; }
     c->dvis++;
     int p = t->player[node], I = t->infoset[node], n = t->nlegal[node];
     double sigma[4];
     mc_strategy(c->R + I * 4, n, sigma);
-    uint32_t ctr[4] = {(uint32_t)ntl + 16u * digits, c->b, c->iter, (uint32_t)c->trav};
+    uint32_t ctr[4] = {first_block[ntl < 3 ? ntl : 3] + (j >> 1), c->b, c->iter, (uint32_t)c->trav};
     uint32_t key[2] = {(uint32_t)c->seed, (uint32_t)(c->seed >> 32)}, o[4];
     og_philox4x32_10(ctr, key, o);
-    double u = p == c->trav ? u53(o[2], o[3]) : u53(o[0], o[1]);
+    double u = (double)(o[2 * (j & 1u) + (p == c->trav ? 1u : 0u)] >> 1) / 2147483648.0;
     int a = np_choice(sigma, n, u);
     if (c->tr_nodes && c->tr_n < c->tr_max) { c->tr_nodes[c->tr_n] = node; c->tr_actions[c->tr_n] = (int8_t)a; }
     c->tr_n++;
     if (p != c->trav)
-        return mcb_rec(c, t->child[node * 4 + a], digits, ntl, reach_opp * sigma[a], samp_trav);
-    double util = mcb_rec(c, t->child[node * 4 + a], digits, ntl + 1, reach_opp, samp_trav * sigma[a]);
+        return mcb_rec(c, t->child[node * 4 + a], j, ntl, reach_opp * sigma[a], samp_trav);
+    double util = mcb_rec(c, t->child[node * 4 + a], j * (uint32_t)(n + 1), ntl + 1, reach_opp, samp_trav * sigma[a]);
     double cfv[4];
     for (int i = 0; i < n; i++)
-        cfv[i] = mcb_rec(c, t->child[node * 4 + i], digits + ((uint32_t)(i + 1) << (3 * ntl)), ntl + 1, reach_opp,
-                         samp_trav * sigma[i]);
+        cfv[i] = mcb_rec(c, t->child[node * 4 + i], j * (uint32_t)(n + 1) + (uint32_t)(i + 1), ntl + 1, reach_opp, samp_trav * sigma[i]);
     double v = np_dot(sigma, cfv, n);
     double w = samp_trav > 0.0 ? reach_opp / samp_trav : 0.0;
     if (c->dR)

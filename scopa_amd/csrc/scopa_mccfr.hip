@@ -15,10 +15,11 @@
 // sampling its action from the frozen sigma|cdf row and leaving its own record for the next ply.  The 16 wavefronts
 // of a workgroup run their pairs independently -- only wave-level LDS ordering between plies, no workgroup barrier
 // in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).
-// Random draws are Philox4x32-10 blocks keyed by the node's PATH (ntl + 16*digits, global traversal id, iteration,
-// traverser), all 112 blocks of a pair computed in a dense pre-pass (draw_pair) and kept as 53-bit integers that are compared
-// with integer thresholds ceil(cdf * 2^53): words 0,1 feed the opponent node, words 2,3 the traverser node below it -- so
-// results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
+// Random draws are Philox4x32-10 blocks keyed by the node's PATH: a node is (traverser, ntl, j) -- ntl traverser plies above it, j its
+// branch index at that level in mixed radix (5,4,3) -- and block (ntl, j >> 1) of the (global traversal id, iteration, traverser)
+// stream serves the four nodes (j even | odd) x (opponent node | traverser node below it), one 32-bit word each.  All 58 blocks of a
+// pair are computed in ONE dense pre-pass (draw_pair) and kept as 31-bit integers that are compared with integer thresholds
+// ceil(cdf * 2^31) -- so results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
 // The update step then gives one lane per traverser node (26 per task): v as the reference's fma chain over <= 4 leaf
 // payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Everything a pair touches is LDS resident
 // (sigma|threshold rows 41 KB, delta 24 KB, 16 x 3.1 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
@@ -56,10 +57,10 @@ __device__ __forceinline__ void mc_sigma(const double *R, int n, double *sigma) 
 }
 
 // np.random.choice(legal, p=sigma): cdf = p.cumsum(); cdf /= cdf[-1]; index = cdf.searchsorted(u, 'right') = #{cdf_i <= u}.
-// Every u here is k * 2^-53 with an integer k < 2^53 (u53 of two Philox words), and cdf_i * 2^53 is exact in float64, so
-// cdf_i <= u  <=>  ceil(cdf_i * 2^53) <= k: the row stores those integer thresholds (bit patterns in the double slots) and the
-// walk compares integers -- the same answer bit for bit, without int->float64 conversions and float64 compares per draw.
-__device__ __forceinline__ void choice_cdf(const double *sigma, int n, double *cdf_bits) {
+// Every u here is k * 2^-31 with an integer k < 2^31 (the top 31 bits of one Philox word), and cdf_i * 2^31 is exact in float64, so
+// cdf_i <= u  <=>  ceil(cdf_i * 2^31) <= k: the row stores those integer thresholds (0 .. 2^31 fit a uint32; 2^31 = never) and the
+// walk compares 32-bit integers -- the same answer as numpy's float64 compare bit for bit, without conversions per draw.
+__device__ __forceinline__ void choice_cdf(const double *sigma, int n, uint32_t *thr) {
     double cdf[4];
     double c = sigma[0];
     cdf[0] = c;
@@ -67,10 +68,15 @@ __device__ __forceinline__ void choice_cdf(const double *sigma, int n, double *c
     for (int i = 1; i < 4; i++) { if (i < n) c += sigma[i]; cdf[i] = c; }
     const double last = c;   // = cdf[n - 1]
 #pragma unroll
-    for (int i = 0; i < 4; i++) {
-        const unsigned long long t = i < n ? (unsigned long long)ceil((cdf[i] / last) * 9007199254740992.0) : ~0ull;  // padding never counts
-        cdf_bits[i] = __longlong_as_double((long long)t);
-    }
+    for (int i = 0; i < 4; i++) thr[i] = i < n ? (uint32_t)ceil((cdf[i] / last) * 2147483648.0) : 0xFFFFFFFFu;  // padding never counts
+}
+// a frozen row as it is kept in HBM, [8] float64: sigma[4] | thresholds as 4 x uint32 | 16 bytes unused
+__device__ __forceinline__ void row_store(double *__restrict__ row, const double *sg, const uint32_t *thr) {
+    double2 *out = reinterpret_cast<double2 *>(row);
+    out[0] = make_double2(sg[0], sg[1]);
+    out[1] = make_double2(sg[2], sg[3]);
+    out[2] = make_double2(__longlong_as_double((long long)(((unsigned long long)thr[1] << 32) | thr[0])),
+                          __longlong_as_double((long long)(((unsigned long long)thr[3] << 32) | thr[2])));
 }
 // the plain float64 form, for the replay kernel whose uniforms come from the host
 __device__ __forceinline__ void choice_cdf_f64(const double *sigma, int n, double *cdf) {
@@ -80,7 +86,6 @@ __device__ __forceinline__ void choice_cdf_f64(const double *sigma, int n, doubl
     const double last = cdf[n - 1];
     for (int i = 0; i < 4; i++) cdf[i] = i < n ? cdf[i] / last : 2.0;  // 2.0 > any u: padding never counts
 }
-__device__ __forceinline__ unsigned long long k53(uint32_t a, uint32_t b) { return ((unsigned long long)(a >> 5) << 26) | (unsigned long long)(b >> 6); }
 
 // traverser plies strictly above ply d, and nodes of ply d (d <= 6) in one task's recursion tree
 __host__ __device__ constexpr int ntl_at(int trav, int d) { return trav == 0 ? (d + 1) >> 1 : d >> 1; }
@@ -88,10 +93,9 @@ __host__ __device__ constexpr int task_nodes(int trav, int d) {
     return ntl_at(trav, d) == 0 ? 1 : ntl_at(trav, d) == 1 ? 5 : ntl_at(trav, d) == 2 ? 20 : 60;
 }
 
-constexpr int kRow = 7;   // doubles per frozen row in LDS: sigma[4] | 3 cdf thresholds.  The last threshold of a row is always >= 2^53
-                           // (cdf[n-1] = 1.0, padding = ~0) and never counts, so it is not kept; the 56-byte stride also spreads
-                           // random-row gathers over 32 bank alignments (64-byte rows could only start at 4 of them: every gather
-                           // was >= 4-way bank-conflicted, SQ_LDS_BANK_CONFLICT = 47 % of LDS cycles)
+constexpr int kRow = 6;   // doubles per frozen row in LDS: sigma[4] | 4 x uint32 thresholds (the last one of a row never counts: cdf[n-1] = 1.0
+                           // -> 2^31, padding = ~0).  48-byte rows start at 16 different bank alignments (64-byte rows could only start
+                           // at 4: every random-row gather was >= 4-way bank-conflicted, SQ_LDS_BANK_CONFLICT = 47 % of LDS cycles)
 constexpr int kUpd = 26;  // traverser nodes with > 1 legal action per task: 1 + 5 + 20
 
 }  // namespace
@@ -102,11 +106,12 @@ k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r >= n_infosets) return;
     const int n = (int)((g_key[r] >> 1) & 7);
-    double R[4], sg[4], cd[4];
+    double R[4], sg[4];
+    uint32_t thr[4];
     for (int c = 0; c < 4; c++) R[c] = g_regret[r * 4 + c];
     mc_sigma(R, n, sg);
-    choice_cdf(sg, n, cd);
-    for (int c = 0; c < 4; c++) { g_sigcdf[r * 8 + c] = sg[c]; g_sigcdf[r * 8 + 4 + c] = cd[c]; }
+    choice_cdf(sg, n, thr);
+    row_store(g_sigcdf + r * 8, sg, thr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -117,12 +122,11 @@ struct WaveScratch {
     double upds[2 * kUpd];   // ... and own sampling probability at every traverser node with > 1 action
     uint16_t updI[2 * kUpd]; // ... and its infoset
     int8_t p6[2 * 60];       // resolved leaf payoffs x2 (traverser's sign) per task
-    // the pair's random draws, one Philox block per (traverser, ntl, branch prefix): 53-bit integers.  Only the halves that are
-    // consumed are kept: words 0,1 (kx) feed the opponent node, words 2,3 (ky) the traverser node below it.
-    unsigned long long kx0[86];  // traverser 0: opponent nodes of plies 1,3,5   (blocks 1..85; slot 0 unused)
-    unsigned long long ky0[26];  // traverser 0: traverser nodes of plies 0,2,4
-    unsigned long long kx1[26];  // traverser 1: opponent nodes of plies 0,2,4
-    unsigned long long ky1[26];  // traverser 1: traverser nodes of plies 1,3,5
+    // the pair's random draws, 31-bit integers, indexed by node (base(ntl) + j, base = 0, 1, 6, 26); only the ones consumed are kept
+    uint32_t kx0[86];        // traverser 0: opponent nodes of plies 1,3,5   (slot 0 unused)
+    uint32_t ky0[26];        // traverser 0: traverser nodes of plies 0,2,4
+    uint32_t kx1[26];        // traverser 1: opponent nodes of plies 0,2,4
+    uint32_t ky1[26];        // traverser 1: traverser nodes of plies 1,3,5
 };
 static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch must keep 16-byte alignment");
 
@@ -135,36 +139,29 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
-// All random draws of one traversal pair in a dense pre-pass: 86 + 26 Philox blocks over 64 lanes (2 rounds = 40 64-bit
-// multiplies per wavefront instead of one Philox per ply round at 3-60 % lane use).  Block (traverser, ntl, j): j indexes the
-// branch prefix in the same mixed radix (5,4,3) as the node index of its ply; counter = (ntl + 16*digits, b, iteration, traverser).
-// Philox counter word 0 of draw block `item` (0..85: traverser 0's blocks, 86..111: traverser 1's): ntl + 16 * digits.  Computed
-// once per workgroup into a 112-entry LDS table: the mixed-radix decode costs ~30 VALU instructions per lane and round, and the
-// VALU pipes are what this kernel is bound by.
-constexpr int kDrawItems = 86 + 26;
-constexpr int kStaticLds = 64 + 512;   // s_vis (+ alignment) and the draw table, beside the dynamic LDS
-__device__ __forceinline__ uint32_t draw_counter0(int item) {
-    const int blk = item < 86 ? item : item - 86;
-    const int ntl = blk == 0 ? 0 : blk < 6 ? 1 : blk < 26 ? 2 : 3;
-    const int j = blk - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26);
-    uint32_t dig;
-    if (ntl <= 1) dig = (uint32_t)j;
-    else if (ntl == 2) dig = (uint32_t)(j / 4) | ((uint32_t)(j % 4) << 3);
-    else dig = (uint32_t)(j / 12) | ((uint32_t)((j / 3) % 4) << 3) | ((uint32_t)(j % 3) << 6);
-    return (uint32_t)ntl + 16u * dig;
-}
+// All random draws of one traversal pair in ONE dense pass: 44 + 14 Philox blocks on 58 lanes (20 64-bit multiplies per wavefront;
+// the first form drew one block per ply round at 3-60 % lane use, the second 112 blocks of which half the words went unused).
+// Lane < 44: traverser 0's block `lane`; lanes 44..57: traverser 1's block `lane - 44`.  Block p of a traverser covers ntl = 0 (p = 0),
+// 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair j0 = 2 * (p - first block of the level), j0 + 1; its words are
+// x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the traverser node below it.
+// Philox counter = (p, global traversal id, iteration, traverser), key = seed.
+constexpr int kStaticLds = 64;   // s_vis (+ alignment), beside the dynamic LDS
 
-__device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi,
-                                          const uint32_t *__restrict__ s_c0) {
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int item = r * 64 + lane;
-        if (item < kDrawItems) {
-            const int trav = item < 86 ? 0 : 1, blk = trav ? item - 86 : item;
-            const philox_out x = philox4x32_10(s_c0[item], b, iteration, (uint32_t)trav, seed_lo, seed_hi);
-            const unsigned long long kx = k53(x.x0, x.x1), ky = k53(x.x2, x.x3);
-            if (trav == 0) { ws.kx0[blk] = kx; if (blk < 26) ws.ky0[blk] = ky; }
-            else           { ws.kx1[blk] = kx; ws.ky1[blk] = ky; }
+__device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
+    if (lane < 58) {
+        const int trav = lane < 44 ? 0 : 1, p = trav ? lane - 44 : lane;
+        const int ntl = p == 0 ? 0 : p < 4 ? 1 : p < 14 ? 2 : 3;
+        const int j0 = 2 * (p - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 4 : 14));
+        const int node = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j0;            // index into the kx / ky arrays
+        const bool two = j0 + 1 < (ntl == 0 ? 1 : ntl == 1 ? 5 : ntl == 2 ? 20 : 60);      // the level has an odd node count at ntl 0, 1
+        const philox_out x = philox4x32_10((uint32_t)p, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
+        if (trav == 0) {
+            ws.kx0[node] = x.x0 >> 1;
+            if (two) ws.kx0[node + 1] = x.x2 >> 1;
+            if (ntl < 3) { ws.ky0[node] = x.x1 >> 1; if (two) ws.ky0[node + 1] = x.x3 >> 1; }
+        } else {
+            ws.kx1[node] = x.x0 >> 1; ws.ky1[node] = x.x1 >> 1;
+            if (two) { ws.kx1[node + 1] = x.x2 >> 1; ws.ky1[node + 1] = x.x3 >> 1; }
         }
     }
     wave_lds_sync();
@@ -224,9 +221,9 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
             s_seen[In] = 1;  // benign race: every writer stores 1
             // this node's draw: block (ntl, j) of its traverser, prepared by draw_pair()
             const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
-            const unsigned long long k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
-            const unsigned long long *thr = reinterpret_cast<const unsigned long long *>(s_sigcdf + In * kRow + 4);
-            // only the first n-1 thresholds can count (those from n-1 on are >= 2^53 > k): one LDS read at the n = 2 plies, where
+            const uint32_t k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
+            const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + In * kRow + 4);
+            // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
             // most nodes are, instead of three
             int a = (thr[0] <= k);
             if constexpr (n > 2) a += (thr[1] <= k);
@@ -257,8 +254,8 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
 __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
-                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const uint32_t *__restrict__ s_c0) {
-    draw_pair(ws, lane, b, iteration, seed_lo, seed_hi, s_c0);
+                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis) {
+    draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
     // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
     NodeRegs st = {1.0, 1.0, 0u};
@@ -330,11 +327,10 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                  unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
-    __shared__ uint32_t s_c0[128];
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
     const int I = n_infosets;
-    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | cdf thresholds[3]
-    double *s_dR = s_sigcdf + (size_t)I * kRow + (I & 1);                        // [I][4] (16-byte aligned)
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows)
+    double *s_dR = s_sigcdf + (size_t)I * kRow;                                  // [I][4] (16-byte aligned)
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));  // [I] traverser visits
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));  // [1653] (+pad)
@@ -343,7 +339,6 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
-    if (tid < kDrawItems) s_c0[tid] = draw_counter0(tid);
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
     // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue),
     // the LDS zeroing runs underneath them, then the loaded pieces are stored.
@@ -351,10 +346,9 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     {
         constexpr int kSig = 7;                                                   // pieces per thread held in registers: covers I <= 1653 at 1024 threads
         const double2 *g2 = reinterpret_cast<const double2 *>(g_sigcdf);
-        auto put = [&](int idx, double2 x) {                                      // 16-byte piece idx of the [I][8] rows -> the 7-double LDS rows
-            const int row = idx >> 2, piece = idx & 3;                            // pieces 0,1: sigma[4]; 2: thresholds 0,1; 3: threshold 2 (| unused)
-            s_sigcdf[row * kRow + piece * 2] = x.x;
-            if (piece * 2 + 1 < kRow) s_sigcdf[row * kRow + piece * 2 + 1] = x.y;
+        auto put = [&](int idx, double2 x) {                                      // 16-byte piece idx of the [I][8] rows -> the 48-byte LDS rows
+            const int row = idx >> 2, piece = idx & 3;                            // pieces 0,1: sigma[4]; 2: the four thresholds; 3: unused
+            if (piece < 3) *reinterpret_cast<double2 *>(s_sigcdf + row * kRow + piece * 2) = x;
         };
         double2 v[kSig];
 #pragma unroll
@@ -387,7 +381,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, s_c0);
+        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis);
     }
     __syncthreads();
 
@@ -435,8 +429,6 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
               uint32_t batch) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
-    __shared__ uint32_t s_c0[128];
-    if (threadIdx.x < kDrawItems) s_c0[threadIdx.x] = draw_counter0(threadIdx.x);
     {
         const size_t deal = blockIdx.x;
         g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision; g_regret += deal * kDecision * 4;
@@ -444,7 +436,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     }
     const int I = g_meta[0];
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow] frozen rows
-    double *s_R = s_sigcdf + (size_t)I * kRow + (I & 1);                         // [I][4] live regret table
+    double *s_R = s_sigcdf + (size_t)I * kRow;                                   // [I][4] live regret table
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_R + (size_t)I * 4);
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));
@@ -462,14 +454,15 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     for (uint32_t it = 0; it < n_iters; it++) {
         for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
             const int n = (int)((g_key[r] >> 1) & 7);
-            double sg[4], cd[4];
+            double sg[4];
+            uint32_t thr[4];
             mc_sigma(s_R + r * 4, n, sg);
-            choice_cdf(sg, n, cd);
-            for (int c = 0; c < 4; c++) { s_sigcdf[r * kRow + c] = sg[c]; if (c < 3) s_sigcdf[r * kRow + 4 + c] = cd[c]; }
+            choice_cdf(sg, n, thr);
+            for (int c = 0; c < 4; c++) { s_sigcdf[r * kRow + c] = sg[c]; reinterpret_cast<uint32_t *>(s_sigcdf + r * kRow + 4)[c] = thr[c]; }
         }
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
-            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, s_c0);
+            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis);
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
@@ -532,11 +525,11 @@ __device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double
     *reinterpret_cast<double2 *>(g_regret + r * 4 + 2) = make_double2(a.R[2], a.R[3]);
     *reinterpret_cast<double2 *>(g_strat + r * 4) = make_double2(a.S[0], a.S[1]);
     *reinterpret_cast<double2 *>(g_strat + r * 4 + 2) = make_double2(a.S[2], a.S[3]);
-    double sg[4], cd[4];
+    double sg[4];
+    uint32_t thr[4];
     mc_sigma(a.R, a.n, sg);
-    choice_cdf(sg, a.n, cd);
-    double2 *out = reinterpret_cast<double2 *>(g_sigcdf + r * 8);
-    out[0] = make_double2(sg[0], sg[1]); out[1] = make_double2(sg[2], sg[3]); out[2] = make_double2(cd[0], cd[1]); out[3] = make_double2(cd[2], cd[3]);
+    choice_cdf(sg, a.n, thr);
+    row_store(g_sigcdf + r * 8, sg, thr);
 }
 
 // one cell (k = 0..3 regret deltas, 4 = visit count) of row r's delta: its 8 group tables summed in table order; non-zero cells are cleared
@@ -704,7 +697,7 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
 
 // ---------------------------------------------------------------------------------------------------------------------
 static size_t traverse_lds_bytes(int n_infosets, int waves) {
-    size_t b = ((size_t)n_infosets * (kRow + 4) + (n_infosets & 1)) * sizeof(double);  // sigma|cdf rows (padded), delta table
+    size_t b = (size_t)n_infosets * (kRow + 4) * sizeof(double);  // sigma|threshold rows, delta table
     b += (size_t)waves * sizeof(WaveScratch);                  // per-wavefront records
     b += (((size_t)n_infosets * 4 + 15) & ~(size_t)15);        // visit counts
     b += 1656 * 2 + 576;                                       // node -> infoset, leaf payoffs
@@ -755,7 +748,7 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
                            unsigned long long *d_counters, uint64_t seed, uint32_t iter0, uint32_t n_iters, uint32_t batch) {
     int waves = 16;
     auto need = [&](int w) {
-        size_t b = ((size_t)max_infosets * (kRow + 4) + 1) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
+        size_t b = (size_t)max_infosets * (kRow + 4) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
         b += (((size_t)max_infosets * 4 + 15) & ~(size_t)15) + 1656 * 2 + 576 + (size_t)max_infosets;
         return (b + 15) & ~(size_t)15;
     };
