@@ -23,6 +23,15 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes) {
 // (hipExtLaunchKernelGGL): the events carry the kernel's own begin/end timestamps, i.e. what a profiler reports as its
 // duration, without the dispatch gaps that hipEventRecord before/after a launch would add.  Returns false when this launch
 // is not sampled (profiling off, or not the stride's turn).
+// the event pool is created when profiling is switched on, not at the first sampled launch (that one launch took a millisecond)
+static void prof_pool_fill(scopa_ctx *ctx) {
+    while (ctx->ev_pool.size() < 4096) {
+        hipEvent_t e;
+        if (hipEventCreate(&e) != hipSuccess) break;
+        ctx->ev_pool.push_back(e);
+    }
+}
+
 bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
     if (!ctx->prof_on) return false;
     if ((ctx->prof_tick++ % ctx->prof_stride) != 0) return false;
@@ -36,11 +45,7 @@ bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
             }
             ctx->ev_used = 0;
         }
-        while (ctx->ev_pool.size() < 4096) {
-            hipEvent_t e;
-            if (hipEventCreate(&e) != hipSuccess) break;
-            ctx->ev_pool.push_back(e);
-        }
+        if (ctx->ev_pool.empty()) prof_pool_fill(ctx);
     }
     if (ctx->ev_used + 2 > ctx->ev_pool.size()) return false;
     *start = ctx->ev_pool[ctx->ev_used];
@@ -362,6 +367,7 @@ int32_t scopa_prof_enable(scopa_ctx *ctx, int32_t stride) {
     ctx->ev_used = 0;
     ctx->prof_launches = 0;
     ctx->prof_ms = 0.0;
+    if (ctx->prof_on) scopa::prof_pool_fill(ctx);
     if (ctx->prof_on && !ctx->d_clock)
         SC_HIP(ctx, hipMalloc(&ctx->d_clock, (size_t)scopa::kClockSamples * scopa::kClockStride * sizeof(unsigned long long)));
     return SCOPA_OK;
