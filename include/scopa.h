@@ -123,6 +123,9 @@ int32_t scopa_visited_get(scopa_ctx *ctx, uint32_t *h_seq);
 int32_t scopa_cfr_exact_iterate(scopa_ctx *ctx, int32_t n_iters, double *h_root_values);
 /* one traversal: CFRTrainer._cfr_recursive(new_initial_state(), player, 1.0, 1.0) -> value */
 int32_t scopa_cfr_exact_traverse(scopa_ctx *ctx, int32_t traverser, double *h_value);
+/* whole-tree traversals run as a schedule of ~75 parallel steps (same per-infoset visit order, bit-identical tables); 1 forces the
+ * one-lane sequential walk, the form the schedule is checked against */
+int32_t scopa_cfr_exact_mode(scopa_ctx *ctx, int32_t sequential);
 /* CFRTrainer._cfr_recursive(state, player, reach_p0, reach_p1) for any state of the tree: the state reached from the
  * root by legal-action INDICES path[0..depth) (index into legal_actions(), i.e. hand position) */
 int32_t scopa_cfr_exact_traverse_from(scopa_ctx *ctx, int32_t traverser, int32_t depth, const int32_t *path,

@@ -23,7 +23,7 @@ SYMBOLS = [
     "scopa_state_current_player", "scopa_state_legal", "scopa_state_rewards_x2", "scopa_state_infoset_key",
     "scopa_key_to_string", "scopa_state_infoset_string", "scopa_step_batch", "scopa_step_batch_host", "scopa_set_deal",
     "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
-    "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
+    "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_mode", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_features_from_states",
@@ -107,6 +107,7 @@ def lib():
         "scopa_tables_set": (i32, [vp, vp, vp, vp]),
         "scopa_cfr_exact_iterate": (i32, [vp, i32, vp]),
         "scopa_cfr_exact_traverse": (i32, [vp, i32, C.POINTER(C.c_double)]),
+        "scopa_cfr_exact_mode": (i32, [vp, i32]),
         "scopa_cfr_exact_traverse_from": (i32, [vp, i32, i32, vp, C.c_double, C.c_double, C.POINTER(C.c_double)]),
         "scopa_visited_get": (i32, [vp, vp]),
         "scopa_mccfr_replay": (i32, [vp, i32, vp, i64, C.POINTER(i64)]),
@@ -299,6 +300,10 @@ class Context:
         rv = np.zeros((max(int(n_iters), 0), 2))
         self._ck(self._L.scopa_cfr_exact_iterate(self._h, int(n_iters), _ptr(rv)), "scopa_cfr_exact_iterate")
         return rv
+
+    def cfr_exact_mode(self, sequential):
+        """False (default): whole-tree traversals as a parallel schedule; True: the one-lane sequential walk.  Same tables bit for bit."""
+        self._ck(self._L.scopa_cfr_exact_mode(self._h, 1 if sequential else 0), "scopa_cfr_exact_mode")
 
     def cfr_exact_traverse(self, traverser):
         v = C.c_double()

@@ -8,6 +8,19 @@
 // the node->infoset map, the payoffs and the first-visit flags in LDS (~80 KB for 738 infosets), so a visit costs a
 // few LDS latencies rather than HBM round trips; the other lanes of the workgroup stage tables in and out.  float64 arithmetic follows numpy operation by operation (no FMA
 // contraction: built with -ffp-contract=off), which is what makes the result bit-identical to the reference.
+//
+// k_cfr_exact_sched (round 2) runs the SAME sequential semantics in ~75 parallel steps instead of 1653 visits.  What the reference's
+// order actually constrains is the order of the visits of ONE infoset (each visit reads the local_strategy the previous visit of
+// that infoset left, :97); visits of different infosets commute.  A visit of node Y is an interval [enter, exit]: children read
+// Y's local_strategy row while Y is open, and the row is rewritten at Y's exit -- so Y may open only after the previous node of its
+// infoset (in DFS order) has exited, and exits only after its children have.  Nodes of one infoset are never nested (a player's hand
+// shrinks along a path), so those are all the constraints.  The schedule is computed once per deal on the host: an as-soon-as-
+// possible levelling of the EXIT events under exactly those constraints (enter costs no step: a node's reach probabilities are the
+// product, root first, of its ancestors' local_strategy entries, and every ancestor is still open -- its row unchanged -- when the
+// node exits).  Per step, one lane per event; a workgroup barrier between steps.  Every infoset sees the same sequence of float64
+// operations as in the reference, so the tables stay bit-identical (tests: vanilla_cfr.npz, 5 checkpoints to 200 iterations).
+#include <vector>
+
 #include "scopa_ctx.h"
 
 using namespace scopa;
@@ -139,10 +152,216 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
         for (int i = tid; i < cells; i += blockDim.x) { g_regret[i] = R[i]; g_strat[i] = S[i]; g_local[i] = L[i]; }
 }
 
+// ---- the scheduled form: whole-tree traversals of one deal -------------------------------------------------------------------
+namespace {
+constexpr int kSchedThreads = 256;
+
+// one visit's arithmetic (vanilla_cfr.py:87-97) for n legal actions as ONE branch-free instruction stream (the lanes of a wavefront
+// handle nodes of different plies; with a branch per slot every LDS read waited for the one before it: 20 round trips per step).
+// All four slots are loaded and computed, slots >= n are SELECTED away (never added as zeros: x + 0.0 would turn -0.0 into +0.0);
+// table rows are zero-padded beyond n and stay so.  Operation for operation what exact_rec<D> does for the slots < n.
+__device__ __forceinline__ double sched_exit(double *__restrict__ R, double *__restrict__ S, double *__restrict__ L, int I, int n, const double (&au)[4],
+                                             bool is_trav, double reach, double opp) {
+    double2 *Lr = reinterpret_cast<double2 *>(L + I * 4), *Rr = reinterpret_cast<double2 *>(R + I * 4), *Sr = reinterpret_cast<double2 *>(S + I * 4);
+    const double2 l01 = Lr[0], l23 = Lr[1], q01 = Rr[0], q23 = Rr[1], s01 = Sr[0], s23 = Sr[1];
+    const double ls[4] = {l01.x, l01.y, l23.x, l23.y};
+    double Rn[4] = {q01.x, q01.y, q23.x, q23.y}, Sn[4] = {s01.x, s01.y, s23.x, s23.y}, pos[4], out[4];
+    double v = ls[0] * au[0];  // np.sum(local_strategy * action_utils) (:87)
+#pragma unroll
+    for (int i = 1; i < 4; i++) { const double t = v + ls[i] * au[i]; v = i < n ? t : v; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {  // (:89-95)
+        const double rn = Rn[i] + opp * (au[i] - v), sn = Sn[i] + reach * ls[i];
+        const bool upd = is_trav && i < n;
+        Rn[i] = upd ? rn : Rn[i];
+        Sn[i] = upd ? sn : Sn[i];
+    }
+    // local_strategy refresh on EVERY visit (:97) = InfoNode.get_strategy (:23-30)
+#pragma unroll
+    for (int i = 0; i < 4; i++) pos[i] = (i < n && Rn[i] > 0.0) ? Rn[i] : 0.0;
+    double sum = pos[0];
+#pragma unroll
+    for (int i = 1; i < 4; i++) { const double t = sum + pos[i]; sum = i < n ? t : sum; }
+    const double uni = n == 4 ? 0.25 : n == 3 ? 1.0 / 3.0 : n == 2 ? 0.5 : 1.0;   // 1.0 / n, correctly rounded either way
+#pragma unroll
+    for (int i = 0; i < 4; i++) { const double q = pos[i] / sum; out[i] = i < n ? (sum > 0.0 ? q : uni) : 0.0; }
+    Lr[0] = make_double2(out[0], out[1]); Lr[1] = make_double2(out[2], out[3]);
+    if (is_trav) {
+        Rr[0] = make_double2(Rn[0], Rn[1]); Rr[1] = make_double2(Rn[2], Rn[3]);
+        Sr[0] = make_double2(Sn[0], Sn[1]); Sr[1] = make_double2(Sn[2], Sn[3]);
+    }
+    return v;
+}
+}  // namespace
+
+// events[e] = node (BFS index, 11 bits) | ply << 11 | (BFS index of its first child, or its first terminal's index at ply 7) << 16, grouped by
+// step: events of step s are [steps[s], steps[s + 1]);
+// paths[node][k], k < ply: the local_strategy cell (infoset * 4 + action) of the node's ancestor at ply k on the way to the node
+__global__ void __launch_bounds__(kSchedThreads)
+k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, double *__restrict__ g_regret,
+                  double *__restrict__ g_strat, double *__restrict__ g_local, int n_infosets, int n_traversals, int first_traverser,
+                  double *__restrict__ root_values, unsigned long long *__restrict__ g_counters, uint32_t *__restrict__ g_visit,
+                  int32_t *__restrict__ g_meta, const uint32_t *__restrict__ g_events, const uint16_t *__restrict__ g_steps, int n_steps,
+                  const uint16_t *__restrict__ g_paths) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    const int tid = threadIdx.x, cells = n_infosets * 4;
+    double *R = reinterpret_cast<double *>(smem), *S = R + cells, *L = S + cells;
+    double *val = L + cells;                                                    // [kDecision] node values of the traversal under way
+    uint32_t *s_ev = reinterpret_cast<uint32_t *>(val + kDecision);             // [kDecision + 1]
+    uint16_t *s_inf = reinterpret_cast<uint16_t *>(s_ev + kDecision + 1);       // [1656]
+    uint16_t *s_st = s_inf + 1656;                                              // [n_steps + 1]
+    uint16_t *s_path = s_st + ((n_steps + 2 + 7) & ~7);                         // [kDecision][8]
+    int8_t *s_pay = reinterpret_cast<int8_t *>(s_path + kDecision * 8);         // [kTerminal]
+    for (int i = tid; i < cells; i += kSchedThreads) { R[i] = g_regret[i]; S[i] = g_strat[i]; L[i] = g_local[i]; }
+    for (int i = tid; i < kDecision; i += kSchedThreads) { s_inf[i] = g_infoset[i]; s_ev[i] = g_events[i]; }
+    for (int i = tid; i <= n_steps; i += kSchedThreads) s_st[i] = g_steps[i];
+    for (int i = tid; i < kDecision * 4; i += kSchedThreads) reinterpret_cast<uint32_t *>(s_path)[i] = reinterpret_cast<const uint32_t *>(g_paths)[i];
+    for (int i = tid; i < kTerminal; i += kSchedThreads) s_pay[i] = g_payoff[i];
+    // dict insertion on first visit (:51-54): a whole-tree traversal meets the infosets in id order (ids ARE the DFS first-visit order)
+    if (tid == 0 && n_traversals > 0) {
+        uint32_t seq = (uint32_t)g_meta[1];
+        for (int I = 0; I < n_infosets; I++)
+            if (g_visit[I] == 0u) g_visit[I] = ++seq;
+        g_meta[1] = (int32_t)seq;
+        g_counters[0] += (unsigned long long)n_traversals * kDecision;
+        g_counters[1] += (unsigned long long)n_traversals * kTerminal;
+    }
+    __syncthreads();
+    for (int t = 0; t < n_traversals; t++) {
+        const int trav = (first_traverser + t) & 1;   // train(): for i in range(num_players) (:108-110)
+        for (int s = 0; s < n_steps; s++) {
+            for (int e = s_st[s] + tid; e < s_st[s + 1]; e += kSchedThreads) {
+                const uint32_t ev = s_ev[e];
+                const int node = (int)(ev & 2047u), d = (int)((ev >> 11) & 7u), n = 4 - (d >> 1), cbase = (int)(ev >> 16);
+                // reach probabilities: the product, root first, of the ancestors' local_strategy entries along the path (:79-85)
+                const uint4 pw = *reinterpret_cast<const uint4 *>(s_path + node * 8);   // the 7 path cells in one 16-byte read
+                const uint32_t pcw[4] = {pw.x, pw.y, pw.z, pw.w};
+                double pl[kPlies - 1], r0 = 1.0, r1 = 1.0;
+#pragma unroll
+                for (int k = 0; k < kPlies - 1; k++) pl[k] = L[(pcw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];   // all seven reads in flight (cells beyond the ply are 0: a valid address)
+#pragma unroll
+                for (int k = 0; k < kPlies - 1; k++) {   // x * 1.0 is x: plies beyond the node's leave the product untouched
+                    const double f = k < d ? pl[k] : 1.0;
+                    if ((k & 1) == 0) r0 = r0 * f; else r1 = r1 * f;
+                }
+                const bool leafp = d == kPlies - 1;
+                double au[4];
+#pragma unroll
+                for (int i = 0; i < 4; i++) {
+                    const int off = i < n ? i : 0;
+                    const int p0 = s_pay[leafp ? cbase + off : 0];
+                    const double child = val[leafp ? 0 : cbase + off];
+                    au[i] = leafp ? 0.5 * (double)(trav == 0 ? p0 : -p0) : child;   // terminal (:58-59) or the child's value
+                }
+                const int I = s_inf[node];
+                const bool is_trav = (d & 1) == trav;
+                const double reach = trav == 0 ? r0 : r1, opp = trav == 0 ? r1 : r0;
+                const double v = sched_exit(R, S, L, I, n, au, is_trav, reach, opp);
+                val[node] = v;
+            }
+            __syncthreads();
+        }
+        if (tid == 0 && root_values) root_values[t] = val[0];
+    }
+    __syncthreads();
+    for (int i = tid; i < cells; i += kSchedThreads) { g_regret[i] = R[i]; g_strat[i] = S[i]; g_local[i] = L[i]; }
+}
+
+// as-soon-as-possible levelling of the EXIT events of one deal's tree under the per-infoset order (see the head of this file)
+constexpr int kSchedSteps = 2 * kDecision, kSchedPaths = (3 * kDecision + 2 + 7) & ~7;   // offsets into d_sched, in uint16 units
+
+static int32_t build_exact_schedule(scopa_ctx *ctx) {
+    if (ctx->sched_valid) return SCOPA_OK;
+    std::vector<uint16_t> inf(kDecision);
+    SC_HIP(ctx, hipMemcpyAsync(inf.data(), ctx->d_infoset, kDecision * sizeof(uint16_t), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::vector<int> last_exit(kDecision, 0), exit_t(kDecision, 0);
+    // iterative DFS in the reference's order (children in legal-action order); a node's "open" time = max(parent's, previous node of its infoset's exit)
+    struct Frame { int d, idx, open, child, mx; };
+    std::vector<Frame> st;
+    st.push_back({0, 0, 0, 0, 0});
+    st.back().open = last_exit[inf[0]]; st.back().mx = st.back().open;
+    int T = 0;
+    while (!st.empty()) {
+        Frame &f = st.back();
+        const int n = nlegal_at(f.d);
+        if (f.d == kPlies - 1 || f.child == n) {   // children done (ply 7's children are terminals): this node exits
+            const int node = level_offset(f.d) + f.idx, tx = f.mx + 1;
+            exit_t[node] = tx; last_exit[inf[node]] = tx;
+            if (tx > T) T = tx;
+            st.pop_back();
+            if (!st.empty() && tx > st.back().mx) st.back().mx = tx;
+            continue;
+        }
+        const int cd = f.d + 1, cidx = f.idx * n + f.child;
+        f.child++;
+        const int popen = f.open;
+        Frame c{cd, cidx, 0, 0, 0};
+        const int cI = inf[level_offset(cd) + cidx];
+        c.open = popen > last_exit[cI] ? popen : last_exit[cI];
+        c.mx = c.open;
+        st.push_back(c);
+    }
+    std::vector<uint16_t> steps(T + 1, 0);
+    std::vector<uint32_t> events(kDecision);
+    std::vector<int> fill(T + 1, 0);
+    for (int node = 0; node < kDecision; node++) fill[exit_t[node]]++;          // exit times are 1..T
+    int off = 0;
+    for (int s = 1; s <= T; s++) { steps[s - 1] = (uint16_t)off; off += fill[s]; fill[s] = steps[s - 1]; }
+    steps[T] = (uint16_t)off;
+    for (int d = 0; d < kPlies; d++)
+        for (int node = level_offset(d); node < level_offset(d + 1); node++) {
+            const int idx = node - level_offset(d), first_child = (d == kPlies - 1 ? 0 : level_offset(d + 1)) + idx * nlegal_at(d);
+            events[fill[exit_t[node]]++] = (uint32_t)node | ((uint32_t)d << 11) | ((uint32_t)first_child << 16);
+        }
+    // the local_strategy cells along every node's path (static per deal)
+    std::vector<uint16_t> paths((size_t)kDecision * 8, 0);
+    for (int d = 1; d < kPlies; d++)
+        for (int idx = 0; idx < level_offset(d + 1) - level_offset(d); idx++) {
+            int x = idx;
+            for (int k = d; k > 0; k--) {
+                const int pn = nlegal_at(k - 1), act = x % pn;
+                x /= pn;
+                paths[(size_t)(level_offset(d) + idx) * 8 + (k - 1)] = (uint16_t)(inf[level_offset(k - 1) + x] * 4 + act);
+            }
+        }
+    // one buffer (uint16 units): [2 * kDecision] events as uint32 | [kDecision + 2] step offsets | [kDecision][8] path cells (16-byte aligned)
+    if (!ctx->d_sched) SC_HIP(ctx, hipMalloc(&ctx->d_sched, (size_t)(kSchedPaths + kDecision * 8) * sizeof(uint16_t)));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched + kSchedPaths, paths.data(), paths.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched, events.data(), kDecision * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched + kSchedSteps, steps.data(), (size_t)(T + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->sched_steps = T;
+    ctx->sched_valid = true;
+    return SCOPA_OK;
+}
+
+static size_t sched_lds_bytes(int n_infosets, int n_steps) {
+    return (size_t)n_infosets * 4 * 8 * 3 + (size_t)kDecision * 8 + (size_t)(kDecision + 1) * 4 + (1656 + ((n_steps + 2 + 7) & ~7) + kDecision * 8) * sizeof(uint16_t) + kTerminal + 32;
+}
+
 static int32_t run_exact(scopa_ctx *ctx, int n_traversals, int first_traverser, double *h_values, int start_depth = 0,
                          int start_idx = 0, double r0 = 1.0, double r1 = 1.0) {
     SC_HIP(ctx, hipSetDevice(ctx->device));
     { const int32_t rc = ensure_scratch(ctx, (size_t)(n_traversals > 0 ? n_traversals : 1) * sizeof(double)); if (rc != SCOPA_OK) return rc; }
+    if (start_depth == 0 && r0 == 1.0 && r1 == 1.0 && !ctx->exact_sequential) {   // whole-tree traversals: the scheduled form, if the deal's tables fit beside it
+        const int32_t rc = build_exact_schedule(ctx);
+        if (rc != SCOPA_OK) return rc;
+        const size_t need = sched_lds_bytes(ctx->n_infosets, ctx->sched_steps);
+        if (need <= (size_t)ctx->lds_limit) {
+            SC_LDS_ATTR(ctx, scopa::kLdsCfrSched, k_cfr_exact_sched, ctx->lds_limit);
+            hipLaunchKernelGGL(k_cfr_exact_sched, dim3(1), dim3(kSchedThreads), need, ctx->stream, ctx->d_infoset, ctx->d_payoff, ctx->d_regret,
+                               ctx->d_strat, ctx->d_local, ctx->n_infosets, n_traversals, first_traverser, ctx->d_scratch, ctx->d_counters,
+                               ctx->d_visit, ctx->d_meta, reinterpret_cast<const uint32_t *>(ctx->d_sched), ctx->d_sched + kSchedSteps, ctx->sched_steps,
+                               ctx->d_sched + kSchedPaths);
+            SC_HIP(ctx, hipGetLastError());
+            if (h_values && n_traversals > 0)
+                SC_HIP(ctx, hipMemcpyAsync(h_values, ctx->d_scratch, (size_t)n_traversals * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+            SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            ctx->sigcdf_valid = false;
+            return SCOPA_OK;
+        }
+    }
     const size_t lds = (size_t)ctx->n_infosets * 4 * 8 * 3;
     const size_t static_lds = 1656 * 2 + kTerminal + sizeof(uint32_t) * kDecision + 256;
     const int use_lds = lds + static_lds <= (size_t)ctx->lds_limit ? 1 : 0;
@@ -165,6 +384,12 @@ int32_t scopa_cfr_exact_iterate(scopa_ctx *ctx, int32_t n_iters, double *h_root_
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_cfr_exact_iterate: no deal set");
     if (n_iters == 0) return SCOPA_OK;
     return run_exact(ctx, n_iters * 2, 0, h_root_values);
+}
+
+int32_t scopa_cfr_exact_mode(scopa_ctx *ctx, int32_t sequential) {
+    if (!ctx || (sequential != 0 && sequential != 1)) return SCOPA_EINVAL;
+    ctx->exact_sequential = sequential != 0;
+    return SCOPA_OK;
 }
 
 int32_t scopa_cfr_exact_traverse(scopa_ctx *ctx, int32_t traverser, double *h_value) {

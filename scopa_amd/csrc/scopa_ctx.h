@@ -68,6 +68,12 @@ struct scopa_ctx {
     int64_t prof_launches = 0;
     double prof_ms = 0.0;
 
+    // exact vanilla CFR, scheduled form (scopa_cfr.hip): EXIT events of the deal's tree levelled under the per-infoset visit order
+    uint16_t *d_sched = nullptr;   // events (uint32 each) | step offsets | [kDecision][8] path cells (layout: scopa_cfr.hip)
+    int sched_steps = 0;
+    bool sched_valid = false;      // false after scopa_set_deal
+    bool exact_sequential = false; // scopa_cfr_exact_mode(ctx, 1): force the one-lane walk (the form the schedule is checked against)
+
     scopa_p2p *p2p = nullptr;  // peer-memory exchange of the N > 1 path
 
     int lds_limit = 160 * 1024;
@@ -105,7 +111,7 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, so the "already raised" flag lives in the
 // context (one context = one device), not in a process-wide static: a second context on another device raises it again.
-enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u };
+enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsCfrSched = 512u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u };
 inline int32_t ensure_lds_attr(scopa_ctx *ctx, uint32_t kernel_bit, const void *fn, int bytes) {
     if (ctx->lds_attr_done & kernel_bit) return SCOPA_OK;
     SC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

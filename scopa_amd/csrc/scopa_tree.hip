@@ -224,6 +224,7 @@ int32_t scopa_set_deal(scopa_ctx *ctx, const uint8_t perm16[16]) {
     ctx->n_infosets = n_inf;
     ctx->has_deal = true;
     ctx->d_delta = ctx->d_delta_own;  // a new deal drops any caller-bound delta buffer
+    ctx->sched_valid = false;         // ... and the exact-CFR schedule of the previous deal
     return scopa_tables_reset(ctx);
 }
 

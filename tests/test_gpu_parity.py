@@ -112,6 +112,29 @@ def test_vanilla_cfr_single_traversals(ctx, sl, golden):
     assert np.array_equal(R, g["it1_regret"])
 
 
+@pytest.mark.parametrize("seed", [42, 0, 123, 282, 129])
+def test_cfr_exact_schedule_is_bit_identical_to_the_sequential_walk(ctx, sl, seed):
+    """Whole-tree vanilla-CFR traversals run as a schedule of parallel steps (31 .. 194 steps for these deals instead of 1653 visits)
+    that keeps the reference's visit order per infoset; the one-lane sequential walk (itself bit-exact vs vanilla_cfr.npz) is the check:
+    tables, root values, first-visit order and counters must be IDENTICAL, on deals with few / many infosets and from non-zero tables."""
+    ctx.set_deal(sl.deal_py_seed(seed))
+    out = []
+    for sequential in (True, False):
+        ctx.tables_reset()
+        ctx.cfr_exact_mode(sequential)
+        c0 = ctx.counters()
+        rv = [ctx.cfr_exact_iterate(1), ctx.cfr_exact_iterate(6)]
+        v1 = ctx.cfr_exact_traverse(1)                      # a single traversal of one player on top
+        R, S, L = ctx.tables_get()
+        c1 = ctx.counters()
+        out.append((np.concatenate(rv), v1, R, S, L, ctx.visited_get(), (c1[0] - c0[0], c1[1] - c0[1])))
+    ctx.cfr_exact_mode(False)
+    a, b = out
+    assert np.array_equal(a[0], b[0]) and a[1] == b[1]
+    assert np.array_equal(a[2], b[2]) and np.array_equal(a[3], b[3]) and np.array_equal(a[4], b[4])
+    assert np.array_equal(a[5], b[5]) and a[6] == b[6] == (1653 * 15, 576 * 15)
+
+
 @pytest.mark.parametrize("seed,iters", [(0, 1), (0, 10), (1, 200), (2, 200)])
 def test_mccfr_replay_bit_exact_vs_reference(ctx, sl, golden, seed, iters):
     m = golden.npz("mccfr.npz")
