@@ -1,0 +1,54 @@
+"""bench.py's contract, run for real on the GPU box (small step counts): the one JSON line, its required keys, a roofline fraction
+that is a fraction, the CPU baseline leg, and `--gpus 2` started PLAINLY -- the script must spawn its ranks itself (here both on the
+one GPU of the test box, --share-gpu) and come back with bit-identical replicas."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*args, timeout=300):
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=timeout, env=env)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines                       # ONE JSON line on stdout, nothing else
+    return json.loads(lines[0])
+
+
+def test_bench_line_contract_n1(ctx):
+    d = _bench("--gpus", "1", "--steps", "10", "--warmup", "2", "--regions", "5", "--pre-phase-s", "0.05", "--no-cpu-baseline")
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 10 and d["warmup"] == 2 and d["scaling"] == "weak" and d["vs_baseline"] is None
+    assert d["dtype"] == "f64" and d["higher_is_better"] is True and "workload" in d["config"]
+    assert d["decision_visits"] == 463 * 4096 * 10 * d["timing"]["regions"]          # exact kernel counters over the timed regions
+    assert abs(d["value"] - 463 * 4096 * 10 / (d["timing"]["region_ms_median"] * 1e-3)) < 1e-3 * d["value"]
+    r = d["roofline"]
+    assert r["kernel"] == "k_mccfr_traverse" and r["launches_timed"] >= 16 and r["bound"] in r["bounds"]
+    assert 0.0 < r["frac"] <= 1.0 and all(b["frac"] is None or 0.0 < b["frac"] <= 1.0 for b in r["bounds"].values())
+    assert r["frac"] == max(b["frac"] for b in r["bounds"].values() if b["frac"] is not None)
+    assert r["traffic"] is None or r["traffic"] > 0
+    assert d["exploitability"]["value"] >= 0.0
+
+
+def test_bench_spawns_its_own_ranks(ctx):
+    d = _bench("--gpus", "2", "--share-gpu", "--steps", "5", "--warmup", "2", "--regions", "3", "--pre-phase-s", "0.05", "--batch", "512", "--no-cpu-baseline")
+    c = d["config"]
+    assert d["n_gpus"] == 2 and c["global_batch"] == 1024 and c["batch_per_gpu"] == 512
+    assert c["exchange"] in ("p2p", "rccl") and c["replicas_bit_identical"] is True and c["sharded_10_iterations_match_one_gpu"] is True
+    assert d["decision_visits"] == 463 * 1024 * 5 * d["timing"]["regions"]
+
+
+def test_bench_sdcfr_workload(ctx):
+    d = _bench("--workload", "sdcfr", "--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline")
+    assert d["dtype"] == "f32" and d["decision_visits"] == (105 + 82) * 256 * 3
+    assert d["roofline"]["kernel"] == "k_sdcfr_traverse" and 0.0 < d["roofline"]["frac"] <= 1.0
