@@ -502,7 +502,7 @@ def main():
                                "note": "exact best-response exploitability of the average strategy on the full tree (k_exploitability); "
                                        "uniform play = 2.2604; the reference's MCCFR update rule (mc_cfr.py:79-84) plateaus -- 0.487 after 5000 of its own "
                                        "sequential iterations, reproduced bit for bit -- while its vanilla CFR reaches 0.0031 after 1000 "
-                                       "(profiles/r01_exploitability_curve.json)"},
+                                       "(profiles/r02_exploitability_curve.json)"},
         }
         if world == 1 and not use_dist and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.batch)
