@@ -218,7 +218,7 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
                 else        { reach = p_reach * sg; samp = p_samp; }
             }
             const int In = s_inf[level_offset(D) + idx];
-            s_seen[In] = 1;  // benign race: every writer stores 1
+            if (!is_trav) s_seen[In] = 1;  // benign race: every writer stores 1.  Traverser nodes are counted in s_cnt, which marks them seen
             // this node's draw: block (ntl, j) of its traverser, prepared by draw_pair()
             const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
             const uint32_t k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
@@ -276,8 +276,7 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         const int act = (trav == 1 && k > 0) ? k - 1 : (int)(ppk >> 21);
         const int idx6 = (int)(ppk & 1023u) * 2 + act;     // = index of the ply-7 node and of the leaf as well
         const int I6 = s_inf[level_offset(6) + idx6], I7 = s_inf[level_offset(7) + idx6];
-        s_seen[I6] = 1;
-        s_seen[I7] = 1;
+        s_seen[trav == 0 ? I7 : I6] = 1;                  // the opponent's node of the two (the traverser's is marked by its count)
         atomicAdd(&s_cnt[trav == 0 ? I6 : I7], 1u);       // the traverser's single-action node: strategy_sum += [1.0]
         const int p0 = s_pay[idx6];
         ws.p6[t] = (int8_t)(trav == 0 ? p0 : -p0);
@@ -390,8 +389,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const unsigned long long t_walk = wall_clock64();
     {
         // infosets first seen by this launch: the loads go out first, their answers are used after the atomics have been issued
-        const bool first0 = tid < I && s_seen[tid] && g_visit[tid] == 0u;
-        const bool first1 = tid + nthr < I && s_seen[tid + nthr] && g_visit[tid + nthr] == 0u;
+        const bool first0 = tid < I && (s_seen[tid] || s_cnt[tid]) && g_visit[tid] == 0u;
+        const bool first1 = tid + nthr < I && (s_seen[tid + nthr] || s_cnt[tid + nthr]) && g_visit[tid + nthr] == 0u;
         double *tab = g_groups + (size_t)(blockIdx.x % kDeltaGroups) * kDeltaTable;
         for (int k = 0; k < 5; k++)
             for (int r = tid; r < I; r += nthr) {
@@ -401,7 +400,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         if (first0) g_visit[tid] = 0x40000000u + (uint32_t)tid;              // racing writers store the same value
         if (first1) g_visit[tid + nthr] = 0x40000000u + (uint32_t)(tid + nthr);
         for (int r = tid + 2 * nthr; r < I; r += nthr)                       // narrow workgroups (many infosets): the rest, plainly
-            if (s_seen[r] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
+            if ((s_seen[r] || s_cnt[r]) && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
     }
     // exact visit counters: wave reduce -> LDS -> this workgroup's own slot (a no-return atomic on a word nobody else adds to;
     // scopa_counters() adds the slots up
@@ -467,6 +466,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
             if (c) {
+                s_seen[r] = 1;   // the walks mark opponent nodes only: a counted traverser visit marks the row here
                 const int n = (int)((g_key[r] >> 1) & 7);
                 for (int k = 0; k < n; k++) g_strat[r * 4 + k] += (double)c * s_sigcdf[r * kRow + k];
                 s_cnt[r] = 0u;
