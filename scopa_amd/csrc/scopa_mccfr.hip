@@ -265,26 +265,47 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
     my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
     my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
     my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
-    // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts
-    for (int t = lane; t < 2 * 60; t += 64) {
-        const int trav = t < 60 ? 0 : 1;
-        const int j = trav ? t - 60 : t;
-        // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
-        int pj = j, k = 0;
-        if (trav == 1) { pj = j / 3; k = j - pj * 3; }
-        const uint32_t ppk = ws.pk5[(trav ? 60 : 0) + pj];
-        const int act = (trav == 1 && k > 0) ? k - 1 : (int)(ppk >> 21);
-        const int idx6 = (int)(ppk & 1023u) * 2 + act;     // = index of the ply-7 node and of the leaf as well
-        const int I6 = s_inf[level_offset(6) + idx6], I7 = s_inf[level_offset(7) + idx6];
-        s_seen[trav == 0 ? I7 : I6] = 1;                  // the opponent's node of the two (the traverser's is marked by its count)
-        atomicAdd(&s_cnt[trav == 0 ? I6 : I7], 1u);       // the traverser's single-action node: strategy_sum += [1.0]
-        const int p0 = s_pay[idx6];
-        ws.p6[t] = (int8_t)(trav == 0 ? p0 : -p0);
-        my_dvis += trav == 0 ? 3 : 2;                       // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
-        my_tvis += 2;
+    // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts.  120 leaves on 64 lanes: both of a lane's items are
+    // loaded before either is used (two dependent LDS round trips for the stage instead of four)
+    {
+        uint32_t ppk[2];
+        int tt[2], trv[2], kk[2];
+        bool on[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int t = lane + 64 * q;
+            on[q] = t < 2 * 60;
+            tt[q] = on[q] ? t : 0;
+            trv[q] = tt[q] < 60 ? 0 : 1;
+            const int j = trv[q] ? tt[q] - 60 : tt[q];
+            // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
+            int pj = j;
+            kk[q] = 0;
+            if (trv[q] == 1) { pj = j / 3; kk[q] = j - pj * 3; }
+            ppk[q] = ws.pk5[(trv[q] ? 60 : 0) + pj];
+        }
+        int idx6[2], I6[2], I7[2], pay[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) {
+            const int act = (trv[q] == 1 && kk[q] > 0) ? kk[q] - 1 : (int)(ppk[q] >> 21);
+            idx6[q] = (int)(ppk[q] & 1023u) * 2 + act;     // = index of the ply-7 node and of the leaf as well
+            I6[q] = s_inf[level_offset(6) + idx6[q]];
+            I7[q] = s_inf[level_offset(7) + idx6[q]];
+            pay[q] = s_pay[idx6[q]];
+        }
+#pragma unroll
+        for (int q = 0; q < 2; q++)
+            if (on[q]) {
+                s_seen[trv[q] == 0 ? I7[q] : I6[q]] = 1;            // the opponent's node of the two (the traverser's is marked by its count)
+                atomicAdd(&s_cnt[trv[q] == 0 ? I6[q] : I7[q]], 1u); // the traverser's single-action node: strategy_sum += [1.0]
+                ws.p6[tt[q]] = (int8_t)(trv[q] == 0 ? pay[q] : -pay[q]);
+                my_dvis += trv[q] == 0 ? 3 : 2;                     // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
+                my_tvis += 2;
+            }
     }
     wave_lds_sync();
-    // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84)
+    // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84); everything is loaded before anything is used, the
+    // slots beyond the node's action count are selected away
     if (lane < 2 * kUpd) {
         const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
         const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
@@ -294,16 +315,24 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
         const int IX = ws.updI[lane];
         const double rX = ws.updr[lane], sX = ws.upds[lane];
-        const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
         const int8_t *p6 = ws.p6 + trav * 60;
+        int pv[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) pv[i] = p6[base + ((i < nX ? i : nX - 1) + 1) * stride];
+        const double2 s01 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow), s23 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow + 2);
+        const double sg[4] = {s01.x, s01.y, s23.x, s23.y};
+        const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
         double cfv[4], v = 0.0;
-        for (int i = 0; i < nX; i++) {
-            cfv[i] = 0.5 * (double)p6[base + (i + 1) * stride];
-            v = fma(s_sigcdf[IX * kRow + i], cfv[i], v);      // np.dot on this numpy build: an fma chain (see oracle)
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            cfv[i] = 0.5 * (double)pv[i];
+            const double t = fma(sg[i], cfv[i], v);          // np.dot on this numpy build: an fma chain (see oracle)
+            v = i < nX ? t : v;
         }
-        for (int i = 0; i < nX; i++) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
             const double delta = w * (cfv[i] - v);
-            if (delta != 0.0) atomicAdd(&s_dR[IX * 4 + i], delta);
+            if (i < nX && delta != 0.0) atomicAdd(&s_dR[IX * 4 + i], delta);
         }
     }
     wave_lds_sync();  // the next pair overwrites this wave's scratch
