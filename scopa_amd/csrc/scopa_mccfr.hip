@@ -183,66 +183,80 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
                                                  unsigned int *__restrict__ s_cnt, NodeRegs &st) {
     constexpr int n = 4 - (D >> 1);
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
-    unsigned int visited = 0;
-    NodeRegs mine = st;
-#pragma unroll
-    for (int t0 = 0; t0 < c0 + c1; t0 += 64) {
-        const int t = t0 + lane;
-        const bool valid = t < c0 + c1;
-        const int trav = t < c0 ? 0 : 1;
-        const int j = trav ? t - c0 : t;
-        const bool is_trav = (D & 1) == trav;
-        const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
-        int idx = 0, p_inf = 0, act = 0;
-        double p_reach = 1.0, p_samp = 1.0;
-        bool p_trav = false;
+    // what a lane gathers for its node before anything is stored: every LDS READ of the ply (both rounds of ply 5) is issued before
+    // the first LDS write or atomic, and none sits under a branch -- lanes without a node read slot 0 and are ignored afterwards
+    struct Pre {
+        bool valid, is_trav;
+        int t, trav, j, idx, In;
+        double reach, samp;
+        uint32_t k, thr0, thr1, thr2;
+    };
+    auto gather = [&](int t0) -> Pre {
+        Pre g;
+        g.t = t0 + lane;
+        g.valid = g.t < c0 + c1;
+        g.trav = g.t < c0 ? 0 : 1;
+        g.j = g.valid ? (g.trav ? g.t - c0 : g.t) : 0;
+        g.is_trav = (D & 1) == g.trav;
+        const int ntl = g.trav == 0 ? (D + 1) >> 1 : D >> 1;
+        g.idx = 0; g.reach = 1.0; g.samp = 1.0;
         if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
             constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
-            p_trav = (pd & 1) == trav;
-            int pj = j, br = 0;
-            if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
-            int plane = (trav ? task_nodes(0, pd) : 0) + pj;
-            plane = valid ? plane : 0;
-            p_reach = __shfl(st.reach, plane);
-            p_samp = __shfl(st.samp, plane);
+            const bool p_trav = (pd & 1) == g.trav;
+            int pj = g.j, br = 0;
+            if (p_trav) { pj = g.j / (pn + 1); br = g.j - pj * (pn + 1); }
+            int plane = (g.trav ? task_nodes(0, pd) : 0) + pj;
+            plane = g.valid ? plane : 0;
+            const double p_reach = __shfl(st.reach, plane), p_samp = __shfl(st.samp, plane);
             const uint32_t ppk = (uint32_t)__shfl((int)st.pk, plane);
-            p_inf = (int)((ppk >> 10) & 2047u);
-            act = (p_trav && br > 0) ? br - 1 : (int)(ppk >> 21);
-            idx = (int)(ppk & 1023u) * pn + act;
+            const int p_inf = (int)((ppk >> 10) & 2047u);
+            const int act = (p_trav && br > 0) ? br - 1 : (int)(ppk >> 21);
+            g.idx = (int)(ppk & 1023u) * pn + act;
+            const double sg = s_sigcdf[p_inf * kRow + act];
+            g.samp = p_trav ? p_samp * sg : p_samp;
+            g.reach = p_trav ? p_reach : p_reach * sg;
         }
-        if (valid) {
-            double reach = 1.0, samp = 1.0;
-            if constexpr (D > 0) {
-                const double sg = s_sigcdf[p_inf * kRow + act];
-                if (p_trav) { samp = p_samp * sg; reach = p_reach; }
-                else        { reach = p_reach * sg; samp = p_samp; }
-            }
-            const int In = s_inf[level_offset(D) + idx];
-            if (!is_trav) s_seen[In] = 1;  // benign race: every writer stores 1.  Traverser nodes are counted in s_cnt, which marks them seen
-            // this node's draw: block (ntl, j) of its traverser, prepared by draw_pair()
-            const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
-            const uint32_t k = trav == 0 ? (is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (is_trav ? ws.ky1[blk] : ws.kx1[blk]);
-            const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + In * kRow + 4);
-            // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
-            // most nodes are, instead of three
-            int a = (thr[0] <= k);
-            if constexpr (n > 2) a += (thr[1] <= k);
-            if constexpr (n > 3) a += (thr[2] <= k);
-            if (is_trav) {  // what the update step needs (mc_cfr.py:81-82)
-                const int x = trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + j;
-                ws.updI[x] = (uint16_t)In;
-                ws.updr[x] = reach;
-                ws.upds[x] = samp;
-                atomicAdd(&s_cnt[In], 1u);
-            }
-            if constexpr (D == 5) {  // 80 nodes in two rounds: the leaf stage reads (idx, sampled action) from LDS
-                ws.pk5[t] = (uint32_t)idx | ((uint32_t)a << 21);
-            } else {
-                mine.reach = reach; mine.samp = samp;
-                mine.pk = (uint32_t)idx | ((uint32_t)In << 10) | ((uint32_t)a << 21);
-            }
-            visited += 1;
+        g.In = s_inf[level_offset(D) + g.idx];
+        // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pair()
+        const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + g.j;
+        g.k = g.trav == 0 ? (g.is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (g.is_trav ? ws.ky1[blk] : ws.kx1[blk]);
+        // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
+        // most nodes are, instead of three
+        const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + g.In * kRow + 4);
+        g.thr0 = thr[0];
+        g.thr1 = n > 2 ? thr[1] : 0xFFFFFFFFu;
+        g.thr2 = n > 3 ? thr[2] : 0xFFFFFFFFu;
+        return g;
+    };
+    unsigned int visited = 0;
+    NodeRegs mine = st;
+    auto finish = [&](const Pre &g) {
+        if (!g.valid) return;
+        const int ntl = g.trav == 0 ? (D + 1) >> 1 : D >> 1;
+        if (!g.is_trav) s_seen[g.In] = 1;  // benign race: every writer stores 1.  Traverser nodes are counted in s_cnt, which marks them seen
+        const int a = (g.thr0 <= g.k) + (g.thr1 <= g.k) + (g.thr2 <= g.k);
+        if (g.is_trav) {  // what the update step needs (mc_cfr.py:81-82)
+            const int x = g.trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + g.j;
+            ws.updI[x] = (uint16_t)g.In;
+            ws.updr[x] = g.reach;
+            ws.upds[x] = g.samp;
+            atomicAdd(&s_cnt[g.In], 1u);
         }
+        if constexpr (D == 5) {  // 80 nodes in two rounds: the leaf stage reads (idx, sampled action) from LDS
+            ws.pk5[g.t] = (uint32_t)g.idx | ((uint32_t)a << 21);
+        } else {
+            mine.reach = g.reach; mine.samp = g.samp;
+            mine.pk = (uint32_t)g.idx | ((uint32_t)g.In << 10) | ((uint32_t)a << 21);
+        }
+        visited += 1;
+    };
+    if constexpr (c0 + c1 > 64) {
+        const Pre g0 = gather(0), g1 = gather(64);
+        finish(g0);
+        finish(g1);
+    } else {
+        const Pre g0 = gather(0);
+        finish(g0);
     }
     st = mine;
     if constexpr (D == 5) wave_lds_sync();
