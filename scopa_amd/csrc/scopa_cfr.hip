@@ -154,43 +154,14 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
 
 // ---- the scheduled form: whole-tree traversals of one deal -------------------------------------------------------------------
 namespace {
-constexpr int kSchedThreads = 256;
+constexpr int kSchedThreads = 512;     // 128 events per pass: a quad of lanes per event, one lane per action slot
 
-// one visit's arithmetic (vanilla_cfr.py:87-97) for n legal actions as ONE branch-free instruction stream (the lanes of a wavefront
-// handle nodes of different plies; with a branch per slot every LDS read waited for the one before it: 20 round trips per step).
-// All four slots are loaded and computed, slots >= n are SELECTED away (never added as zeros: x + 0.0 would turn -0.0 into +0.0);
-// table rows are zero-padded beyond n and stay so.  Operation for operation what exact_rec<D> does for the slots < n.
-__device__ __forceinline__ double sched_exit(double *__restrict__ R, double *__restrict__ S, double *__restrict__ L, int I, int n, const double (&au)[4],
-                                             bool is_trav, double reach, double opp) {
-    double2 *Lr = reinterpret_cast<double2 *>(L + I * 4), *Rr = reinterpret_cast<double2 *>(R + I * 4), *Sr = reinterpret_cast<double2 *>(S + I * 4);
-    const double2 l01 = Lr[0], l23 = Lr[1], q01 = Rr[0], q23 = Rr[1], s01 = Sr[0], s23 = Sr[1];
-    const double ls[4] = {l01.x, l01.y, l23.x, l23.y};
-    double Rn[4] = {q01.x, q01.y, q23.x, q23.y}, Sn[4] = {s01.x, s01.y, s23.x, s23.y}, pos[4], out[4];
-    double v = ls[0] * au[0];  // np.sum(local_strategy * action_utils) (:87)
-#pragma unroll
-    for (int i = 1; i < 4; i++) { const double t = v + ls[i] * au[i]; v = i < n ? t : v; }
-#pragma unroll
-    for (int i = 0; i < 4; i++) {  // (:89-95)
-        const double rn = Rn[i] + opp * (au[i] - v), sn = Sn[i] + reach * ls[i];
-        const bool upd = is_trav && i < n;
-        Rn[i] = upd ? rn : Rn[i];
-        Sn[i] = upd ? sn : Sn[i];
-    }
-    // local_strategy refresh on EVERY visit (:97) = InfoNode.get_strategy (:23-30)
-#pragma unroll
-    for (int i = 0; i < 4; i++) pos[i] = (i < n && Rn[i] > 0.0) ? Rn[i] : 0.0;
-    double sum = pos[0];
-#pragma unroll
-    for (int i = 1; i < 4; i++) { const double t = sum + pos[i]; sum = i < n ? t : sum; }
-    const double uni = n == 4 ? 0.25 : n == 3 ? 1.0 / 3.0 : n == 2 ? 0.5 : 1.0;   // 1.0 / n, correctly rounded either way
-#pragma unroll
-    for (int i = 0; i < 4; i++) { const double q = pos[i] / sum; out[i] = i < n ? (sum > 0.0 ? q : uni) : 0.0; }
-    Lr[0] = make_double2(out[0], out[1]); Lr[1] = make_double2(out[2], out[3]);
-    if (is_trav) {
-        Rr[0] = make_double2(Rn[0], Rn[1]); Rr[1] = make_double2(Rn[2], Rn[3]);
-        Sr[0] = make_double2(Sn[0], Sn[1]); Sr[1] = make_double2(Sn[2], Sn[3]);
-    }
-    return v;
+// value of lane K (0..3) of the caller's quad (4 consecutive lanes), for every lane of the quad: two DPP moves, no LDS
+template <int K>
+__device__ __forceinline__ double quad_bcast(double x) {
+    const int lo = __builtin_amdgcn_mov_dpp(__double2loint(x), K * 0x55, 0xF, 0xF, true);
+    const int hi = __builtin_amdgcn_mov_dpp(__double2hiint(x), K * 0x55, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
 }
 }  // namespace
 
@@ -230,34 +201,57 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
     for (int t = 0; t < n_traversals; t++) {
         const int trav = (first_traverser + t) & 1;   // train(): for i in range(num_players) (:108-110)
         for (int s = 0; s < n_steps; s++) {
-            for (int e = s_st[s] + tid; e < s_st[s + 1]; e += kSchedThreads) {
-                const uint32_t ev = s_ev[e];
+            // One visit (vanilla_cfr.py:87-97) per QUAD of lanes, lane i of the quad = action slot i: the slot's table cells, its child's
+            // value, its product, its regret update and its division are the lane's own; the two ordered sums (np.sum over <= 4 slots,
+            // left to right) are done by every lane on quad-broadcast operands.  Branch-free: slots >= n and quads without an event
+            // are SELECTED away (never added as zeros: x + 0.0 would turn -0.0 into +0.0), stores are predicated.  With one lane per
+            // node a step cost ~500 instructions on wavefronts that sit alone on their SIMD (1.2 us); a quad per node issues ~150.
+            const int e0 = s_st[s], e1 = s_st[s + 1], slot = tid & 3;
+            for (int eb = e0; eb < e1; eb += kSchedThreads / 4) {
+                const int e = eb + (tid >> 2);
+                const bool live = e < e1;
+                const uint32_t ev = s_ev[live ? e : e0];
                 const int node = (int)(ev & 2047u), d = (int)((ev >> 11) & 7u), n = 4 - (d >> 1), cbase = (int)(ev >> 16);
+                const bool on = slot < n;
                 // reach probabilities: the product, root first, of the ancestors' local_strategy entries along the path (:79-85)
                 const uint4 pw = *reinterpret_cast<const uint4 *>(s_path + node * 8);   // the 7 path cells in one 16-byte read
                 const uint32_t pcw[4] = {pw.x, pw.y, pw.z, pw.w};
                 double pl[kPlies - 1], r0 = 1.0, r1 = 1.0;
 #pragma unroll
                 for (int k = 0; k < kPlies - 1; k++) pl[k] = L[(pcw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];   // all seven reads in flight (cells beyond the ply are 0: a valid address)
+                const bool leafp = d == kPlies - 1;
+                const int off = on ? slot : 0, I = s_inf[node];
+                const int p0 = s_pay[leafp ? cbase + off : 0];
+                const double child = val[leafp ? 0 : cbase + off];
+                const double ls = L[I * 4 + slot], Rc = R[I * 4 + slot], Sc = S[I * 4 + slot];   // rows are zero-padded beyond n
 #pragma unroll
                 for (int k = 0; k < kPlies - 1; k++) {   // x * 1.0 is x: plies beyond the node's leave the product untouched
                     const double f = k < d ? pl[k] : 1.0;
                     if ((k & 1) == 0) r0 = r0 * f; else r1 = r1 * f;
                 }
-                const bool leafp = d == kPlies - 1;
-                double au[4];
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    const int off = i < n ? i : 0;
-                    const int p0 = s_pay[leafp ? cbase + off : 0];
-                    const double child = val[leafp ? 0 : cbase + off];
-                    au[i] = leafp ? 0.5 * (double)(trav == 0 ? p0 : -p0) : child;   // terminal (:58-59) or the child's value
-                }
-                const int I = s_inf[node];
                 const bool is_trav = (d & 1) == trav;
                 const double reach = trav == 0 ? r0 : r1, opp = trav == 0 ? r1 : r0;
-                const double v = sched_exit(R, S, L, I, n, au, is_trav, reach, opp);
-                val[node] = v;
+                const double au = leafp ? 0.5 * (double)(trav == 0 ? p0 : -p0) : child;   // terminal (:58-59) or the child's value
+                const double prod = ls * au;
+                double v = quad_bcast<0>(prod);  // np.sum(local_strategy * action_utils) (:87)
+                { const double t1 = v + quad_bcast<1>(prod); v = n > 1 ? t1 : v; }
+                { const double t2 = v + quad_bcast<2>(prod); v = n > 2 ? t2 : v; }
+                { const double t3 = v + quad_bcast<3>(prod); v = n > 3 ? t3 : v; }
+                const bool upd = is_trav && on;   // (:89-95)
+                const double Rn = upd ? Rc + opp * (au - v) : Rc, Sn = upd ? Sc + reach * ls : Sc;
+                // local_strategy refresh on EVERY visit (:97) = InfoNode.get_strategy (:23-30)
+                const double pos = (on && Rn > 0.0) ? Rn : 0.0;
+                double sum = quad_bcast<0>(pos);
+                { const double t1 = sum + quad_bcast<1>(pos); sum = n > 1 ? t1 : sum; }
+                { const double t2 = sum + quad_bcast<2>(pos); sum = n > 2 ? t2 : sum; }
+                { const double t3 = sum + quad_bcast<3>(pos); sum = n > 3 ? t3 : sum; }
+                const double uni = n == 4 ? 0.25 : n == 3 ? 1.0 / 3.0 : n == 2 ? 0.5 : 1.0;   // 1.0 / n, correctly rounded either way
+                const double q = pos / sum;
+                if (live) {
+                    L[I * 4 + slot] = on ? (sum > 0.0 ? q : uni) : 0.0;
+                    if (upd) { R[I * 4 + slot] = Rn; S[I * 4 + slot] = Sn; }
+                    if (slot == 0) val[node] = v;
+                }
             }
             __syncthreads();
         }
