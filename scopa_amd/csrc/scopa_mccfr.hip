@@ -5,34 +5,34 @@
 // action is re-expanded by a fresh sampled sub-traversal (:69-78); at an opponent node only the sampled child is
 // followed.  With the 4,4,3,3,2,2,1,1 legal profile that recursion tree is always the same shape: per ply
 // 1,5,5,20,20,60,60,120 nodes for traverser 0 and 1,1,5,5,20,20,60,60 for traverser 1 (291 / 172 decision visits,
-// 120 leaves), a node being named by the branch digits taken at the traverser plies above it (0 = the sampled child,
-// i+1 = re-expansion of action i).
+// 120 leaves).  A node is (traverser, ntl, j): ntl traverser plies above it, j its branch index at that level (child of a traverser
+// node with n legal actions: j*(n+1) for the sampled child, j*(n+1) + i + 1 for the re-expansion of action i).
 //
 // Kernel design (k_mccfr_traverse): LEVEL-SYNCHRONOUS over the recursion tree, one lane per UNIQUE node, one
 // WAVEFRONT per traversal pair.  Ply d of a pair is one step over its 2, 6, 10, 25, 40, 80 nodes (plies 0..5), each
 // lane deriving its node from its parent's values, fetched from the parent's lane with cross-lane reads (index arithmetic:
-// the game tree is regular),
-// sampling its action from the frozen sigma|cdf row and leaving its own record for the next ply.  The 16 wavefronts
-// of a workgroup run their pairs independently -- only wave-level LDS ordering between plies, no workgroup barrier
-// in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).
-// Random draws are Philox4x32-10 blocks keyed by the node's PATH: a node is (traverser, ntl, j) -- ntl traverser plies above it, j its
-// branch index at that level in mixed radix (5,4,3) -- and block (ntl, j >> 1) of the (global traversal id, iteration, traverser)
+// the game tree is regular), sampling its action from the frozen sigma|threshold row and keeping its own values in registers for
+// the next ply.  The 16 wavefronts of a workgroup run their pairs independently -- only wave-level LDS ordering between plies,
+// no workgroup barrier in the main loop -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).
+// Random draws are Philox4x32-10 blocks keyed by the node: block (ntl, j >> 1) of the (global traversal id, iteration, traverser)
 // stream serves the four nodes (j even | odd) x (opponent node | traverser node below it), one 32-bit word each.  All 58 blocks of a
 // pair are computed in ONE dense pre-pass (draw_pair) and kept as 31-bit integers that are compared with integer thresholds
-// ceil(cdf * 2^31) -- so results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they only resolve the 60 leaf payoffs per task and the visit counts.
-// The update step then gives one lane per traverser node (26 per task): v as the reference's fma chain over <= 4 leaf
-// payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Everything a pair touches is LDS resident
-// (sigma|threshold rows 41 KB, delta 24 KB, 16 x 3.1 KB wave scratch, tree maps 4 KB at 738 infosets; one persistent
-// 1024-thread workgroup per CU); each workgroup finally streams its partial table as one coalesced SLAB to HBM and
-// k_mccfr_reduce_apply (k_mccfr_reduce + k_mccfr_apply on the split path) sums the slabs in a fixed order, for N > 1
-// exchanges the rows with the peers (scopa_p2p.h), and applies them.  Strategy sums are integer visit counts (sigma is frozen, so
-// strategy_sum += count * sigma).
+// ceil(cdf * 2^31) -- so results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they
+// only resolve the 60 leaf payoffs per task and the visit counts.  The update step then gives one lane per traverser node (26 per
+// task): v as the reference's fma chain over <= 4 leaf payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Every stage
+// gathers what it reads before it stores anything (branch-free loads, slots beyond a node's action count selected away).
+// Everything a pair touches is LDS resident (sigma|threshold rows 35 KB, delta 24 KB, 16 x 2 KB wave scratch, tree maps 4 KB at
+// 738 infosets; one 1024-thread workgroup per CU).  A workgroup finally adds its non-zero cells to one of 8 GROUP TABLES in HBM
+// with memory-side float64 atomics; k_mccfr_apply_groups (one small launch; k_mccfr_exchange_apply for N > 1, which exchanges the
+// rows with the peers first, scopa_p2p.h; k_mccfr_fold + k_mccfr_apply on the split path) sums the 8 tables in table order and
+// applies them.  Strategy sums are integer visit counts (sigma is frozen, so strategy_sum += count * sigma).
 //
-// History (rocprofv3, B = 4096 per traverser, profiles/): v1 one lane per leaf path + global f64 atomics + one global
-// counter atomic per wavefront: 122 us (100 us of it 8192 same-address atomics); v2 slabs + per-workgroup counters +
-// traverser-specialised walk: 20-23 us, 2.8 us per 16 tasks (issue-bound at ~1.5 cycles/instruction); v3 unique
-// nodes with workgroup-wide plies: same time (latency-bound); v4-v6 (unique nodes per wavefront, dense Philox pre-pass,
-// integer thresholds, batched prologue loads, streamed slabs): 14.9 us, see DESIGN.md section 4.
+// History (rocprofv3, B = 4096 per traverser, profiles/; full table in DESIGN.md section 4): v1 one lane per leaf path + global f64
+// atomics + one global counter atomic per wavefront: 122 us (100 us of it 8192 same-address atomics); v2 per-workgroup slabs +
+// a reduce kernel + traverser-specialised walk: 20-23 us; v3 unique nodes with workgroup-wide plies: same time (latency-bound);
+// v4-v7 (unique nodes per wavefront, dense Philox pre-pass, integer thresholds, node records in registers): 13.6 us + 8.3 us of
+// slab reduce; v8-v11 (round 2: slabs -> sparse atomics into group tables, lane-per-cell apply kernel, one Philox pass of 31-bit
+// draws, gather-then-store stages): 12.2 us + 4.9 us, 15.6 us per iteration.
 #include <hip/hip_ext.h>
 
 #include "scopa_ctx.h"
