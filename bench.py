@@ -150,18 +150,24 @@ def main_sdcfr(args):
     import torch.distributed as dist
     from scopa_amd.envs import load_game
     from scopa_amd.algorithms.deep_cfr import DeepCFR
-    world, rank, local = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0"))
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    local = 0 if args.share_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     if args.gpus != world:
         sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         sys.exit("bench.py needs a GPU: the solver path has no CPU fallback")
+    if local >= torch.cuda.device_count():
+        sys.exit(f"bench.py: rank {rank} wants GPU {local}, the node shows {torch.cuda.device_count()} (use --share-gpu to rehearse on fewer GPUs)")
     torch.cuda.set_device(local)
     saved_stdout = None
     if world > 1:
         sys.stdout.flush()
         saved_stdout = os.dup(1)
         os.dup2(2, 1)
-        dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
+        if args.share_gpu:   # rehearsal: all ranks on device 0, gloo carries the gradient all-reduce (RCCL refuses two ranks on one device)
+            dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", rank=rank, world_size=world, device_id=torch.device(f"cuda:{local}"))
     batch = args.batch
     torch.manual_seed(0)
     _so = os.dup(1)
@@ -203,9 +209,18 @@ def main_sdcfr(args):
     fence()
     elapsed = time.perf_counter() - t0
     if world > 1:
-        tm = torch.tensor([elapsed], dtype=torch.float64, device=f"cuda:{local}")
+        tm = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else f"cuda:{local}")
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
         elapsed = float(tm.item())
+        # replicas must have stayed identical: the same averaged gradients, the same Adam steps
+        flat = torch.cat([p.detach().reshape(-1) for a in d.advantage_nets for p in a.net.parameters()]).double()
+        h = torch.tensor([float(flat.sum().item()), float((flat * flat).sum().item())], dtype=torch.float64, device="cpu" if args.share_gpu else f"cuda:{local}")
+        hs = [torch.zeros_like(h) for _ in range(world)]
+        dist.all_gather(hs, h)
+        replicas_identical = all(bool(torch.equal(x, hs[0])) for x in hs)
+        assert replicas_identical, "SDCFR replicas' advantage nets differ after the run"
+    else:
+        replicas_identical = None
     visits = (ctx.sdcfr_visits() - v0) * world
     assert visits == (105 + 82) * batch * args.steps * world
     kern_ms = [a.elapsed_time(b) for a, b in d.kernel_events]
@@ -232,7 +247,8 @@ def main_sdcfr(args):
                                       f"(k_sdcfr_traverse fills the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch 128 per player on PyTorch-ROCm",
                           "batch_per_gpu": batch, "global_batch": batch * world, "iterations": args.steps,
                           "parallelism": f"dp{world}" + (" + 1 gradient all-reduce of 55104 B per optimiser step (RCCL)" if world > 1 else ""),
-                          "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)"},
+                          "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)",
+                          "replicas_bit_identical": replicas_identical, "shared_gpu_rehearsal": bool(args.share_gpu)},
                "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms)},
                "roofline": {"bound": top, "achieved": bounds[top]["achieved"], "peak": bounds[top]["peak"], "unit": bounds[top]["unit"], "frac": bounds[top]["frac"],
                             "traffic": None, "kernel": "k_sdcfr_traverse", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,

@@ -52,3 +52,10 @@ def test_bench_sdcfr_workload(ctx):
     d = _bench("--workload", "sdcfr", "--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline")
     assert d["dtype"] == "f32" and d["decision_visits"] == (105 + 82) * 256 * 3
     assert d["roofline"]["kernel"] == "k_sdcfr_traverse" and 0.0 < d["roofline"]["frac"] <= 1.0
+
+
+def test_bench_sdcfr_two_ranks_spawned(ctx):
+    """BASELINE configs[4] at rehearsal scale: `--workload sdcfr --gpus 2` started plainly, both ranks on the one GPU."""
+    d = _bench("--workload", "sdcfr", "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "128", "--no-cpu-baseline")
+    assert d["n_gpus"] == 2 and d["config"]["global_batch"] == 256 and d["config"]["replicas_bit_identical"] is True
+    assert d["decision_visits"] == (105 + 82) * 128 * 2 * 2
