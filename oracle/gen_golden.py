@@ -16,6 +16,7 @@ Fixtures (consumers: tests/, oracle pinning):
   vanilla_cfr.npz     CFRTrainer tables after 1,2,5,50,200 iterations             (vanilla_cfr.py:56-120)
   mccfr.npz           MCCFRTrainer tables under np.random.seed(k)                 (mc_cfr.py:37-99)
   MiniScopa_MCCFR_data.reference.json  the reference's committed 10-run MCCFR experiment output (experiment_tracker.py:82-158)
+  vanilla_cfr_experiment.json  the reference's vanilla-CFR experiment runner, seeded and shortened (run_vanilla_cfr_experiment.py:59-131)
   mccfr_experiment_runs.json  24 seeded runs of the reference's published experiment (run_mccfr_experiment.py:64-137) + exact EV of each final policy
   mccfr_frozen.npz    MCCFRTrainer._sample driven with frozen strategies and path-keyed draws: batched-MCCFR deltas (mc_cfr.py:37-86)
   evaluate.json       evaluate_agent results under np.random.seed(k)              (vanilla_cfr.py:157-216, mc_cfr.py:146-206)
@@ -671,6 +672,27 @@ def gen_experiment(ns, n_runs=24):
     print("experiment:", summary)
 
 
+def gen_vanilla_experiment(ns):
+    """The reference's vanilla-CFR experiment runner (run_vanilla_cfr_experiment.py:59-131: per iteration two direct _cfr_recursive
+    calls, evaluate_policy_quick every 5 iterations, evaluate_agent at the end) run by the reference under np.random.seed(11), shortened
+    to 30 iterations / 600 final episodes.  tests/test_gpu_boundary.py runs the same protocol on the build's classes and expects
+    these numbers back exactly: training is deterministic and bit-pinned, the evaluators consume the numpy stream identically."""
+    import contextlib
+    import importlib
+    import io
+    exp = importlib.import_module("experiments.run_vanilla_cfr_experiment")
+    np.random.seed(11)
+    with contextlib.redirect_stdout(io.StringIO()):
+        m = exp.run_vanilla_cfr_experiment(iterations=30, eval_interval=5, final_eval_episodes=600)
+    out = dict(seed=11, iterations=30, eval_interval=5, final_eval_episodes=600, eval_iterations=m.eval_iterations, eval_rewards=m.eval_rewards,
+               eval_scopas_trained=m.eval_scopas_trained, eval_scopas_random=m.eval_scopas_random, eval_scopa_diff=m.eval_scopa_diff,
+               final_reward=m.final_reward, final_scopa_trained=m.final_scopa_trained, final_scopa_random=m.final_scopa_random,
+               final_scopa_diff=m.final_scopa_diff, num_info_sets=m.num_info_sets, next_uniform=float(np.random.random_sample()))
+    with open(os.path.join(OUT, "vanilla_cfr_experiment.json"), "w") as f:
+        json.dump(out, f)
+    print("vanilla experiment:", out["eval_rewards"], out["final_reward"], out["num_info_sets"])
+
+
 def gen_tracker(ns):
     """The reference's committed experiment output (src/experiments/experiments/results/MiniScopa_MCCFR_data.json: 10 MCCFR runs x
     500 iterations, written by ExperimentTracker.save_data_for_plotting, experiment_tracker.py:82-158) as a fixture: a data file,
@@ -683,7 +705,7 @@ def gen_tracker(ns):
     print("tracker: runs", d["num_runs"], "eval points", len(d["runs"][0]["eval_iterations"]))
 
 
-ALL = dict(experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+ALL = dict(vanilla_experiment=gen_vanilla_experiment, experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

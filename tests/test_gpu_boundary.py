@@ -134,6 +134,26 @@ def test_reference_experiment_replayed_bit_for_bit(game, golden):
             assert (rew, st["trained_avg"], st["opponent_avg"]) == (r["eval_rewards"][k], r["eval_scopas_trained"][k], r["eval_scopas_random"][k])
 
 
+def test_reference_vanilla_cfr_experiment_protocol_reproduced(game, golden):
+    """The CALLER side of the path: the reference's vanilla-CFR experiment runner (run_vanilla_cfr_experiment.py:59-131 -- direct
+    _cfr_recursive calls per player, evaluate_policy_quick every 5 iterations, evaluate_agent at the end), run by the reference under
+    np.random.seed(11) (tests/golden/vanilla_cfr_experiment.json).  The build's runner on the build's classes returns the same
+    ExperimentMetrics, number for number, and leaves the numpy stream at the same position."""
+    import importlib.util
+    import os
+    from conftest import ROOT
+    spec = importlib.util.spec_from_file_location("reproduce_vanilla", os.path.join(ROOT, "benchmarks", "reproduce_vanilla_cfr_experiment.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    r = golden.json("vanilla_cfr_experiment.json")
+    np.random.seed(r["seed"])
+    m = mod.run_vanilla_cfr_experiment(game, r["iterations"], r["eval_interval"], r["final_eval_episodes"])
+    for k in ("eval_iterations", "eval_rewards", "eval_scopas_trained", "eval_scopas_random", "eval_scopa_diff", "final_reward",
+              "final_scopa_trained", "final_scopa_random", "final_scopa_diff", "num_info_sets"):
+        assert getattr(m, k) == r[k], k
+    assert float(np.random.random_sample()) == r["next_uniform"]
+
+
 def test_mccfr_trainer_batched_mode(game, oracle):
     from scopa_amd.algorithms import MCCFRTrainer
     tr = MCCFRTrainer(game, batch=512, seed=77)
