@@ -44,7 +44,7 @@ __device__ __forceinline__ double *p2p_line(double *inbox, int par, int world, i
 // (sc0 sc1) access -- inbox memory is fine-grained, such accesses go to memory, not through this XCD's L2 -- ordered by
 // s_waitcnt alone: the sequence word is issued only after the data stores of the same line were acknowledged (vmcnt(0)),
 // and the data loads are issued only after the sequence word was seen.  No cache maintenance, so the kernel's L2 contents
-// (slabs, tables) are left alone; it relies on the fabric acknowledging a remote store only once it is visible at its
+// (group tables, solver tables) are left alone; it relies on the fabric acknowledging a remote store only once it is visible at its
 // destination, which is why callers switch it on only after validating it on their topology (scopa_p2p_set_form).
 
 typedef double p2p_v2f64 __attribute__((ext_vector_type(2)));

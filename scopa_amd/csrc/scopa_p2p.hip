@@ -2,19 +2,20 @@
 //
 // The per-iteration exchange is 29.5 KB (n_infosets x 5 float64): far below the size at which a ring collective's
 // bandwidth matters and dominated by its latency.  With one process per GPU on one node every rank can map every peer's
-// buffer (hipIpc*), and the exchange is done row by row (scopa_p2p.h: p2p_exchange_row): the owner of an infoset row stores
+// buffer (hipIpc*), and the exchange is done row by row (scopa_p2p.h: p2p_exchange_wave4): the owner of an infoset row stores
 // its 40 bytes into a 64-byte line of every peer's inbox, fences at system scope, release-stores the sequence number into
 // the same lines, waits (bounded) for the `world` sequence words of its row and adds the rows IN RANK ORDER -- the same
 // order on every rank, so the replicas' tables stay bit-identical and the sum is reproducible run to run (a ring's order
-// is not ours to fix).  Rows are independent, so the exchange sits INSIDE the reduce+apply kernel
-// (k_mccfr_reduce_apply<true>, scopa_mccfr.hip): an N > 1 iteration is the same two launches as a single-GPU one.
+// is not ours to fix).  Rows are independent, so the exchange sits INSIDE the apply kernel
+// (k_mccfr_exchange_apply, scopa_mccfr.hip): an N > 1 iteration is the same two launches as a single-GPU one.
 // k_p2p_rows is the stand-alone form on the delta buffer (scopa_p2p_allreduce_delta: validation and the split path).
 // Inboxes are fine-grained device memory (coherent at system scope inside a kernel).  Lines are double-buffered by
 // sequence parity: a peer can only be one exchange ahead (its exchange s+1 of a row needs this rank's row of s+1, which is
 // launched after this rank's kernel of exchange s has finished), so a line of parity s & 1 is never overwritten while
 // it is being read.
-// Every wait is bounded by a wall-clock budget; a timeout is counted in an error word the host reads
-// (scopa_p2p_status) and makes all later waits fall through, so a dead peer can never hang the GPU.
+// Every wait is bounded by a wall-clock budget; a timeout is counted in an error word, sets a pinned host word that makes
+// scopa_p2p_allreduce_delta / scopa_mccfr_iterate_sharded fail with SCOPA_ETIMEOUT (p2p_check), and makes all later waits fall
+// through, so a dead peer can never hang the GPU nor go unnoticed.
 // The reference has no distributed code; torch.distributed (RCCL) remains the portable path and the check
 // (scopa_amd/distributed.py validates this exchange against it before using it).
 #include <string.h>
