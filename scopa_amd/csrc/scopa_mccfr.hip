@@ -117,10 +117,9 @@ k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g
 // ---------------------------------------------------------------------------------------------------------------------
 // Per-wavefront scratch in LDS: the records of one traversal pair (2 tasks) + what the update step needs.
 struct WaveScratch {
-    uint32_t pk5[80];        // ply 5 (60 + 20 nodes, two rounds): idx | sampled action << 21, for the leaf stage
-    double updr[2 * kUpd];   // opponent reach ...
-    double upds[2 * kUpd];   // ... and own sampling probability at every traverser node with > 1 action
-    uint16_t updI[2 * kUpd]; // ... and its infoset
+    uint32_t npk[166];       // one record per node of plies 0..5 (2 + 6 + 10 + 25 + 40 nodes, then ply 5's 60 + 20 from slot 86): idx | infoset << 10
+                             // | sampled action << 21.  The leaf stage reads ply 5's; the update step rebuilds a traverser node's reach and
+                             // sampling probability from its ancestors' records
     int8_t p6[2 * 60];       // resolved leaf payoffs x2 (traverser's sign) per task
     // the pair's random draws, 31-bit integers, indexed by node (base(ntl) + j, base = 0, 1, 6, 26); only the ones consumed are kept
     uint32_t kx0[86];        // traverser 0: opponent nodes of plies 1,3,5   (slot 0 unused)
@@ -145,7 +144,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair j0 = 2 * (p - first block of the level), j0 + 1; its words are
 // x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the traverser node below it.
 // Philox counter = (p, global traversal id, iteration, traverser), key = seed.
-constexpr int kStaticLds = 64;   // s_vis (+ alignment), beside the dynamic LDS
+constexpr int kStaticLds = 64 + 640;   // s_vis (+ alignment) and the update step's ancestor table, beside the dynamic LDS
 
 __device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
     if (lane < 58) {
@@ -167,14 +166,38 @@ __device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b,
     wave_lds_sync();
 }
 
-// What a node hands down to its children, kept in the REGISTERS of the lane that computed it: plies 0..4 have at most 40
-// nodes per pair, so a child fetches its parent's values with cross-lane reads (ds_bpermute: the LDS crossbar, no memory, no
-// bank conflicts) instead of a 24-byte record written to and read back from LDS.  Only ply 5 (80 nodes, two rounds) leaves
-// something in LDS: (idx, sampled action) in one word per node, for the leaf stage.
+// A node hands ONE word down to its children, kept in the REGISTER of the lane that computed it and fetched by the child with a
+// cross-lane read (ds_bpermute: the LDS crossbar, no memory, no bank conflicts): pk = idx | infoset << 10 | sampled action << 21.
+// The same word goes to ws.npk for the update step.  (Until round 2 a node also handed down the two float64 products reach and
+// sampling probability: four more cross-lane reads, a sigma read and two multiplications on EVERY node of every ply, although only
+// the 52 traverser nodes of the update step use them -- 15 LDS operations per ply; now 7.)
 struct NodeRegs {
-    double reach, samp;
-    uint32_t pk;   // idx (10 bits) | infoset << 10 (11 bits) | sampled action << 21
+    uint32_t pk;
 };
+
+// where ply d's node records start in ws.npk, and the slot of node (traverser, j) of ply d
+__host__ __device__ constexpr int npk_offset(int d) { return d == 0 ? 0 : d == 1 ? 2 : d == 2 ? 8 : d == 3 ? 18 : d == 4 ? 43 : 86; }
+__host__ __device__ constexpr int npk_slot(int trav, int d, int j) { return npk_offset(d) + (trav ? task_nodes(0, d) : 0) + j; }
+
+// The update step's static knowledge, one row of 6 uint16 per update lane x (0..51: traverser x / 26, level m, node j): for every ply
+// q above the node the ws.npk slot of its ancestor there (low byte) and the action that leads from that ancestor towards the node if
+// it is FORCED by a re-expansion (high byte = action + 1; 0 = the ancestor's sampled action), 0xFFFF for q >= the node's ply;
+// entry 5 = the node's own slot.  Built once per workgroup.
+constexpr int kAncRow = 6;
+__device__ __forceinline__ void anc_build(int x, uint16_t *__restrict__ row) {
+    const int trav = x < kUpd ? 0 : 1, xx = trav ? x - kUpd : x;
+    const int m = xx == 0 ? 0 : xx < 6 ? 1 : 2;
+    int j = xx - (m == 0 ? 0 : m == 1 ? 1 : 6);
+    const int d = 2 * m + trav;
+    row[5] = (uint16_t)npk_slot(trav, d, j);
+    for (int q = 0; q < 5; q++) row[q] = 0xFFFFu;
+    for (int c = d; c > 0; c--) {                       // climb: node j of ply c -> its parent at ply c - 1
+        const int pd = c - 1, pn = 4 - (pd >> 1);
+        int forced = 0;
+        if ((pd & 1) == trav) { const int pj = j / (pn + 1), br = j - pj * (pn + 1); forced = br; j = pj; }   // br = 0: the sampled child
+        row[pd] = (uint16_t)(npk_slot(trav, pd, j) | (forced << 8));
+    }
+}
 
 // One ply of one traversal pair: lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's.
 template <int D>
@@ -187,39 +210,33 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
     // the first LDS write or atomic, and none sits under a branch -- lanes without a node read slot 0 and are ignored afterwards
     struct Pre {
         bool valid, is_trav;
-        int t, trav, j, idx, In;
-        double reach, samp;
+        int t, idx, In;
         uint32_t k, thr0, thr1, thr2;
     };
     auto gather = [&](int t0) -> Pre {
         Pre g;
         g.t = t0 + lane;
         g.valid = g.t < c0 + c1;
-        g.trav = g.t < c0 ? 0 : 1;
-        g.j = g.valid ? (g.trav ? g.t - c0 : g.t) : 0;
-        g.is_trav = (D & 1) == g.trav;
-        const int ntl = g.trav == 0 ? (D + 1) >> 1 : D >> 1;
-        g.idx = 0; g.reach = 1.0; g.samp = 1.0;
+        const int trav = g.t < c0 ? 0 : 1;
+        const int j = g.valid ? (trav ? g.t - c0 : g.t) : 0;
+        g.is_trav = (D & 1) == trav;
+        const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
+        g.idx = 0;
         if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
             constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
-            const bool p_trav = (pd & 1) == g.trav;
-            int pj = g.j, br = 0;
-            if (p_trav) { pj = g.j / (pn + 1); br = g.j - pj * (pn + 1); }
-            int plane = (g.trav ? task_nodes(0, pd) : 0) + pj;
+            const bool p_trav = (pd & 1) == trav;
+            int pj = j, br = 0;
+            if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
+            int plane = (trav ? task_nodes(0, pd) : 0) + pj;
             plane = g.valid ? plane : 0;
-            const double p_reach = __shfl(st.reach, plane), p_samp = __shfl(st.samp, plane);
             const uint32_t ppk = (uint32_t)__shfl((int)st.pk, plane);
-            const int p_inf = (int)((ppk >> 10) & 2047u);
             const int act = (p_trav && br > 0) ? br - 1 : (int)(ppk >> 21);
             g.idx = (int)(ppk & 1023u) * pn + act;
-            const double sg = s_sigcdf[p_inf * kRow + act];
-            g.samp = p_trav ? p_samp * sg : p_samp;
-            g.reach = p_trav ? p_reach : p_reach * sg;
         }
         g.In = s_inf[level_offset(D) + g.idx];
         // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pair()
-        const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + g.j;
-        g.k = g.trav == 0 ? (g.is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (g.is_trav ? ws.ky1[blk] : ws.kx1[blk]);
+        const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
+        g.k = trav == 0 ? (g.is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (g.is_trav ? ws.ky1[blk] : ws.kx1[blk]);
         // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
         // most nodes are, instead of three
         const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + g.In * kRow + 4);
@@ -232,22 +249,12 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
     NodeRegs mine = st;
     auto finish = [&](const Pre &g) {
         if (!g.valid) return;
-        const int ntl = g.trav == 0 ? (D + 1) >> 1 : D >> 1;
-        if (!g.is_trav) s_seen[g.In] = 1;  // benign race: every writer stores 1.  Traverser nodes are counted in s_cnt, which marks them seen
         const int a = (g.thr0 <= g.k) + (g.thr1 <= g.k) + (g.thr2 <= g.k);
-        if (g.is_trav) {  // what the update step needs (mc_cfr.py:81-82)
-            const int x = g.trav * kUpd + (ntl == 0 ? 0 : ntl == 1 ? 1 : 6) + g.j;
-            ws.updI[x] = (uint16_t)g.In;
-            ws.updr[x] = g.reach;
-            ws.upds[x] = g.samp;
-            atomicAdd(&s_cnt[g.In], 1u);
-        }
-        if constexpr (D == 5) {  // 80 nodes in two rounds: the leaf stage reads (idx, sampled action) from LDS
-            ws.pk5[g.t] = (uint32_t)g.idx | ((uint32_t)a << 21);
-        } else {
-            mine.reach = g.reach; mine.samp = g.samp;
-            mine.pk = (uint32_t)g.idx | ((uint32_t)g.In << 10) | ((uint32_t)a << 21);
-        }
+        if (g.is_trav) atomicAdd(&s_cnt[g.In], 1u);   // strategy_sum += sigma per traverser visit (mc_cfr.py:84); also marks the infoset seen
+        else s_seen[g.In] = 1;                        // benign race: every writer stores 1
+        const uint32_t pk = (uint32_t)g.idx | ((uint32_t)g.In << 10) | ((uint32_t)a << 21);
+        ws.npk[npk_offset(D) + g.t] = pk;             // the update step walks these records; the leaf stage reads ply 5's (80 nodes, two rounds)
+        if constexpr (D < 5) mine.pk = pk;
         visited += 1;
     };
     if constexpr (c0 + c1 > 64) {
@@ -268,11 +275,11 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
 __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
-                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis) {
+                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const uint16_t *__restrict__ s_anc) {
     draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
     // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
-    NodeRegs st = {1.0, 1.0, 0u};
+    NodeRegs st = {0u};
     my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
     my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
     my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
@@ -296,7 +303,7 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
             int pj = j;
             kk[q] = 0;
             if (trv[q] == 1) { pj = j / 3; kk[q] = j - pj * 3; }
-            ppk[q] = ws.pk5[(trv[q] ? 60 : 0) + pj];
+            ppk[q] = ws.npk[npk_offset(5) + (trv[q] ? 60 : 0) + pj];
         }
         int idx6[2], I6[2], I7[2], pay[2];
 #pragma unroll
@@ -318,8 +325,10 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
             }
     }
     wave_lds_sync();
-    // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84); everything is loaded before anything is used, the
-    // slots beyond the node's action count are selected away
+    // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84).  The node's opponent reach and own sampling probability
+    // are rebuilt here from its ancestors' records -- the product, root first, of sigma[ancestor infoset][action towards the node] over
+    // the opponent's / the traverser's plies above it: the same factors in the same order as the reference's top-down updates
+    // (:58-65, :75-76).  Everything is loaded before anything is used; plies / slots beyond the node's are selected away (x * 1.0 = x).
     if (lane < 2 * kUpd) {
         const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
         const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
@@ -327,14 +336,32 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         const int nX = 4 - m;
         const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
         const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
-        const int IX = ws.updI[lane];
-        const double rX = ws.updr[lane], sX = ws.upds[lane];
+        const uint16_t *an = s_anc + lane * kAncRow;
+        uint32_t rec[5];
+        uint16_t ae[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) { ae[q] = an[q]; rec[q] = ws.npk[ae[q] == 0xFFFFu ? 0 : (ae[q] & 0xFFu)]; }   // slots < 86: one byte
+        const int IX = (int)((ws.npk[an[5]] >> 10) & 2047u);
         const int8_t *p6 = ws.p6 + trav * 60;
         int pv[4];
 #pragma unroll
         for (int i = 0; i < 4; i++) pv[i] = p6[base + ((i < nX ? i : nX - 1) + 1) * stride];
+        double fq[5];
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const int forced = ae[q] >> 8;
+            const int act = forced ? forced - 1 : (int)(rec[q] >> 21);
+            fq[q] = s_sigcdf[(int)((rec[q] >> 10) & 2047u) * kRow + act];
+        }
         const double2 s01 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow), s23 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow + 2);
         const double sg[4] = {s01.x, s01.y, s23.x, s23.y};
+        double rX = 1.0, sX = 1.0;
+#pragma unroll
+        for (int q = 0; q < 5; q++) {
+            const bool on = ae[q] != 0xFFFFu, own = (q & 1) == trav;
+            sX = sX * ((on && own) ? fq[q] : 1.0);
+            rX = rX * ((on && !own) ? fq[q] : 1.0);
+        }
         const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
         double cfv[4], v = 0.0;
 #pragma unroll
@@ -369,6 +396,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                  unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
+    __shared__ uint16_t s_anc[2 * kUpd * kAncRow];
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows)
@@ -381,6 +409,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
+    if (tid < 2 * kUpd) anc_build(tid, s_anc + tid * kAncRow);
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
     // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue),
     // the LDS zeroing runs underneath them, then the loaded pieces are stored.
@@ -423,7 +452,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis);
+        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, s_anc);
     }
     __syncthreads();
 
@@ -471,6 +500,8 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
               uint32_t batch) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
+    __shared__ uint16_t s_anc[2 * kUpd * kAncRow];
+    if (threadIdx.x < 2 * kUpd) anc_build(threadIdx.x, s_anc + threadIdx.x * kAncRow);
     {
         const size_t deal = blockIdx.x;
         g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision; g_regret += deal * kDecision * 4;
@@ -504,7 +535,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         }
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
-            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis);
+            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, s_anc);
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
