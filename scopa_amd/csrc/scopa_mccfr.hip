@@ -184,6 +184,11 @@ __host__ __device__ constexpr int npk_slot(int trav, int d, int j) { return npk_
 // it is FORCED by a re-expansion (high byte = action + 1; 0 = the ancestor's sampled action), 0xFFFF for q >= the node's ply;
 // entry 5 = the node's own slot.  Built once per workgroup.
 constexpr int kAncRow = 6;
+struct AncRegs { uint32_t w[3]; };   // an update lane's row, read once per wavefront: it is the same for every pair the wave walks
+__device__ __forceinline__ AncRegs anc_load(const uint16_t *__restrict__ s_anc, int lane) {
+    const uint32_t *r = reinterpret_cast<const uint32_t *>(s_anc + (lane < 2 * kUpd ? lane : 0) * kAncRow);
+    return AncRegs{{r[0], r[1], r[2]}};
+}
 __device__ __forceinline__ void anc_build(int x, uint16_t *__restrict__ row) {
     const int trav = x < kUpd ? 0 : 1, xx = trav ? x - kUpd : x;
     const int m = xx == 0 ? 0 : xx < 6 ? 1 : 2;
@@ -275,7 +280,7 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
 __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
-                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const uint16_t *__restrict__ s_anc) {
+                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const AncRegs &anc) {
     draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
     // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
@@ -336,12 +341,11 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         const int nX = 4 - m;
         const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
         const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
-        const uint16_t *an = s_anc + lane * kAncRow;
         uint32_t rec[5];
-        uint16_t ae[5];
+        uint32_t ae[5];
 #pragma unroll
-        for (int q = 0; q < 5; q++) { ae[q] = an[q]; rec[q] = ws.npk[ae[q] == 0xFFFFu ? 0 : (ae[q] & 0xFFu)]; }   // slots < 86: one byte
-        const int IX = (int)((ws.npk[an[5]] >> 10) & 2047u);
+        for (int q = 0; q < 5; q++) { ae[q] = (anc.w[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; rec[q] = ws.npk[ae[q] == 0xFFFFu ? 0 : (ae[q] & 0xFFu)]; }   // slots < 86: one byte
+        const int IX = (int)((ws.npk[anc.w[2] >> 16] >> 10) & 2047u);
         const int8_t *p6 = ws.p6 + trav * 60;
         int pv[4];
 #pragma unroll
@@ -449,10 +453,11 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const unsigned long long t_pro = wall_clock64();
 
     WaveScratch &ws = s_wave[wave];
+    const AncRegs anc = anc_load(s_anc, lane);
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, s_anc);
+        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc);
     }
     __syncthreads();
 
@@ -523,6 +528,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
     __syncthreads();
     WaveScratch &ws = s_wave[wave];
+    const AncRegs anc = anc_load(s_anc, lane);
     unsigned int my_dvis = 0, my_tvis = 0;
     for (uint32_t it = 0; it < n_iters; it++) {
         for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
@@ -535,7 +541,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         }
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
-            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, s_anc);
+            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, anc);
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
