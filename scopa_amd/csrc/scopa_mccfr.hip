@@ -204,11 +204,89 @@ __device__ __forceinline__ void anc_build(int x, uint16_t *__restrict__ row) {
     }
 }
 
-// One ply of one traversal pair: lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's.
+// LDS addresses as 32-bit integers: what the lane-static tables below hold (a generic pointer laundered through a register would
+// come back as a flat pointer).
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p; }
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t a) { return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a; }
+
+// Everything about a lane's node SLOT that does not depend on the pair being walked -- which lane holds the parent, whether the action
+// towards the node is forced by a re-expansion, where its draw word lies, how many visits the lane accounts for: computed ONCE per
+// wavefront and pinned in registers.  Left to itself the compiler re-derives these selects inside the pair loop (it holds them cheap):
+// 33 VALU instructions per ply and slot instead of 17, and enough SGPR masks to spill the Philox round keys.
+// Slot D = ply D's node of this lane (lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's);
+// slot 6 = ply 5's second round (80 nodes); leaf slots q = 0, 1 = leaves lane, lane + 64 of the 120.
+struct LaneSlots {
+    uint32_t plane4[7];   // ds_bpermute address: 4 x the lane that holds the parent's record
+    uint32_t amask[7];    // action towards this node = (parent's sampled action & amask) | aforce
+    uint32_t aforce[7];
+    uint32_t kword[7];    // LDS address of the slot's draw word in the wave's scratch
+    uint32_t leaf_rec[2], leaf_amask[2], leaf_aforce[2];   // the same for a leaf: LDS address of its ply-5 ancestor's record
+    uint32_t dvis, tvis;  // decision / terminal visits this lane's slots stand for, per pair
+};
+#define SCOPA_PIN(x) asm volatile("" : "+v"(x))
+
+template <int D, int ROUND>
+__device__ __forceinline__ void lane_slot_build(LaneSlots &ls, const WaveScratch &ws, int lane) {
+    constexpr int S = D + ROUND;
+    constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
+    const int t = lane + 64 * ROUND;
+    const bool valid = t < c0 + c1;
+    const int trav = t < c0 ? 0 : 1;
+    const int j = valid ? (trav ? t - c0 : t) : 0;
+    const bool is_trav = (D & 1) == trav;
+    const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
+    uint32_t plane4 = 0u, amask = valid ? ~0u : 0u, aforce = 0u;
+    if constexpr (D > 0) {
+        constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
+        const bool p_trav = (pd & 1) == trav;
+        int pj = j, br = 0;
+        if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
+        if (valid) plane4 = 4u * (uint32_t)((trav ? task_nodes(0, pd) : 0) + pj);
+        if (valid && p_trav && br > 0) { amask = 0u; aforce = (uint32_t)(br - 1); }
+    }
+    // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pair()
+    const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
+    const uint32_t koff = trav == 0 ? (is_trav ? offsetof(WaveScratch, ky0) : offsetof(WaveScratch, kx0))
+                                    : (is_trav ? offsetof(WaveScratch, ky1) : offsetof(WaveScratch, kx1));
+    uint32_t kword = lds_addr(&ws) + koff + 4u * (uint32_t)blk;
+    SCOPA_PIN(plane4); SCOPA_PIN(amask); SCOPA_PIN(aforce); SCOPA_PIN(kword);
+    ls.plane4[S] = plane4; ls.amask[S] = amask; ls.aforce[S] = aforce; ls.kword[S] = kword;
+    ls.dvis += valid ? 1u : 0u;
+}
+
+__device__ __forceinline__ LaneSlots lane_slots_build(const WaveScratch &ws, int lane) {
+    LaneSlots ls;
+    ls.dvis = 0u; ls.tvis = 0u;
+    lane_slot_build<0, 0>(ls, ws, lane);
+    lane_slot_build<1, 0>(ls, ws, lane);
+    lane_slot_build<2, 0>(ls, ws, lane);
+    lane_slot_build<3, 0>(ls, ws, lane);
+    lane_slot_build<4, 0>(ls, ws, lane);
+    lane_slot_build<5, 0>(ls, ws, lane);
+    lane_slot_build<5, 1>(ls, ws, lane);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int t = lane + 64 * q;
+        const bool on = t < 2 * 60;
+        const int tt = on ? t : 0, trv = tt < 60 ? 0 : 1, j = trv ? tt - 60 : tt;
+        // ply-5 ancestor: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
+        int pj = j, kk = 0;
+        if (trv == 1) { pj = j / 3; kk = j - pj * 3; }
+        uint32_t rec = lds_addr(&ws.npk[npk_offset(5) + (trv ? 60 : 0) + pj]);
+        uint32_t amask = (trv == 1 && kk > 0) ? 0u : ~0u, aforce = (trv == 1 && kk > 0) ? (uint32_t)(kk - 1) : 0u;
+        SCOPA_PIN(rec); SCOPA_PIN(amask); SCOPA_PIN(aforce);
+        ls.leaf_rec[q] = rec; ls.leaf_amask[q] = amask; ls.leaf_aforce[q] = aforce;
+        ls.dvis += on ? (trv == 0 ? 3u : 2u) : 0u;   // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
+        ls.tvis += on ? 2u : 0u;
+    }
+    SCOPA_PIN(ls.dvis); SCOPA_PIN(ls.tvis);
+    return ls;
+}
+
+// One ply of one traversal pair.
 template <int D>
-__device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf,
-                                                 const double *__restrict__ s_sigcdf, uint8_t *__restrict__ s_seen,
-                                                 unsigned int *__restrict__ s_cnt, NodeRegs &st) {
+__device__ __forceinline__ void ply_step(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const double *__restrict__ s_sigcdf,
+                                         uint8_t *__restrict__ s_seen, unsigned int *__restrict__ s_cnt, NodeRegs &st, const LaneSlots &ls) {
     constexpr int n = 4 - (D >> 1);
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
     // what a lane gathers for its node before anything is stored: every LDS READ of the ply (both rounds of ply 5) is issued before
@@ -218,30 +296,21 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
         int t, idx, In;
         uint32_t k, thr0, thr1, thr2;
     };
-    auto gather = [&](int t0) -> Pre {
+    auto gather = [&](auto round) -> Pre {
+        constexpr int ROUND = decltype(round)::value, S = D + ROUND;
         Pre g;
-        g.t = t0 + lane;
+        g.t = 64 * ROUND + lane;
         g.valid = g.t < c0 + c1;
-        const int trav = g.t < c0 ? 0 : 1;
-        const int j = g.valid ? (trav ? g.t - c0 : g.t) : 0;
-        g.is_trav = (D & 1) == trav;
-        const int ntl = trav == 0 ? (D + 1) >> 1 : D >> 1;
+        g.is_trav = (D & 1) == (g.t < c0 ? 0 : 1);
         g.idx = 0;
         if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
-            constexpr int pd = D > 0 ? D - 1 : 0, pn = 4 - (pd >> 1);
-            const bool p_trav = (pd & 1) == trav;
-            int pj = j, br = 0;
-            if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
-            int plane = (trav ? task_nodes(0, pd) : 0) + pj;
-            plane = g.valid ? plane : 0;
-            const uint32_t ppk = (uint32_t)__shfl((int)st.pk, plane);
-            const int act = (p_trav && br > 0) ? br - 1 : (int)(ppk >> 21);
-            g.idx = (int)(ppk & 1023u) * pn + act;
+            constexpr int pn = 4 - ((D - 1) >> 1);
+            const uint32_t ppk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ls.plane4[S], (int)st.pk);
+            const uint32_t act = ((ppk >> 21) & ls.amask[S]) | ls.aforce[S];
+            g.idx = (int)((ppk & 1023u) * pn + act);
         }
         g.In = s_inf[level_offset(D) + g.idx];
-        // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pair()
-        const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
-        g.k = trav == 0 ? (g.is_trav ? ws.ky0[blk] : ws.kx0[blk]) : (g.is_trav ? ws.ky1[blk] : ws.kx1[blk]);
+        g.k = lds_read_u32(ls.kword[S]);
         // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
         // most nodes are, instead of three
         const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + g.In * kRow + 4);
@@ -250,7 +319,6 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
         g.thr2 = n > 3 ? thr[2] : 0xFFFFFFFFu;
         return g;
     };
-    unsigned int visited = 0;
     NodeRegs mine = st;
     auto finish = [&](const Pre &g) {
         if (!g.valid) return;
@@ -260,19 +328,17 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
         const uint32_t pk = (uint32_t)g.idx | ((uint32_t)g.In << 10) | ((uint32_t)a << 21);
         ws.npk[npk_offset(D) + g.t] = pk;             // the update step walks these records; the leaf stage reads ply 5's (80 nodes, two rounds)
         if constexpr (D < 5) mine.pk = pk;
-        visited += 1;
     };
     if constexpr (c0 + c1 > 64) {
-        const Pre g0 = gather(0), g1 = gather(64);
+        const Pre g0 = gather(std::integral_constant<int, 0>{}), g1 = gather(std::integral_constant<int, 1>{});
         finish(g0);
         finish(g1);
     } else {
-        const Pre g0 = gather(0);
+        const Pre g0 = gather(std::integral_constant<int, 0>{});
         finish(g0);
     }
     st = mine;
     if constexpr (D == 5) wave_lds_sync();
-    return visited;
 }
 
 // One traversal pair (both traversers of global traversal id b) on one wavefront: plies 0..5 level by level, plies 6-7, then the
@@ -280,22 +346,25 @@ __device__ __forceinline__ unsigned int ply_step(WaveScratch &ws, int lane, cons
 __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                           unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
-                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const AncRegs &anc) {
+                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const AncRegs &anc, const LaneSlots &ls,
+                                          const double *__restrict__ s_one) {
     draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
     // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
     NodeRegs st = {0u};
-    my_dvis += ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
-    my_dvis += ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
-    my_dvis += ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
-    my_dvis += ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
-    my_dvis += ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
-    my_dvis += ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st);
+    ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
+    ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
+    ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
+    ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
+    ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
+    ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
+    my_dvis += ls.dvis;   // the recursion tree has one shape: 291 + 172 decision visits and 2 x 120 terminal visits per pair
+    my_tvis += ls.tvis;
     // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts.  120 leaves on 64 lanes: both of a lane's items are
     // loaded before either is used (two dependent LDS round trips for the stage instead of four)
     {
         uint32_t ppk[2];
-        int tt[2], trv[2], kk[2];
+        int tt[2], trv[2];
         bool on[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
@@ -303,18 +372,13 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
             on[q] = t < 2 * 60;
             tt[q] = on[q] ? t : 0;
             trv[q] = tt[q] < 60 ? 0 : 1;
-            const int j = trv[q] ? tt[q] - 60 : tt[q];
-            // ply-5 parent: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
-            int pj = j;
-            kk[q] = 0;
-            if (trv[q] == 1) { pj = j / 3; kk[q] = j - pj * 3; }
-            ppk[q] = ws.npk[npk_offset(5) + (trv[q] ? 60 : 0) + pj];
+            ppk[q] = lds_read_u32(ls.leaf_rec[q]);
         }
         int idx6[2], I6[2], I7[2], pay[2];
 #pragma unroll
         for (int q = 0; q < 2; q++) {
-            const int act = (trv[q] == 1 && kk[q] > 0) ? kk[q] - 1 : (int)(ppk[q] >> 21);
-            idx6[q] = (int)(ppk[q] & 1023u) * 2 + act;     // = index of the ply-7 node and of the leaf as well
+            const uint32_t act = ((ppk[q] >> 21) & ls.leaf_amask[q]) | ls.leaf_aforce[q];
+            idx6[q] = (int)((ppk[q] & 1023u) * 2 + act);   // = index of the ply-7 node and of the leaf as well
             I6[q] = s_inf[level_offset(6) + idx6[q]];
             I7[q] = s_inf[level_offset(7) + idx6[q]];
             pay[q] = s_pay[idx6[q]];
@@ -325,15 +389,13 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
                 s_seen[trv[q] == 0 ? I7[q] : I6[q]] = 1;            // the opponent's node of the two (the traverser's is marked by its count)
                 atomicAdd(&s_cnt[trv[q] == 0 ? I6[q] : I7[q]], 1u); // the traverser's single-action node: strategy_sum += [1.0]
                 ws.p6[tt[q]] = (int8_t)(trv[q] == 0 ? pay[q] : -pay[q]);
-                my_dvis += trv[q] == 0 ? 3 : 2;                     // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
-                my_tvis += 2;
             }
     }
     wave_lds_sync();
     // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84).  The node's opponent reach and own sampling probability
     // are rebuilt here from its ancestors' records -- the product, root first, of sigma[ancestor infoset][action towards the node] over
     // the opponent's / the traverser's plies above it: the same factors in the same order as the reference's top-down updates
-    // (:58-65, :75-76).  Everything is loaded before anything is used; plies / slots beyond the node's are selected away (x * 1.0 = x).
+    // (:58-65, :75-76).  Everything is loaded before anything is used.
     if (lane < 2 * kUpd) {
         const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
         const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
@@ -352,20 +414,17 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         for (int i = 0; i < 4; i++) pv[i] = p6[base + ((i < nX ? i : nX - 1) + 1) * stride];
         double fq[5];
 #pragma unroll
-        for (int q = 0; q < 5; q++) {
+        for (int q = 0; q < 5; q++) {   // plies at or below the node's own: the factor 1.0, read from LDS like the others (one select, on the address)
             const int forced = ae[q] >> 8;
             const int act = forced ? forced - 1 : (int)(rec[q] >> 21);
-            fq[q] = s_sigcdf[(int)((rec[q] >> 10) & 2047u) * kRow + act];
+            const double *f = ae[q] != 0xFFFFu ? s_sigcdf + (int)((rec[q] >> 10) & 2047u) * kRow + act : s_one;
+            fq[q] = *f;
         }
         const double2 s01 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow), s23 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow + 2);
         const double sg[4] = {s01.x, s01.y, s23.x, s23.y};
-        double rX = 1.0, sX = 1.0;
-#pragma unroll
-        for (int q = 0; q < 5; q++) {
-            const bool on = ae[q] != 0xFFFFu, own = (q & 1) == trav;
-            sX = sX * ((on && own) ? fq[q] : 1.0);
-            rX = rX * ((on && !own) ? fq[q] : 1.0);
-        }
+        // even plies are traverser 0's, odd plies traverser 1's: two chains, root first (1.0 * x = x, x * 1.0 = x: the reference's products)
+        const double even = (fq[0] * fq[2]) * fq[4], odd = fq[1] * fq[3];
+        const double sX = trav == 0 ? even : odd, rX = trav == 0 ? odd : even;
         const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
         double cfv[4], v = 0.0;
 #pragma unroll
@@ -401,6 +460,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     __shared__ uint16_t s_anc[2 * kUpd * kAncRow];
+    __shared__ double s_one[1];
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows)
@@ -414,6 +474,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
     if (tid < 2 * kUpd) anc_build(tid, s_anc + tid * kAncRow);
+    if (tid == 0) s_one[0] = 1.0;
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
     // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue),
     // the LDS zeroing runs underneath them, then the loaded pieces are stored.
@@ -454,10 +515,11 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 
     WaveScratch &ws = s_wave[wave];
     const AncRegs anc = anc_load(s_anc, lane);
+    const LaneSlots ls = lane_slots_build(ws, lane);
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc);
+        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
     }
     __syncthreads();
 
@@ -506,7 +568,9 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     __shared__ uint16_t s_anc[2 * kUpd * kAncRow];
+    __shared__ double s_one[1];
     if (threadIdx.x < 2 * kUpd) anc_build(threadIdx.x, s_anc + threadIdx.x * kAncRow);
+    if (threadIdx.x == 0) s_one[0] = 1.0;
     {
         const size_t deal = blockIdx.x;
         g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision; g_regret += deal * kDecision * 4;
@@ -529,6 +593,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     __syncthreads();
     WaveScratch &ws = s_wave[wave];
     const AncRegs anc = anc_load(s_anc, lane);
+    const LaneSlots ls = lane_slots_build(ws, lane);
     unsigned int my_dvis = 0, my_tvis = 0;
     for (uint32_t it = 0; it < n_iters; it++) {
         for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
@@ -541,7 +606,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         }
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
-            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, anc);
+            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
