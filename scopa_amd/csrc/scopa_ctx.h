@@ -69,6 +69,7 @@ struct scopa_ctx {
     double prof_ms = 0.0;
 
     // exact vanilla CFR, scheduled form (scopa_cfr.hip): EXIT events of the deal's tree levelled under the per-infoset visit order
+    uint32_t *d_lane_tab = nullptr;   // [9][64] uint4: what a lane's node slots are made of, for the traversal kernels (scopa_mccfr.hip: LaneSlots), built at first use
     uint16_t *d_sched = nullptr;   // events (uint32 each) | step offsets | [kDecision][8] path cells (layout: scopa_cfr.hip)
     int sched_steps = 0;
     bool sched_valid = false;      // false after scopa_set_deal

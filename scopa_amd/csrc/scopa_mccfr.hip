@@ -144,23 +144,30 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair j0 = 2 * (p - first block of the level), j0 + 1; its words are
 // x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the traverser node below it.
 // Philox counter = (p, global traversal id, iteration, traverser), key = seed.
-constexpr int kStaticLds = 64 + 640;   // s_vis (+ alignment) and the update step's ancestor table, beside the dynamic LDS
+constexpr int kStaticLds = 64;   // s_vis, s_one, s_next (+ alignment), beside the dynamic LDS
 
-__device__ __forceinline__ void draw_pair(WaveScratch &ws, int lane, uint32_t b, uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
+template <int NP>
+__device__ __forceinline__ void draw_pairs(WaveScratch *ws, int lane, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
     if (lane < 58) {
         const int trav = lane < 44 ? 0 : 1, p = trav ? lane - 44 : lane;
         const int ntl = p == 0 ? 0 : p < 4 ? 1 : p < 14 ? 2 : 3;
         const int j0 = 2 * (p - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 4 : 14));
         const int node = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j0;            // index into the kx / ky arrays
         const bool two = j0 + 1 < (ntl == 0 ? 1 : ntl == 1 ? 5 : ntl == 2 ? 20 : 60);      // the level has an odd node count at ntl 0, 1
-        const philox_out x = philox4x32_10((uint32_t)p, b, iteration, (uint32_t)trav, seed_lo, seed_hi);
-        if (trav == 0) {
-            ws.kx0[node] = x.x0 >> 1;
-            if (two) ws.kx0[node + 1] = x.x2 >> 1;
-            if (ntl < 3) { ws.ky0[node] = x.x1 >> 1; if (two) ws.ky0[node + 1] = x.x3 >> 1; }
-        } else {
-            ws.kx1[node] = x.x0 >> 1; ws.ky1[node] = x.x1 >> 1;
-            if (two) { ws.kx1[node + 1] = x.x2 >> 1; ws.ky1[node + 1] = x.x3 >> 1; }
+        philox_out x[NP];
+#pragma unroll
+        for (int i = 0; i < NP; i++) x[i] = philox4x32_10((uint32_t)p, b[i], iteration, (uint32_t)trav, seed_lo, seed_hi);   // independent chains
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            WaveScratch &w = ws[i];
+            if (trav == 0) {
+                w.kx0[node] = x[i].x0 >> 1;
+                if (two) w.kx0[node + 1] = x[i].x2 >> 1;
+                if (ntl < 3) { w.ky0[node] = x[i].x1 >> 1; if (two) w.ky0[node + 1] = x[i].x3 >> 1; }
+            } else {
+                w.kx1[node] = x[i].x0 >> 1; w.ky1[node] = x[i].x1 >> 1;
+                if (two) { w.kx1[node + 1] = x[i].x2 >> 1; w.ky1[node + 1] = x[i].x3 >> 1; }
+            }
         }
     }
     wave_lds_sync();
@@ -182,13 +189,9 @@ __host__ __device__ constexpr int npk_slot(int trav, int d, int j) { return npk_
 // The update step's static knowledge, one row of 6 uint16 per update lane x (0..51: traverser x / 26, level m, node j): for every ply
 // q above the node the ws.npk slot of its ancestor there (low byte) and the action that leads from that ancestor towards the node if
 // it is FORCED by a re-expansion (high byte = action + 1; 0 = the ancestor's sampled action), 0xFFFF for q >= the node's ply;
-// entry 5 = the node's own slot.  Built once per workgroup.
+// entry 5 = the node's own slot.  Part of the lane table.
 constexpr int kAncRow = 6;
-struct AncRegs { uint32_t w[3]; };   // an update lane's row, read once per wavefront: it is the same for every pair the wave walks
-__device__ __forceinline__ AncRegs anc_load(const uint16_t *__restrict__ s_anc, int lane) {
-    const uint32_t *r = reinterpret_cast<const uint32_t *>(s_anc + (lane < 2 * kUpd ? lane : 0) * kAncRow);
-    return AncRegs{{r[0], r[1], r[2]}};
-}
+struct AncRegs { uint32_t w[3]; };   // an update lane's row
 __device__ __forceinline__ void anc_build(int x, uint16_t *__restrict__ row) {
     const int trav = x < kUpd ? 0 : 1, xx = trav ? x - kUpd : x;
     const int m = xx == 0 ? 0 : xx < 6 ? 1 : 2;
@@ -210,23 +213,27 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 __device__ __forceinline__ uint32_t lds_read_u32(uint32_t a) { return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a; }
 
 // Everything about a lane's node SLOT that does not depend on the pair being walked -- which lane holds the parent, whether the action
-// towards the node is forced by a re-expansion, where its draw word lies, how many visits the lane accounts for: computed ONCE per
-// wavefront and pinned in registers.  Left to itself the compiler re-derives these selects inside the pair loop (it holds them cheap):
-// 33 VALU instructions per ply and slot instead of 17, and enough SGPR masks to spill the Philox round keys.
+// towards the node is forced by a re-expansion, where its draw word lies, how many visits the lane accounts for, the update lane's
+// ancestor row -- is the same for every wavefront of every launch: k_lane_table computes it ONCE per context into a 9 KB table and a
+// wavefront loads its 36 words per lane under the prologue's other loads.  (Derived in the kernel it was ~300 VALU instructions per
+// wavefront before the first pair -- as much as a whole pair costs -- and, left to the compiler, 33 instead of 17 per ply and slot
+// inside the pair loop plus enough SGPR masks to spill the Philox round keys.)
 // Slot D = ply D's node of this lane (lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's);
 // slot 6 = ply 5's second round (80 nodes); leaf slots q = 0, 1 = leaves lane, lane + 64 of the 120.
 struct LaneSlots {
     uint32_t plane4[7];   // ds_bpermute address: 4 x the lane that holds the parent's record
     uint32_t amask[7];    // action towards this node = (parent's sampled action & amask) | aforce
     uint32_t aforce[7];
-    uint32_t kword[7];    // LDS address of the slot's draw word in the wave's scratch
+    uint32_t kword[7];    // LDS address of the slot's draw word in the wave's scratch (table: offset within WaveScratch)
     uint32_t leaf_rec[2], leaf_amask[2], leaf_aforce[2];   // the same for a leaf: LDS address of its ply-5 ancestor's record
     uint32_t dvis, tvis;  // decision / terminal visits this lane's slots stand for, per pair
 };
-#define SCOPA_PIN(x) asm volatile("" : "+v"(x))
+// table layout: word w of lane l at [w / 4][l] . (w % 4), i.e. 9 x 64 uint4 -- a wavefront reads 9 coalesced 1 KB lines
+constexpr int kLaneWords = 36, kLaneVecs = kLaneWords / 4;
+constexpr int kLwPlane = 0, kLwAmask = 6, kLwAforce = 12, kLwKword = 18, kLwLeafRec = 25, kLwLeafAmask = 27, kLwLeafAforce = 29, kLwDvis = 31, kLwTvis = 32, kLwAnc = 33;
 
 template <int D, int ROUND>
-__device__ __forceinline__ void lane_slot_build(LaneSlots &ls, const WaveScratch &ws, int lane) {
+__device__ __forceinline__ void lane_slot_build(uint32_t *w, uint32_t &dvis, int lane) {
     constexpr int S = D + ROUND;
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
     const int t = lane + 64 * ROUND;
@@ -243,155 +250,142 @@ __device__ __forceinline__ void lane_slot_build(LaneSlots &ls, const WaveScratch
         if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
         if (valid) plane4 = 4u * (uint32_t)((trav ? task_nodes(0, pd) : 0) + pj);
         if (valid && p_trav && br > 0) { amask = 0u; aforce = (uint32_t)(br - 1); }
+        w[kLwPlane + S - 1] = plane4; w[kLwAmask + S - 1] = amask; w[kLwAforce + S - 1] = aforce;
     }
-    // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pair()
+    // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pairs()
     const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
     const uint32_t koff = trav == 0 ? (is_trav ? offsetof(WaveScratch, ky0) : offsetof(WaveScratch, kx0))
                                     : (is_trav ? offsetof(WaveScratch, ky1) : offsetof(WaveScratch, kx1));
-    uint32_t kword = lds_addr(&ws) + koff + 4u * (uint32_t)blk;
-    SCOPA_PIN(plane4); SCOPA_PIN(amask); SCOPA_PIN(aforce); SCOPA_PIN(kword);
-    ls.plane4[S] = plane4; ls.amask[S] = amask; ls.aforce[S] = aforce; ls.kword[S] = kword;
-    ls.dvis += valid ? 1u : 0u;
+    w[kLwKword + S] = koff + 4u * (uint32_t)blk;
+    dvis += valid ? 1u : 0u;
 }
 
-__device__ __forceinline__ LaneSlots lane_slots_build(const WaveScratch &ws, int lane) {
-    LaneSlots ls;
-    ls.dvis = 0u; ls.tvis = 0u;
-    lane_slot_build<0, 0>(ls, ws, lane);
-    lane_slot_build<1, 0>(ls, ws, lane);
-    lane_slot_build<2, 0>(ls, ws, lane);
-    lane_slot_build<3, 0>(ls, ws, lane);
-    lane_slot_build<4, 0>(ls, ws, lane);
-    lane_slot_build<5, 0>(ls, ws, lane);
-    lane_slot_build<5, 1>(ls, ws, lane);
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const int t = lane + 64 * q;
-        const bool on = t < 2 * 60;
-        const int tt = on ? t : 0, trv = tt < 60 ? 0 : 1, j = trv ? tt - 60 : tt;
-        // ply-5 ancestor: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
-        int pj = j, kk = 0;
-        if (trv == 1) { pj = j / 3; kk = j - pj * 3; }
-        uint32_t rec = lds_addr(&ws.npk[npk_offset(5) + (trv ? 60 : 0) + pj]);
-        uint32_t amask = (trv == 1 && kk > 0) ? 0u : ~0u, aforce = (trv == 1 && kk > 0) ? (uint32_t)(kk - 1) : 0u;
-        SCOPA_PIN(rec); SCOPA_PIN(amask); SCOPA_PIN(aforce);
-        ls.leaf_rec[q] = rec; ls.leaf_amask[q] = amask; ls.leaf_aforce[q] = aforce;
-        ls.dvis += on ? (trv == 0 ? 3u : 2u) : 0u;   // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
-        ls.tvis += on ? 2u : 0u;
-    }
-    SCOPA_PIN(ls.dvis); SCOPA_PIN(ls.tvis);
-    return ls;
-}
-
-// One ply of one traversal pair.
-template <int D>
-__device__ __forceinline__ void ply_step(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const double *__restrict__ s_sigcdf,
-                                         uint8_t *__restrict__ s_seen, unsigned int *__restrict__ s_cnt, NodeRegs &st, const LaneSlots &ls) {
+// One ply of NP traversal pairs (one or two: the pairs' dependent chains -- parent record, infoset, thresholds -- interleave).
+template <int D, int NP>
+__device__ __forceinline__ void ply_step(WaveScratch *ws, int lane, const uint16_t *__restrict__ s_inf, const double *__restrict__ s_sigcdf,
+                                         uint8_t *__restrict__ s_seen, unsigned int *__restrict__ s_cnt, NodeRegs (&st)[NP], const LaneSlots &ls) {
     constexpr int n = 4 - (D >> 1);
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
-    // what a lane gathers for its node before anything is stored: every LDS READ of the ply (both rounds of ply 5) is issued before
+    constexpr int NR = c0 + c1 > 64 ? 2 : 1;   // ply 5: 80 nodes, two rounds
+    // what a lane gathers for its node before anything is stored: every LDS READ of the ply (all rounds, all pairs) is issued before
     // the first LDS write or atomic, and none sits under a branch -- lanes without a node read slot 0 and are ignored afterwards
     struct Pre {
-        bool valid, is_trav;
-        int t, idx, In;
+        int idx, In;
         uint32_t k, thr0, thr1, thr2;
     };
-    auto gather = [&](auto round) -> Pre {
-        constexpr int ROUND = decltype(round)::value, S = D + ROUND;
-        Pre g;
-        g.t = 64 * ROUND + lane;
-        g.valid = g.t < c0 + c1;
-        g.is_trav = (D & 1) == (g.t < c0 ? 0 : 1);
-        g.idx = 0;
-        if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
-            constexpr int pn = 4 - ((D - 1) >> 1);
-            const uint32_t ppk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ls.plane4[S], (int)st.pk);
-            const uint32_t act = ((ppk >> 21) & ls.amask[S]) | ls.aforce[S];
-            g.idx = (int)((ppk & 1023u) * pn + act);
+    Pre g[NP][NR];
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const int S = D + r;
+            Pre &q = g[i][r];
+            q.idx = 0;
+            if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
+                constexpr int pn = 4 - ((D > 0 ? D - 1 : 0) >> 1);
+                const uint32_t ppk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ls.plane4[S], (int)st[i].pk);
+                const uint32_t act = ((ppk >> 21) & ls.amask[S]) | ls.aforce[S];
+                q.idx = (int)((ppk & 1023u) * pn + act);
+            }
+            q.In = s_inf[level_offset(D) + q.idx];
+            q.k = lds_read_u32(ls.kword[S] + (uint32_t)(i * sizeof(WaveScratch)));
+            // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
+            // most nodes are, instead of three
+            const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + q.In * kRow + 4);
+            q.thr0 = thr[0];
+            q.thr1 = n > 2 ? thr[1] : 0xFFFFFFFFu;
+            q.thr2 = n > 3 ? thr[2] : 0xFFFFFFFFu;
         }
-        g.In = s_inf[level_offset(D) + g.idx];
-        g.k = lds_read_u32(ls.kword[S]);
-        // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
-        // most nodes are, instead of three
-        const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + g.In * kRow + 4);
-        g.thr0 = thr[0];
-        g.thr1 = n > 2 ? thr[1] : 0xFFFFFFFFu;
-        g.thr2 = n > 3 ? thr[2] : 0xFFFFFFFFu;
-        return g;
-    };
-    NodeRegs mine = st;
-    auto finish = [&](const Pre &g) {
-        if (!g.valid) return;
-        const int a = (g.thr0 <= g.k) + (g.thr1 <= g.k) + (g.thr2 <= g.k);
-        if (g.is_trav) atomicAdd(&s_cnt[g.In], 1u);   // strategy_sum += sigma per traverser visit (mc_cfr.py:84); also marks the infoset seen
-        else s_seen[g.In] = 1;                        // benign race: every writer stores 1
-        const uint32_t pk = (uint32_t)g.idx | ((uint32_t)g.In << 10) | ((uint32_t)a << 21);
-        ws.npk[npk_offset(D) + g.t] = pk;             // the update step walks these records; the leaf stage reads ply 5's (80 nodes, two rounds)
-        if constexpr (D < 5) mine.pk = pk;
-    };
-    if constexpr (c0 + c1 > 64) {
-        const Pre g0 = gather(std::integral_constant<int, 0>{}), g1 = gather(std::integral_constant<int, 1>{});
-        finish(g0);
-        finish(g1);
-    } else {
-        const Pre g0 = gather(std::integral_constant<int, 0>{});
-        finish(g0);
-    }
-    st = mine;
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+#pragma unroll
+        for (int r = 0; r < NR; r++) {
+            const Pre &q = g[i][r];
+            const int t = 64 * r + lane;
+            if (t < c0 + c1) {
+                const int a = (q.thr0 <= q.k) + (q.thr1 <= q.k) + (q.thr2 <= q.k);
+                if ((D & 1) == (t < c0 ? 0 : 1)) atomicAdd(&s_cnt[q.In], 1u);   // strategy_sum += sigma per traverser visit (mc_cfr.py:84); also marks the infoset seen
+                else s_seen[q.In] = 1;                                          // benign race: every writer stores 1
+                const uint32_t pk = (uint32_t)q.idx | ((uint32_t)q.In << 10) | ((uint32_t)a << 21);
+                ws[i].npk[npk_offset(D) + t] = pk;    // the update step walks these records; the leaf stage reads ply 5's
+                if constexpr (D < 5) st[i].pk = pk;
+            }
+        }
     if constexpr (D == 5) wave_lds_sync();
 }
 
-// One traversal pair (both traversers of global traversal id b) on one wavefront: plies 0..5 level by level, plies 6-7, then the
-// regret update.  Regret increments go to `s_dR` with LDS float64 atomics, traverser visits to `s_cnt`.
-__device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
-                                          const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
-                                          unsigned int *__restrict__ s_cnt, uint32_t b, uint32_t iteration, uint32_t seed_lo,
-                                          uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const AncRegs &anc, const LaneSlots &ls,
-                                          const double *__restrict__ s_one) {
-    draw_pair(ws, lane, b, iteration, seed_lo, seed_hi);
-    // plies 0..5: one lane per unique node of the pair's two recursion trees (ply constants are compile-time); a ply's nodes
+#ifdef SCOPA_WALK_STAMPS   // development build only: shader-clock stamps of wavefront 0's stages, summed over its pairs (tests/tools/walk_stamps.py)
+__device__ unsigned long long g_walk_stamps[16];
+__device__ unsigned long long g_wave_clocks[3 * 16];   // whole pair loop per wavefront, workgroups 0, 100, 255; [2*16..] = wave's hardware id
+#define WALK_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) { g_walk_stamps[i] += now_ - t_prev_; } t_prev_ = now_; } while (0)
+#else
+#define WALK_STAMP(i) do { } while (0)
+#endif
+
+// NP traversal pairs (both traversers of global traversal ids b[0..NP)) on one wavefront: plies 0..5 level by level, plies 6-7, then
+// the regret update.  Regret increments go to `s_dR` with LDS float64 atomics, traverser visits to `s_cnt`.
+// A pair is ONE dependent chain -- about 26 LDS round trips and 300 vector instructions, 7 400 shader clocks measured, whatever the
+// load on the CU (tests/tools/walk_stamps.py): with 16 wavefronts per CU neither the LDS array nor the SIMDs were more than 70 % busy.
+// A wavefront that has two or more pairs to walk therefore takes them two at a time: every stage gathers for both, then stores for both.
+template <int NP>
+__device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
+                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
+                                           unsigned int *__restrict__ s_cnt, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo,
+                                           uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const AncRegs &anc, const LaneSlots &ls,
+                                           const double *__restrict__ s_one) {
+#ifdef SCOPA_WALK_STAMPS
+    const unsigned long long w_start_ = wall_clock64();
+    unsigned long long t_prev_ = clock64();
+#endif
+    draw_pairs<NP>(ws, lane, b, iteration, seed_lo, seed_hi);
+    WALK_STAMP(0);
+    // plies 0..5: one lane per unique node of a pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
-    NodeRegs st = {0u};
-    ply_step<0>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
-    ply_step<1>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
-    ply_step<2>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
-    ply_step<3>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
-    ply_step<4>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
-    ply_step<5>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls);
-    my_dvis += ls.dvis;   // the recursion tree has one shape: 291 + 172 decision visits and 2 x 120 terminal visits per pair
-    my_tvis += ls.tvis;
-    // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts.  120 leaves on 64 lanes: both of a lane's items are
-    // loaded before either is used (two dependent LDS round trips for the stage instead of four)
+    NodeRegs st[NP];
+#pragma unroll
+    for (int i = 0; i < NP; i++) st[i].pk = 0u;
+    ply_step<0, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(1);
+    ply_step<1, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(2);
+    ply_step<2, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(3);
+    ply_step<3, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(4);
+    ply_step<4, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(5);
+    ply_step<5, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(6);
+    my_dvis += NP * ls.dvis;   // the recursion tree has one shape: 291 + 172 decision visits and 2 x 120 terminal visits per pair
+    my_tvis += NP * ls.tvis;
+    // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts.  120 leaves on 64 lanes: all of a lane's items are
+    // loaded before any is used (two dependent LDS round trips for the stage)
     {
-        uint32_t ppk[2];
-        int tt[2], trv[2];
-        bool on[2];
+        uint32_t ppk[NP][2];
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const int t = lane + 64 * q;
-            on[q] = t < 2 * 60;
-            tt[q] = on[q] ? t : 0;
-            trv[q] = tt[q] < 60 ? 0 : 1;
-            ppk[q] = lds_read_u32(ls.leaf_rec[q]);
-        }
-        int idx6[2], I6[2], I7[2], pay[2];
+        for (int i = 0; i < NP; i++)
 #pragma unroll
-        for (int q = 0; q < 2; q++) {
-            const uint32_t act = ((ppk[q] >> 21) & ls.leaf_amask[q]) | ls.leaf_aforce[q];
-            idx6[q] = (int)((ppk[q] & 1023u) * 2 + act);   // = index of the ply-7 node and of the leaf as well
-            I6[q] = s_inf[level_offset(6) + idx6[q]];
-            I7[q] = s_inf[level_offset(7) + idx6[q]];
-            pay[q] = s_pay[idx6[q]];
-        }
+            for (int q = 0; q < 2; q++) ppk[i][q] = lds_read_u32(ls.leaf_rec[q] + (uint32_t)(i * sizeof(WaveScratch)));
+        int I6[NP][2], I7[NP][2], pay[NP][2];
 #pragma unroll
-        for (int q = 0; q < 2; q++)
-            if (on[q]) {
-                s_seen[trv[q] == 0 ? I7[q] : I6[q]] = 1;            // the opponent's node of the two (the traverser's is marked by its count)
-                atomicAdd(&s_cnt[trv[q] == 0 ? I6[q] : I7[q]], 1u); // the traverser's single-action node: strategy_sum += [1.0]
-                ws.p6[tt[q]] = (int8_t)(trv[q] == 0 ? pay[q] : -pay[q]);
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const uint32_t act = ((ppk[i][q] >> 21) & ls.leaf_amask[q]) | ls.leaf_aforce[q];
+                const int idx6 = (int)((ppk[i][q] & 1023u) * 2 + act);   // = index of the ply-7 node and of the leaf as well
+                I6[i][q] = s_inf[level_offset(6) + idx6];
+                I7[i][q] = s_inf[level_offset(7) + idx6];
+                pay[i][q] = s_pay[idx6];
+            }
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                const int t = lane + 64 * q;
+                if (t < 2 * 60) {
+                    const int trv = t < 60 ? 0 : 1;
+                    s_seen[trv == 0 ? I7[i][q] : I6[i][q]] = 1;            // the opponent's node of the two (the traverser's is marked by its count)
+                    atomicAdd(&s_cnt[trv == 0 ? I6[i][q] : I7[i][q]], 1u); // the traverser's single-action node: strategy_sum += [1.0]
+                    ws[i].p6[t] = (int8_t)(trv == 0 ? pay[i][q] : -pay[i][q]);
+                }
             }
     }
     wave_lds_sync();
+    WALK_STAMP(7);
     // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84).  The node's opponent reach and own sampling probability
     // are rebuilt here from its ancestors' records -- the product, root first, of sigma[ancestor infoset][action towards the node] over
     // the opponent's / the traverser's plies above it: the same factors in the same order as the reference's top-down updates
@@ -403,43 +397,114 @@ __device__ __forceinline__ void walk_pair(WaveScratch &ws, int lane, const uint1
         const int nX = 4 - m;
         const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
         const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
-        uint32_t rec[5];
         uint32_t ae[5];
 #pragma unroll
-        for (int q = 0; q < 5; q++) { ae[q] = (anc.w[q >> 1] >> (16 * (q & 1))) & 0xFFFFu; rec[q] = ws.npk[ae[q] == 0xFFFFu ? 0 : (ae[q] & 0xFFu)]; }   // slots < 86: one byte
-        const int IX = (int)((ws.npk[anc.w[2] >> 16] >> 10) & 2047u);
-        const int8_t *p6 = ws.p6 + trav * 60;
-        int pv[4];
+        for (int q = 0; q < 5; q++) ae[q] = (anc.w[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        uint32_t rec[NP][5];
+        int IX[NP], pv[NP][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) pv[i] = p6[base + ((i < nX ? i : nX - 1) + 1) * stride];
-        double fq[5];
+        for (int i = 0; i < NP; i++) {
 #pragma unroll
-        for (int q = 0; q < 5; q++) {   // plies at or below the node's own: the factor 1.0, read from LDS like the others (one select, on the address)
-            const int forced = ae[q] >> 8;
-            const int act = forced ? forced - 1 : (int)(rec[q] >> 21);
-            const double *f = ae[q] != 0xFFFFu ? s_sigcdf + (int)((rec[q] >> 10) & 2047u) * kRow + act : s_one;
-            fq[q] = *f;
+            for (int q = 0; q < 5; q++) rec[i][q] = ws[i].npk[ae[q] == 0xFFFFu ? 0 : (ae[q] & 0xFFu)];   // slots < 86: one byte
+            IX[i] = (int)((ws[i].npk[anc.w[2] >> 16] >> 10) & 2047u);
+            const int8_t *p6 = ws[i].p6 + trav * 60;
+#pragma unroll
+            for (int c = 0; c < 4; c++) pv[i][c] = p6[base + ((c < nX ? c : nX - 1) + 1) * stride];
         }
-        const double2 s01 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow), s23 = *reinterpret_cast<const double2 *>(s_sigcdf + IX * kRow + 2);
-        const double sg[4] = {s01.x, s01.y, s23.x, s23.y};
-        // even plies are traverser 0's, odd plies traverser 1's: two chains, root first (1.0 * x = x, x * 1.0 = x: the reference's products)
-        const double even = (fq[0] * fq[2]) * fq[4], odd = fq[1] * fq[3];
-        const double sX = trav == 0 ? even : odd, rX = trav == 0 ? odd : even;
-        const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
-        double cfv[4], v = 0.0;
+        double fq[NP][5], sg[NP][4];
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            cfv[i] = 0.5 * (double)pv[i];
-            const double t = fma(sg[i], cfv[i], v);          // np.dot on this numpy build: an fma chain (see oracle)
-            v = i < nX ? t : v;
+        for (int i = 0; i < NP; i++) {
+#pragma unroll
+            for (int q = 0; q < 5; q++) {   // plies at or below the node's own: the factor 1.0, read from LDS like the others (one select, on the address)
+                const int forced = ae[q] >> 8;
+                const int act = forced ? forced - 1 : (int)(rec[i][q] >> 21);
+                const double *f = ae[q] != 0xFFFFu ? s_sigcdf + (int)((rec[i][q] >> 10) & 2047u) * kRow + act : s_one;
+                fq[i][q] = *f;
+            }
+            const double2 s01 = *reinterpret_cast<const double2 *>(s_sigcdf + IX[i] * kRow), s23 = *reinterpret_cast<const double2 *>(s_sigcdf + IX[i] * kRow + 2);
+            sg[i][0] = s01.x; sg[i][1] = s01.y; sg[i][2] = s23.x; sg[i][3] = s23.y;
         }
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-            const double delta = w * (cfv[i] - v);
-            if (i < nX && delta != 0.0) atomicAdd(&s_dR[IX * 4 + i], delta);
+        for (int i = 0; i < NP; i++) {
+            // even plies are traverser 0's, odd plies traverser 1's: two chains, root first (1.0 * x = x, x * 1.0 = x: the reference's products)
+            const double even = (fq[i][0] * fq[i][2]) * fq[i][4], odd = fq[i][1] * fq[i][3];
+            const double sX = trav == 0 ? even : odd, rX = trav == 0 ? odd : even;
+            const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
+            double cfv[4], v = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                cfv[c] = 0.5 * (double)pv[i][c];
+                const double t = fma(sg[i][c], cfv[c], v);       // np.dot on this numpy build: an fma chain (see oracle)
+                v = c < nX ? t : v;
+            }
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const double delta = w * (cfv[c] - v);
+                if (c < nX && delta != 0.0) atomicAdd(&s_dR[IX[i] * 4 + c], delta);
+            }
         }
     }
-    wave_lds_sync();  // the next pair overwrites this wave's scratch
+    wave_lds_sync();  // the next pairs overwrite this wave's scratch
+    WALK_STAMP(8);
+#ifdef SCOPA_WALK_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0) { g_walk_stamps[15] += NP; g_walk_stamps[14] += wall_clock64() - w_start_; }
+#endif
+}
+
+// the lane table of a context (one launch of 64 threads, at the first traversal launch)
+__global__ void __launch_bounds__(64) k_lane_table(uint32_t *__restrict__ g_tab) {
+    const int lane = threadIdx.x;
+    uint32_t w[kLaneWords];
+    for (int i = 0; i < kLaneWords; i++) w[i] = 0u;
+    uint32_t dvis = 0u, tvis = 0u;
+    lane_slot_build<0, 0>(w, dvis, lane);
+    lane_slot_build<1, 0>(w, dvis, lane);
+    lane_slot_build<2, 0>(w, dvis, lane);
+    lane_slot_build<3, 0>(w, dvis, lane);
+    lane_slot_build<4, 0>(w, dvis, lane);
+    lane_slot_build<5, 0>(w, dvis, lane);
+    lane_slot_build<5, 1>(w, dvis, lane);
+    for (int q = 0; q < 2; q++) {
+        const int t = lane + 64 * q;
+        const bool on = t < 2 * 60;
+        const int tt = on ? t : 0, trv = tt < 60 ? 0 : 1, j = trv ? tt - 60 : tt;
+        // ply-5 ancestor: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
+        int pj = j, kk = 0;
+        if (trv == 1) { pj = j / 3; kk = j - pj * 3; }
+        w[kLwLeafRec + q] = (uint32_t)(offsetof(WaveScratch, npk) + 4 * (npk_offset(5) + (trv ? 60 : 0) + pj));
+        w[kLwLeafAmask + q] = (trv == 1 && kk > 0) ? 0u : ~0u;
+        w[kLwLeafAforce + q] = (trv == 1 && kk > 0) ? (uint32_t)(kk - 1) : 0u;
+        dvis += on ? (trv == 0 ? 3u : 2u) : 0u;   // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
+        tvis += on ? 2u : 0u;
+    }
+    w[kLwDvis] = dvis; w[kLwTvis] = tvis;
+    uint16_t row[kAncRow] = {0, 0, 0, 0, 0, 0};
+    if (lane < 2 * kUpd) anc_build(lane, row);
+    for (int i = 0; i < 3; i++) w[kLwAnc + i] = (uint32_t)row[2 * i] | ((uint32_t)row[2 * i + 1] << 16);
+    for (int i = 0; i < kLaneWords; i++) g_tab[((i >> 2) * 64 + lane) * 4 + (i & 3)] = w[i];
+}
+
+struct LaneVecs { uint4 v[kLaneVecs]; };
+__device__ __forceinline__ LaneVecs lane_table_load(const uint4 *__restrict__ g_tab, int lane) {   // issue early, unpack after the prologue
+    LaneVecs r;
+#pragma unroll
+    for (int f = 0; f < kLaneVecs; f++) r.v[f] = g_tab[f * 64 + lane];
+    return r;
+}
+__device__ __forceinline__ void lane_table_unpack(const LaneVecs &r, uint32_t ws_base, LaneSlots &ls, AncRegs &anc) {
+    uint32_t w[kLaneWords];
+#pragma unroll
+    for (int f = 0; f < kLaneVecs; f++) { w[4 * f] = r.v[f].x; w[4 * f + 1] = r.v[f].y; w[4 * f + 2] = r.v[f].z; w[4 * f + 3] = r.v[f].w; }
+    ls.plane4[0] = ls.amask[0] = ls.aforce[0] = 0u;
+#pragma unroll
+    for (int S = 1; S < 7; S++) { ls.plane4[S] = w[kLwPlane + S - 1]; ls.amask[S] = w[kLwAmask + S - 1]; ls.aforce[S] = w[kLwAforce + S - 1]; }
+#pragma unroll
+    for (int S = 0; S < 7; S++) ls.kword[S] = ws_base + w[kLwKword + S];
+#pragma unroll
+    for (int q = 0; q < 2; q++) { ls.leaf_rec[q] = ws_base + w[kLwLeafRec + q]; ls.leaf_amask[q] = w[kLwLeafAmask + q]; ls.leaf_aforce[q] = w[kLwLeafAforce + q]; }
+    ls.dvis = w[kLwDvis]; ls.tvis = w[kLwTvis];
+#pragma unroll
+    for (int i = 0; i < 3; i++) anc.w[i] = w[kLwAnc + i];
 }
 
 // Where a launch leaves its result.  A workgroup's partial delta table (regret increments + traverser-visit counts, LDS) is added
@@ -456,25 +521,31 @@ __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_groups,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
-                 unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock) {
+                 unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock,
+                 const uint4 *__restrict__ g_lane_tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
-    __shared__ uint16_t s_anc[2 * kUpd * kAncRow];
     __shared__ double s_one[1];
+    __shared__ uint32_t s_next[1];   // next pair of this workgroup not taken yet
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows)
     double *s_dR = s_sigcdf + (size_t)I * kRow;                                  // [I][4] (16-byte aligned)
-    WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup]
-    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));  // [I] traverser visits
+    WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup][2 pairs in flight]
+    unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + 2 * (blockDim.x >> 6));  // [I] traverser visits
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));  // [1653] (+pad)
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_inf + 1656);                    // [576]
     uint8_t *s_seen = reinterpret_cast<uint8_t *>(s_pay + kTerminal);            // [I]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
-    if (tid < 2 * kUpd) anc_build(tid, s_anc + tid * kAncRow);
-    if (tid == 0) s_one[0] = 1.0;
+    const LaneVecs lane_words = lane_table_load(g_lane_tab, tid & 63);
+    if (tid == 0) {
+        s_one[0] = 1.0;
+        const uint32_t per_wg = (nb + gridDim.x - 1) / gridDim.x, W = blockDim.x >> 6;
+        const uint32_t first = blockIdx.x * per_wg, count = first < nb ? (nb - first < per_wg ? nb - first : per_wg) : 0u;
+        s_next[0] = count >= 2 * W ? 2 * W : W;   // behind the static first takes (main loop)
+    }
     // ---- prologue: this iteration's frozen strategy rows and the tree maps into LDS ----------------------------------
     // All global loads are issued before anything waits on one of them (one memory round trip for the whole prologue),
     // the LDS zeroing runs underneath them, then the loaded pieces are stored.
@@ -513,13 +584,45 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     __syncthreads();
     const unsigned long long t_pro = wall_clock64();
 
-    WaveScratch &ws = s_wave[wave];
-    const AncRegs anc = anc_load(s_anc, lane);
-    const LaneSlots ls = lane_slots_build(ws, lane);
+    WaveScratch *ws = s_wave + 2 * wave;
+    AncRegs anc;
+    LaneSlots ls;
+    lane_table_unpack(lane_words, lds_addr(ws), ls, anc);
     unsigned int my_dvis = 0, my_tvis = 0;
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
-    for (uint32_t pg = blockIdx.x * (uint32_t)n_waves + (uint32_t)wave; pg < nb; pg += gridDim.x * (uint32_t)n_waves) {
-        walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, b0 + pg, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+    // The workgroup owns pairs [first, first + count); its wavefronts TAKE them from a counter in LDS instead of owning a fixed share:
+    // the SIMD's issue arbiter favours its oldest wavefront, so with equal shares the first wave of each SIMD finished its 16 pairs
+    // (B = 65 536) in 79 k clocks and the fourth in 130 k, and the workgroup waited for the fourth (tests/tools/walk_stamps.py).
+    // Which wavefront walks a pair does not matter: its draws are keyed by the pair's global id.
+    {
+#ifdef SCOPA_WALK_STAMPS
+        const unsigned long long loop_start_ = clock64();
+#endif
+        const uint32_t per_wg = (nb + gridDim.x - 1) / gridDim.x;
+        const uint32_t first = blockIdx.x * per_wg, count = first < nb ? (nb - first < per_wg ? nb - first : per_wg) : 0u;
+        const uint32_t W = (uint32_t)n_waves;
+        // the first take needs no counter: two pairs per wavefront if the workgroup has that many, else one (s_next starts behind them)
+        const bool start_two = count >= 2 * W;
+        uint32_t c = start_two ? 2 * (uint32_t)wave : (uint32_t)wave, g = start_two ? 2u : 1u;
+        for (;;) {
+            if (g == 2 && c + 1 < count) {      // two pairs in flight
+                const uint32_t two[2] = {b0 + first + c, b0 + first + c + 1};
+                walk_pairs<2>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, two, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+            } else if (c < count) {
+                const uint32_t one[1] = {b0 + first + c};
+                walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, one, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+            }
+            if (count <= W || c + g >= count) break;   // nothing was left behind the static takes / the counter has run out
+            g = count - c > 4 * W ? 2u : 1u;             // single pairs towards the end: the last take bounds the imbalance
+            uint32_t got = 0;
+            if (lane == 0) got = atomicAdd(s_next, g);
+            c = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+            if (c >= count) break;
+        }
+#ifdef SCOPA_WALK_STAMPS
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) g_wave_clocks[(blockIdx.x == 0 ? 0 : 16) + wave] += clock64() - loop_start_;
+        if (lane == 0 && blockIdx.x == 0) { unsigned int hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_wave_clocks[32 + wave] = hw; }
+#endif
     }
     __syncthreads();
 
@@ -564,12 +667,11 @@ __global__ void __launch_bounds__(1024)
 k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff, const uint64_t *__restrict__ g_key,
               double *__restrict__ g_regret, double *__restrict__ g_strat, const int32_t *__restrict__ g_meta, uint32_t *__restrict__ g_visit,
               unsigned long long *__restrict__ g_counters, uint32_t seed_lo, uint32_t seed_hi, uint32_t iter0, uint32_t n_iters,
-              uint32_t batch) {
+              uint32_t batch, const uint4 *__restrict__ g_lane_tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
-    __shared__ uint16_t s_anc[2 * kUpd * kAncRow];
     __shared__ double s_one[1];
-    if (threadIdx.x < 2 * kUpd) anc_build(threadIdx.x, s_anc + threadIdx.x * kAncRow);
+    const LaneVecs lane_words = lane_table_load(g_lane_tab, threadIdx.x & 63);
     if (threadIdx.x == 0) s_one[0] = 1.0;
     {
         const size_t deal = blockIdx.x;
@@ -591,9 +693,10 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
     __syncthreads();
-    WaveScratch &ws = s_wave[wave];
-    const AncRegs anc = anc_load(s_anc, lane);
-    const LaneSlots ls = lane_slots_build(ws, lane);
+    WaveScratch *ws = s_wave + wave;
+    AncRegs anc;
+    LaneSlots ls;
+    lane_table_unpack(lane_words, lds_addr(ws), ls, anc);
     unsigned int my_dvis = 0, my_tvis = 0;
     for (uint32_t it = 0; it < n_iters; it++) {
         for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
@@ -605,8 +708,10 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
             for (int c = 0; c < 4; c++) { s_sigcdf[r * kRow + c] = sg[c]; reinterpret_cast<uint32_t *>(s_sigcdf + r * kRow + 4)[c] = thr[c]; }
         }
         __syncthreads();
-        for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves)
-            walk_pair(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, pg, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+        for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves) {
+            const uint32_t one[1] = {pg};
+            walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, one, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+        }
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
             const unsigned int c = s_cnt[r];
@@ -849,11 +954,20 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
 
 static size_t traverse_lds_bytes(int n_infosets, int waves) {
     size_t b = (size_t)n_infosets * (kRow + 4) * sizeof(double);  // sigma|threshold rows, delta table
-    b += (size_t)waves * sizeof(WaveScratch);                  // per-wavefront records
+    b += (size_t)waves * 2 * sizeof(WaveScratch);              // per-wavefront records, two pairs in flight
     b += (((size_t)n_infosets * 4 + 15) & ~(size_t)15);        // visit counts
     b += 1656 * 2 + 576;                                       // node -> infoset, leaf payoffs
     b += (size_t)n_infosets;                                   // seen flags
     return (b + 15) & ~(size_t)15;
+}
+
+// the context's lane table (k_lane_table), built on its stream before the first launch that reads it
+static int32_t ensure_lane_table(scopa_ctx *ctx) {
+    if (ctx->d_lane_tab) return SCOPA_OK;
+    SC_HIP(ctx, hipMalloc(&ctx->d_lane_tab, (size_t)kLaneWords * 64 * sizeof(uint32_t)));
+    hipLaunchKernelGGL(k_lane_table, dim3(1), dim3(64), 0, ctx->stream, ctx->d_lane_tab);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
 }
 
 // One traversal launch of `nb` traversal pairs [b0, b0 + nb) of iteration `iteration` against the rows in d_sigcdf; the launch
@@ -871,6 +985,7 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     const uint32_t grid = n_passes < (uint32_t)ctx->n_cus ? n_passes : (uint32_t)ctx->n_cus;
     SC_REQUIRE(ctx, grid <= 1024u, SCOPA_ELIMIT, "mccfr traverse: more than 1024 compute units");
     static_assert(kClockStride >= 4 * 512, "clock sample stride");
+    if (int32_t rc = ensure_lane_table(ctx)) return rc;
     if (!ctx->sigcdf_valid) {  // tables were changed by another entry point since the last apply
         hipLaunchKernelGGL(k_mccfr_prepare, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
@@ -884,11 +999,11 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     if (sampled)
         hipExtLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ev0, ev1, 0, ctx->d_infoset, ctx->d_payoff,
                               ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock);
+                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab);
     else
         hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                            ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock);
+                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -906,8 +1021,9 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
     while (waves > 1 && need(waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
     SC_REQUIRE(ctx, need(waves) + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
     SC_LDS_ATTR(ctx, scopa::kLdsMulti, k_mccfr_multi, ctx->lds_limit - kStaticLds);
+    if (int32_t rc = ensure_lane_table(ctx)) return rc;
     hipLaunchKernelGGL(k_mccfr_multi, dim3(n_deals), dim3(waves * 64), need(waves), ctx->stream, d_infoset, d_payoff, d_key, d_regret, d_strat,
-                       d_meta, d_visit, d_counters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, n_iters, batch);
+                       d_meta, d_visit, d_counters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, n_iters, batch, (const uint4 *)ctx->d_lane_tab);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -1062,3 +1178,14 @@ int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_unif
 }
 
 }  // extern "C"
+
+#ifdef SCOPA_WALK_STAMPS
+extern "C" int scopa_debug_wave_clocks(unsigned long long *out48) {
+    return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_wave_clocks), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -1;
+}
+extern "C" int scopa_debug_walk_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_walk_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_walk_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
