@@ -173,7 +173,10 @@ def test_mccfr_batched_delta_vs_reference_sample(ctx, sl, golden, case):
     assert set(np.flatnonzero(seen)) == set(idx)                 # exactly the reference's dict keys exist afterwards
 
 
-@pytest.mark.parametrize("batch", [1, 7, 64, 1000])
+# batches beyond 4096 exercise how a workgroup's wavefronts take pairs (scopa_mccfr.hip, main loop): 4101 = 16 wavefronts x 256
+# workgroups + a ragged last workgroup; 5000 = between one and two pairs per wavefront (single takes from the counter); 10240 = two pairs
+# in flight, then single takes; 17923 = more than four pairs per wavefront (double takes, single ones towards the end, ragged tail)
+@pytest.mark.parametrize("batch", [1, 7, 64, 1000, 4101, 5000, 10240, 17923])
 def test_mccfr_batched_delta_vs_oracle(ctx, sl, oracle, batch):
     """One iteration's deltas from a non-trivial frozen table: regret deltas to 1e-12, visit counts EXACT."""
     t = oracle.Tree(seed=42)
