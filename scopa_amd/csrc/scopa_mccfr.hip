@@ -97,6 +97,10 @@ constexpr int kRow = 6;   // doubles per frozen row in LDS: sigma[4] | 4 x uint3
                            // -> 2^31, padding = ~0).  48-byte rows start at 16 different bank alignments (64-byte rows could only start
                            // at 4: every random-row gather was >= 4-way bank-conflicted, SQ_LDS_BANK_CONFLICT = 47 % of LDS cycles)
 constexpr int kUpd = 26;  // traverser nodes with > 1 legal action per task: 1 + 5 + 20
+// visits of one traversal pair: the recursion tree has one shape (nodes per ply 1,5,5,20,20,60,60,120 for traverser 0 and
+// 1,1,5,5,20,20,60,60 for traverser 1; every ply-7 node has one leaf below it)
+constexpr unsigned int kPairDecisionVisits = (1 + 5 + 5 + 20 + 20 + 60 + 60 + 120) + (1 + 1 + 5 + 5 + 20 + 20 + 60 + 60), kPairTerminalVisits = 120 + 120;
+static_assert(kPairDecisionVisits == 463, "291 + 172");
 
 }  // namespace
 
@@ -213,7 +217,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(
 __device__ __forceinline__ uint32_t lds_read_u32(uint32_t a) { return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a; }
 
 // Everything about a lane's node SLOT that does not depend on the pair being walked -- which lane holds the parent, whether the action
-// towards the node is forced by a re-expansion, where its draw word lies, how many visits the lane accounts for, the update lane's
+// towards the node is forced by a re-expansion, where its draw word lies, the update lane's
 // ancestor row -- is the same for every wavefront of every launch: k_lane_table computes it ONCE per context into a 9 KB table and a
 // wavefront loads its 36 words per lane under the prologue's other loads.  (Derived in the kernel it was ~300 VALU instructions per
 // wavefront before the first pair -- as much as a whole pair costs -- and, left to the compiler, 33 instead of 17 per ply and slot
@@ -226,14 +230,13 @@ struct LaneSlots {
     uint32_t aforce[7];
     uint32_t kword[7];    // LDS address of the slot's draw word in the wave's scratch (table: offset within WaveScratch)
     uint32_t leaf_rec[2], leaf_amask[2], leaf_aforce[2];   // the same for a leaf: LDS address of its ply-5 ancestor's record
-    uint32_t dvis, tvis;  // decision / terminal visits this lane's slots stand for, per pair
 };
 // table layout: word w of lane l at [w / 4][l] . (w % 4), i.e. 9 x 64 uint4 -- a wavefront reads 9 coalesced 1 KB lines
 constexpr int kLaneWords = 36, kLaneVecs = kLaneWords / 4;
-constexpr int kLwPlane = 0, kLwAmask = 6, kLwAforce = 12, kLwKword = 18, kLwLeafRec = 25, kLwLeafAmask = 27, kLwLeafAforce = 29, kLwDvis = 31, kLwTvis = 32, kLwAnc = 33;
+constexpr int kLwPlane = 0, kLwAmask = 6, kLwAforce = 12, kLwKword = 18, kLwLeafRec = 25, kLwLeafAmask = 27, kLwLeafAforce = 29, kLwAnc = 31;   // 34, 35 unused
 
 template <int D, int ROUND>
-__device__ __forceinline__ void lane_slot_build(uint32_t *w, uint32_t &dvis, int lane) {
+__device__ __forceinline__ void lane_slot_build(uint32_t *w, int lane) {
     constexpr int S = D + ROUND;
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
     const int t = lane + 64 * ROUND;
@@ -257,7 +260,6 @@ __device__ __forceinline__ void lane_slot_build(uint32_t *w, uint32_t &dvis, int
     const uint32_t koff = trav == 0 ? (is_trav ? offsetof(WaveScratch, ky0) : offsetof(WaveScratch, kx0))
                                     : (is_trav ? offsetof(WaveScratch, ky1) : offsetof(WaveScratch, kx1));
     w[kLwKword + S] = koff + 4u * (uint32_t)blk;
-    dvis += valid ? 1u : 0u;
 }
 
 // One ply of NP traversal pairs (one or two: the pairs' dependent chains -- parent record, infoset, thresholds -- interleave).
@@ -331,7 +333,7 @@ template <int NP>
 __device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
                                            const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
                                            unsigned int *__restrict__ s_cnt, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo,
-                                           uint32_t seed_hi, unsigned int &my_dvis, unsigned int &my_tvis, const AncRegs &anc, const LaneSlots &ls,
+                                           uint32_t seed_hi, unsigned int &my_pairs, const AncRegs &anc, const LaneSlots &ls,
                                            const double *__restrict__ s_one) {
 #ifdef SCOPA_WALK_STAMPS
     const unsigned long long w_start_ = wall_clock64();
@@ -350,8 +352,7 @@ __device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint
     ply_step<3, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(4);
     ply_step<4, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(5);
     ply_step<5, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(6);
-    my_dvis += NP * ls.dvis;   // the recursion tree has one shape: 291 + 172 decision visits and 2 x 120 terminal visits per pair
-    my_tvis += NP * ls.tvis;
+    my_pairs += NP;   // wave-uniform; the recursion tree has one shape: kPairDecisionVisits + kPairTerminalVisits per pair
     // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts.  120 leaves on 64 lanes: all of a lane's items are
     // loaded before any is used (two dependent LDS round trips for the stage)
     {
@@ -456,14 +457,13 @@ __global__ void __launch_bounds__(64) k_lane_table(uint32_t *__restrict__ g_tab)
     const int lane = threadIdx.x;
     uint32_t w[kLaneWords];
     for (int i = 0; i < kLaneWords; i++) w[i] = 0u;
-    uint32_t dvis = 0u, tvis = 0u;
-    lane_slot_build<0, 0>(w, dvis, lane);
-    lane_slot_build<1, 0>(w, dvis, lane);
-    lane_slot_build<2, 0>(w, dvis, lane);
-    lane_slot_build<3, 0>(w, dvis, lane);
-    lane_slot_build<4, 0>(w, dvis, lane);
-    lane_slot_build<5, 0>(w, dvis, lane);
-    lane_slot_build<5, 1>(w, dvis, lane);
+    lane_slot_build<0, 0>(w, lane);
+    lane_slot_build<1, 0>(w, lane);
+    lane_slot_build<2, 0>(w, lane);
+    lane_slot_build<3, 0>(w, lane);
+    lane_slot_build<4, 0>(w, lane);
+    lane_slot_build<5, 0>(w, lane);
+    lane_slot_build<5, 1>(w, lane);
     for (int q = 0; q < 2; q++) {
         const int t = lane + 64 * q;
         const bool on = t < 2 * 60;
@@ -474,10 +474,7 @@ __global__ void __launch_bounds__(64) k_lane_table(uint32_t *__restrict__ g_tab)
         w[kLwLeafRec + q] = (uint32_t)(offsetof(WaveScratch, npk) + 4 * (npk_offset(5) + (trv ? 60 : 0) + pj));
         w[kLwLeafAmask + q] = (trv == 1 && kk > 0) ? 0u : ~0u;
         w[kLwLeafAforce + q] = (trv == 1 && kk > 0) ? (uint32_t)(kk - 1) : 0u;
-        dvis += on ? (trv == 0 ? 3u : 2u) : 0u;   // ply 6 + ply 7 (two recursion nodes under a traverser ply 6)
-        tvis += on ? 2u : 0u;
     }
-    w[kLwDvis] = dvis; w[kLwTvis] = tvis;
     uint16_t row[kAncRow] = {0, 0, 0, 0, 0, 0};
     if (lane < 2 * kUpd) anc_build(lane, row);
     for (int i = 0; i < 3; i++) w[kLwAnc + i] = (uint32_t)row[2 * i] | ((uint32_t)row[2 * i + 1] << 16);
@@ -502,7 +499,6 @@ __device__ __forceinline__ void lane_table_unpack(const LaneVecs &r, uint32_t ws
     for (int S = 0; S < 7; S++) ls.kword[S] = ws_base + w[kLwKword + S];
 #pragma unroll
     for (int q = 0; q < 2; q++) { ls.leaf_rec[q] = ws_base + w[kLwLeafRec + q]; ls.leaf_amask[q] = w[kLwLeafAmask + q]; ls.leaf_aforce[q] = w[kLwLeafAforce + q]; }
-    ls.dvis = w[kLwDvis]; ls.tvis = w[kLwTvis];
 #pragma unroll
     for (int i = 0; i < 3; i++) anc.w[i] = w[kLwAnc + i];
 }
@@ -588,7 +584,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     AncRegs anc;
     LaneSlots ls;
     lane_table_unpack(lane_words, lds_addr(ws), ls, anc);
-    unsigned int my_dvis = 0, my_tvis = 0;
+    unsigned int my_pairs = 0;   // pairs this wavefront walked
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     // The workgroup owns pairs [first, first + count); its wavefronts TAKE them from a counter in LDS instead of owning a fixed share:
     // the SIMD's issue arbiter favours its oldest wavefront, so with equal shares the first wave of each SIMD finished its 16 pairs
@@ -607,10 +603,10 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         for (;;) {
             if (g == 2 && c + 1 < count) {      // two pairs in flight
                 const uint32_t two[2] = {b0 + first + c, b0 + first + c + 1};
-                walk_pairs<2>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, two, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+                walk_pairs<2>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, two, iteration, seed_lo, seed_hi, my_pairs, anc, ls, s_one);
             } else if (c < count) {
                 const uint32_t one[1] = {b0 + first + c};
-                walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, one, iteration, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+                walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, one, iteration, seed_lo, seed_hi, my_pairs, anc, ls, s_one);
             }
             if (count <= W || c + g >= count) break;   // nothing was left behind the static takes / the counter has run out
             g = count - c > 4 * W ? 2u : 1u;             // single pairs towards the end: the last take bounds the imbalance
@@ -644,13 +640,9 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         for (int r = tid + 2 * nthr; r < I; r += nthr)                       // narrow workgroups (many infosets): the rest, plainly
             if ((s_seen[r] || s_cnt[r]) && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
     }
-    // exact visit counters: wave reduce -> LDS -> this workgroup's own slot (a no-return atomic on a word nobody else adds to;
+    // exact visit counters: pairs walked per wavefront x the visits of a pair -> LDS -> this workgroup's own slot (a no-return atomic on a word nobody else adds to;
     // scopa_counters() adds the slots up
-    for (int off = 32; off > 0; off >>= 1) {
-        my_dvis += __shfl_down(my_dvis, off);
-        my_tvis += __shfl_down(my_tvis, off);
-    }
-    if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
+    if (lane == 0) { atomicAdd(&s_vis[0], my_pairs * kPairDecisionVisits); atomicAdd(&s_vis[1], my_pairs * kPairTerminalVisits); }
     __syncthreads();
     if (tid < 2) atomicAdd(&g_wg_counts[blockIdx.x * 2 + tid], (unsigned long long)s_vis[tid]);   // its own slot: no contention, nothing to wait for
     if (g_clock && tid == 0) {   // sampled launches: this workgroup's phase stamps (start | prologue done | walks done | end)
@@ -697,7 +689,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     AncRegs anc;
     LaneSlots ls;
     lane_table_unpack(lane_words, lds_addr(ws), ls, anc);
-    unsigned int my_dvis = 0, my_tvis = 0;
+    unsigned int my_pairs = 0;   // pairs this wavefront walked
     for (uint32_t it = 0; it < n_iters; it++) {
         for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
             const int n = (int)((g_key[r] >> 1) & 7);
@@ -710,7 +702,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves) {
             const uint32_t one[1] = {pg};
-            walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, one, iter0 + it, seed_lo, seed_hi, my_dvis, my_tvis, anc, ls, s_one);
+            walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, one, iter0 + it, seed_lo, seed_hi, my_pairs, anc, ls, s_one);
         }
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
@@ -726,8 +718,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     }
     for (int i = tid; i < I * 4; i += blockDim.x) g_regret[i] = s_R[i];
     for (int r = tid; r < I; r += blockDim.x) if (s_seen[r] && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
-    for (int off = 32; off > 0; off >>= 1) { my_dvis += __shfl_down(my_dvis, off); my_tvis += __shfl_down(my_tvis, off); }
-    if (lane == 0) { atomicAdd(&s_vis[0], my_dvis); atomicAdd(&s_vis[1], my_tvis); }
+    if (lane == 0) { atomicAdd(&s_vis[0], my_pairs * kPairDecisionVisits); atomicAdd(&s_vis[1], my_pairs * kPairTerminalVisits); }
     __syncthreads();
     if (tid < 2) g_counters[tid] += s_vis[tid];
 }
