@@ -338,9 +338,11 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                  long long capacity, long long write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
                  uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
     extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_next[1];                                               // next traversal of this workgroup not taken yet
     float *s_w = reinterpret_cast<float *>(smem);                           // [2][kNetFloats]
     SdWave *s_wave = reinterpret_cast<SdWave *>(s_w + 2 * kNetFloats);      // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
+    if (tid == 0) s_next[0] = n_waves;
     for (int i = tid; i < 2 * kNetFloats / 4; i += blockDim.x)
         reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_weights)[i];
     __syncthreads();
@@ -386,7 +388,14 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
     }
     SdWave &ws = s_wave[wave];
 
-    for (int tb = blockIdx.x * n_waves + wave; tb < batch; tb += gridDim.x * n_waves) {
+    // The workgroup owns traversals [first, first + count) and its wavefronts TAKE them from a counter in LDS (the first one is
+    // static): 10 wavefronts share 4 SIMDs unevenly and the SIMD's arbiter favours its oldest wavefront, so equal shares would leave
+    // the workgroup waiting for its slowest wavefront (scopa_mccfr.hip, main loop, has the measurement).  Which wavefront walks a
+    // traversal does not matter: draws and memory-row positions are keyed by the traversal id.
+    const int per_wg = (batch + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int first = (int)blockIdx.x * per_wg, count = first < batch ? (batch - first < per_wg ? batch - first : per_wg) : 0;
+    for (int c = wave; c < count;) {
+        const int tb = first + c;
         if (lane == 0) ws.idx[0][0] = 0;
         sd_sync();
         int width = 1;
@@ -604,6 +613,9 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
         }
         if (lane == 0) root_values[tb] = ws.val[cur][0];
         sd_sync();
+        int got = 0;
+        if (lane == 0) got = atomicAdd(s_next, 1);
+        c = __builtin_amdgcn_readfirstlane(got);
     }
 }
 
@@ -618,13 +630,13 @@ extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser,
     if (!batch) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
     // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 10, the kernel's launch bound)
-    int waves = (int)(((size_t)ctx->lds_limit - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
+    int waves = (int)(((size_t)ctx->lds_limit - 64 - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
     waves = waves > 10 ? 10 : waves;
     SC_REQUIRE(ctx, waves >= 8, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (the weight staging assumes >= 512 threads)");
     const int threads = waves * 64;
     const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
-    SC_REQUIRE(ctx, lds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
-    SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse, ctx->lds_limit);
+    SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
+    SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse, ctx->lds_limit - 64);   // 64: the kernel's static LDS (s_next), beside the dynamic part
     const int passes = (batch + waves - 1) / waves;
     const int grid = passes < ctx->n_cus ? passes : ctx->n_cus;
     hipLaunchKernelGGL(k_sdcfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_states, ctx->d_payoff, d_weights, (int)traverser,
