@@ -45,7 +45,7 @@ struct scopa_ctx {
     double *d_delta = nullptr;        // buffer in use (internal or caller-bound)
     double *d_delta_own = nullptr;    // the internal one
     double *d_scratch = nullptr;  // root values / uniforms staging
-    double *d_sigcdf = nullptr;   // [kDecision][8] sigma | cdf rows of the frozen regret table
+    double *d_sigcdf = nullptr;   // [kDecision][6] sigma | threshold rows of the frozen regret table (48 bytes: the layout the traversal keeps in LDS)
     bool sigcdf_valid = false;    // false whenever d_regret changed outside k_mccfr_apply
     double *d_groups = nullptr;   // [8 group tables][5][kDecision] float64: where traversal launches add their deltas (scopa_mccfr.hip); all-zero between launches' applies
     unsigned long long *d_clock = nullptr;   // [2048 sampled launches][512 workgroups][4] phase stamps on the 100 MHz device clock (allocated by scopa_prof_enable)

@@ -106,7 +106,7 @@ int32_t scopa_ctx_create(int32_t device_id, void *hip_stream, scopa_ctx **out) {
               hipMalloc(&ctx->d_key, sizeof(uint64_t) * kDecision) == hipSuccess &&
               hipMalloc(&ctx->d_meta, sizeof(int32_t) * 8) == hipSuccess &&
               hipMalloc(&ctx->d_visit, sizeof(uint32_t) * kDecision) == hipSuccess &&
-              hipMalloc(&ctx->d_sigcdf, (size_t)kDecision * 8 * sizeof(double)) == hipSuccess &&
+              hipMalloc(&ctx->d_sigcdf, (size_t)kDecision * 6 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_groups, scopa::kDeltaGroups * scopa::kDeltaTable * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_regret, rows * 4 * sizeof(double)) == hipSuccess &&
               hipMalloc(&ctx->d_strat, rows * 4 * sizeof(double)) == hipSuccess &&

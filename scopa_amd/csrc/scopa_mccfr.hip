@@ -75,7 +75,8 @@ __device__ __forceinline__ void choice_cdf(const double *sigma, int n, uint32_t 
 #pragma unroll
     for (int i = 0; i < 4; i++) thr[i] = i < n ? (uint32_t)ceil((cdf[i] / last) * 2147483648.0) : 0xFFFFFFFFu;  // padding never counts
 }
-// a frozen row as it is kept in HBM, [8] float64: sigma[4] | thresholds as 4 x uint32 | 16 bytes unused
+// a frozen row as it is kept in HBM and in LDS, [kRow = 6] float64: sigma[4] | thresholds as 4 x uint32 (48 bytes: the traversal's
+// prologue copies the rows to LDS as they are; until round 2 the HBM rows were 64 bytes with 16 unused, a quarter of the prologue's row bytes)
 __device__ __forceinline__ void row_store(double *__restrict__ row, const double *sg, const uint32_t *thr) {
     double2 *out = reinterpret_cast<double2 *>(row);
     out[0] = make_double2(sg[0], sg[1]);
@@ -109,7 +110,7 @@ static_assert(kPairDecisionVisits == 463, "291 + 172");
 
 }  // namespace
 
-// sigma | cdf rows of the frozen regret table, [n_infosets][8] float64, computed once per iteration
+// sigma | cdf rows of the frozen regret table, [n_infosets][kRow] float64, computed once per iteration
 __global__ void __launch_bounds__(256)
 k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g_regret, double *__restrict__ g_sigcdf, int n_infosets) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
@@ -120,7 +121,7 @@ k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g
     for (int c = 0; c < 4; c++) R[c] = g_regret[r * 4 + c];
     mc_sigma(R, n, sg);
     choice_cdf(sg, n, thr);
-    row_store(g_sigcdf + r * 8, sg, thr);
+    row_store(g_sigcdf + r * kRow, sg, thr);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -153,7 +154,7 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair j0 = 2 * (p - first block of the level), j0 + 1; its words are
 // x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the traverser node below it.
 // Philox counter = (p, global traversal id, iteration, traverser), key = seed.
-constexpr int kStaticLds = 64;   // s_vis, s_one, s_next (+ alignment), beside the dynamic LDS
+constexpr int kStaticLds = 64 + 9216;   // s_vis, s_one, s_next (+ alignment) and the staged lane table, beside the dynamic LDS
 
 template <int NP>
 __device__ __forceinline__ void draw_pairs(WaveScratch *ws, int lane, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
@@ -324,6 +325,7 @@ __device__ __forceinline__ void ply_step(WaveScratch *ws, int lane, const uint16
 #ifdef SCOPA_WALK_STAMPS   // development build only: shader-clock stamps of wavefront 0's stages, summed over its pairs (tests/tools/walk_stamps.py)
 __device__ unsigned long long g_walk_stamps[16];
 __device__ unsigned long long g_wave_clocks[3 * 16];   // whole pair loop per wavefront, workgroups 0, 100, 255; [2*16..] = wave's hardware id
+__device__ unsigned long long g_wave_phases[4 * 16];   // workgroup 0, per wavefront: entry -> prologue barrier | -> first pair | pair loop | -> kernel end
 #define WALK_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) { g_walk_stamps[i] += now_ - t_prev_; } t_prev_ = now_; } while (0)
 #else
 #define WALK_STAMP(i) do { } while (0)
@@ -487,7 +489,7 @@ __global__ void __launch_bounds__(64) k_lane_table(uint32_t *__restrict__ g_tab)
 }
 
 struct LaneVecs { uint4 v[kLaneVecs]; };
-__device__ __forceinline__ LaneVecs lane_table_load(const uint4 *__restrict__ g_tab, int lane) {   // issue early, unpack after the prologue
+__device__ __forceinline__ LaneVecs lane_table_load(const uint4 *__restrict__ g_tab, int lane) {
     LaneVecs r;
 #pragma unroll
     for (int f = 0; f < kLaneVecs; f++) r.v[f] = g_tab[f * 64 + lane];
@@ -528,7 +530,11 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     __shared__ unsigned int s_vis[2];
     __shared__ double s_one[1];
     __shared__ uint32_t s_next[1];   // next pair of this workgroup not taken yet
+    __shared__ uint4 s_lane_tab[kLaneVecs * 64];   // the lane table, staged once per workgroup (16 wavefronts reading it from L2 each: 147 KB per workgroup)
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
+#ifdef SCOPA_WALK_STAMPS
+    const unsigned long long c_entry_ = clock64();
+#endif
     const int I = n_infosets;
     double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows)
     double *s_dR = s_sigcdf + (size_t)I * kRow;                                  // [I][4] (16-byte aligned)
@@ -540,7 +546,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
-    const LaneVecs lane_words = lane_table_load(g_lane_tab, tid & 63);
+    const uint4 lane_piece = tid < kLaneVecs * 64 ? g_lane_tab[tid] : make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) {
         s_one[0] = 1.0;
         const uint32_t per_wg = (nb + gridDim.x - 1) / gridDim.x, W = blockDim.x >> 6;
@@ -552,17 +558,14 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     // the LDS zeroing runs underneath them, then the loaded pieces are stored.
     const uint32_t *gi = reinterpret_cast<const uint32_t *>(g_infoset), *gp = reinterpret_cast<const uint32_t *>(g_payoff);
     {
-        constexpr int kSig = 7;                                                   // pieces per thread held in registers: covers I <= 1653 at 1024 threads
-        const double2 *g2 = reinterpret_cast<const double2 *>(g_sigcdf);
-        auto put = [&](int idx, double2 x) {                                      // 16-byte piece idx of the [I][8] rows -> the 48-byte LDS rows
-            const int row = idx >> 2, piece = idx & 3;                            // pieces 0,1: sigma[4]; 2: the four thresholds; 3: unused
-            if (piece < 3) *reinterpret_cast<double2 *>(s_sigcdf + row * kRow + piece * 2) = x;
-        };
+        constexpr int kSig = 5;                                                   // 16-byte pieces per thread held in registers: covers I <= 1653 at 1024 threads
+        const double2 *g2 = reinterpret_cast<const double2 *>(g_sigcdf);          // the rows have the LDS layout: a straight copy of 3 I pieces
+        double2 *s2 = reinterpret_cast<double2 *>(s_sigcdf);
         double2 v[kSig];
 #pragma unroll
         for (int j = 0; j < kSig; j++) {
             const int idx = tid + j * nthr;
-            v[j] = idx < I * 4 ? g2[idx] : make_double2(0.0, 0.0);
+            v[j] = idx < I * 3 ? g2[idx] : make_double2(0.0, 0.0);
         }
         // node -> infoset map: 1653 u16 = 826 words + one half word; leaf payoffs: 576 bytes = 144 words (both arrays 4-byte aligned)
         const uint32_t wi = tid < kDecision / 2 ? gi[tid] : 0u;
@@ -573,9 +576,10 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 #pragma unroll
         for (int j = 0; j < kSig; j++) {
             const int idx = tid + j * nthr;
-            if (idx < I * 4) put(idx, v[j]);
+            if (idx < I * 3) s2[idx] = v[j];
         }
-        for (int idx = tid + kSig * nthr; idx < I * 4; idx += nthr) put(idx, g2[idx]);  // narrower workgroups (many infosets): the rest, plainly
+        for (int idx = tid + kSig * nthr; idx < I * 3; idx += nthr) s2[idx] = g2[idx];  // narrower workgroups (many infosets): the rest, plainly
+        if (tid < kLaneVecs * 64) s_lane_tab[tid] = lane_piece;
         if (tid < kDecision / 2) reinterpret_cast<uint32_t *>(s_inf)[tid] = wi;
         if (tid == 0) s_inf[kDecision - 1] = last_inf;
         if (tid < kTerminal / 4) reinterpret_cast<uint32_t *>(s_pay)[tid] = wp;
@@ -584,11 +588,15 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     for (int i = tid + nthr; i < kTerminal / 4; i += nthr) reinterpret_cast<uint32_t *>(s_pay)[i] = gp[i];
     __syncthreads();
     const unsigned long long t_pro = wall_clock64();
+#ifdef SCOPA_WALK_STAMPS
+    const unsigned long long c_barrier_ = clock64();
+    unsigned long long c_loop0_ = 0, c_loop1_ = 0;
+#endif
 
     WaveScratch *ws = s_wave + 2 * wave;
     AncRegs anc;
     LaneSlots ls;
-    lane_table_unpack(lane_words, lds_addr(ws), ls, anc);
+    lane_table_unpack(lane_table_load(s_lane_tab, lane), lds_addr(ws), ls, anc);
     unsigned int my_pairs = 0;   // pairs this wavefront walked
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     // The workgroup owns pairs [first, first + count); its wavefronts TAKE them from a counter in LDS instead of owning a fixed share:
@@ -598,6 +606,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     {
 #ifdef SCOPA_WALK_STAMPS
         const unsigned long long loop_start_ = clock64();
+        c_loop0_ = loop_start_;
 #endif
         const uint32_t per_wg = (nb + gridDim.x - 1) / gridDim.x;
         const uint32_t first = blockIdx.x * per_wg, count = first < nb ? (nb - first < per_wg ? nb - first : per_wg) : 0u;
@@ -621,7 +630,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
             if (c >= count) break;
         }
 #ifdef SCOPA_WALK_STAMPS
-        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) g_wave_clocks[(blockIdx.x == 0 ? 0 : 16) + wave] += clock64() - loop_start_;
+        c_loop1_ = clock64();
+        if (lane == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) g_wave_clocks[(blockIdx.x == 0 ? 0 : 16) + wave] += c_loop1_ - loop_start_;
         if (lane == 0 && blockIdx.x == 0) { unsigned int hw; asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw)); g_wave_clocks[32 + wave] = hw; }
 #endif
     }
@@ -650,6 +660,12 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     if (lane == 0) { atomicAdd(&s_vis[0], my_pairs * kPairDecisionVisits); atomicAdd(&s_vis[1], my_pairs * kPairTerminalVisits); }
     __syncthreads();
     if (tid < 2) atomicAdd(&g_wg_counts[blockIdx.x * 2 + tid], (unsigned long long)s_vis[tid]);   // its own slot: no contention, nothing to wait for
+#ifdef SCOPA_WALK_STAMPS
+    if (blockIdx.x == 0 && (tid & 63) == 0) {
+        g_wave_phases[(tid >> 6)] += c_barrier_ - c_entry_; g_wave_phases[16 + (tid >> 6)] += c_loop0_ - c_barrier_;
+        g_wave_phases[32 + (tid >> 6)] += c_loop1_ - c_loop0_; g_wave_phases[48 + (tid >> 6)] += clock64() - c_loop1_;
+    }
+#endif
     if (g_clock && tid == 0) {   // sampled launches: this workgroup's phase stamps (start | prologue done | walks done | end)
         g_clock[blockIdx.x * 4] = t_start; g_clock[blockIdx.x * 4 + 1] = t_pro; g_clock[blockIdx.x * 4 + 2] = t_walk; g_clock[blockIdx.x * 4 + 3] = wall_clock64();
     }
@@ -754,7 +770,7 @@ __device__ __forceinline__ ApplyRow apply_row_load(int r, const uint64_t *__rest
     ApplyRow a;
     const double2 r0 = *reinterpret_cast<const double2 *>(g_regret + r * 4), r1 = *reinterpret_cast<const double2 *>(g_regret + r * 4 + 2);
     const double2 s0 = *reinterpret_cast<const double2 *>(g_strat + r * 4), s1 = *reinterpret_cast<const double2 *>(g_strat + r * 4 + 2);
-    const double2 g0 = *reinterpret_cast<const double2 *>(g_sigcdf + r * 8), g1 = *reinterpret_cast<const double2 *>(g_sigcdf + r * 8 + 2);
+    const double2 g0 = *reinterpret_cast<const double2 *>(g_sigcdf + r * kRow), g1 = *reinterpret_cast<const double2 *>(g_sigcdf + r * kRow + 2);
     a.n = (int)((g_key[r] >> 1) & 7);
     a.R[0] = r0.x; a.R[1] = r0.y; a.R[2] = r1.x; a.R[3] = r1.y;
     a.S[0] = s0.x; a.S[1] = s0.y; a.S[2] = s1.x; a.S[3] = s1.y;
@@ -775,7 +791,7 @@ __device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double
     uint32_t thr[4];
     mc_sigma(a.R, a.n, sg);
     choice_cdf(sg, a.n, thr);
-    row_store(g_sigcdf + r * 8, sg, thr);
+    row_store(g_sigcdf + r * kRow, sg, thr);
 }
 
 // one cell (k = 0..3 regret deltas, 4 = visit count) of row r's delta: its 8 group tables summed in table order; non-zero cells are cleared
@@ -1176,6 +1192,9 @@ int32_t scopa_mccfr_replay(scopa_ctx *ctx, int32_t n_iters, const double *h_unif
 }  // extern "C"
 
 #ifdef SCOPA_WALK_STAMPS
+extern "C" int scopa_debug_wave_phases(unsigned long long *out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_wave_phases), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
 extern "C" int scopa_debug_wave_clocks(unsigned long long *out48) {
     return hipMemcpyFromSymbol(out48, HIP_SYMBOL(g_wave_clocks), sizeof(unsigned long long) * 48) == hipSuccess ? 0 : -1;
 }

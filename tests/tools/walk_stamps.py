@@ -27,3 +27,7 @@ its = N + 200
 for g, nm in ((0, "workgroup 0"), (16, "workgroup 100")):
     print(f"  pair loop per wavefront, {nm} (clocks per launch):", " ".join(f"{float(x) / its:.0f}" for x in wc[g:g + 16]))
 print("  HW_ID of workgroup 0's wavefronts (wave slot bits 3:0, SIMD bits 5:4, CU bits 11:8):", " ".join(f"simd{(int(x) >> 4) & 3}" for x in wc[32:48]))
+ph = np.zeros(64, np.uint64)
+lib.scopa_debug_wave_phases(ph.ctypes.data_as(ctypes.c_void_p))
+for k, nm in enumerate(("kernel entry -> prologue barrier", "barrier -> first pair (lane table unpack, lane statics)", "pair loop", "pair loop end -> kernel end (barrier, atomics)")):
+    print(f"  workgroup 0, {nm}:", " ".join(f"{float(x) / its:.0f}" for x in ph[16 * k:16 * k + 16]))
