@@ -84,9 +84,26 @@ struct scopa_ctx {
 
 namespace scopa {
 
-// group tables of the batched-MCCFR delta (scopa_mccfr.hip): 8 cell-major tables of [5][kDecision] float64 per context
-constexpr int kDeltaGroups = 8;
-constexpr size_t kDeltaTable = (size_t)kDecision * 5;              // doubles per group table
+// group tables of the batched-MCCFR delta (scopa_mccfr.hip): cell-major tables of [5][kGroupRows] float64 per context
+#ifndef SCOPA_GROUPS
+#define SCOPA_GROUPS 16
+#endif
+#ifndef SCOPA_GROUP_PERM
+#define SCOPA_GROUP_PERM 0
+#endif
+constexpr int kDeltaGroups = SCOPA_GROUPS;
+constexpr int kGroupRows = 1664;                                   // kDecision rounded up to 64 x 26
+constexpr size_t kDeltaTable = (size_t)kGroupRows * 5;             // doubles per group table
+// where cell k (0..3 regret deltas, 4 visit count) of infoset row r lies in a group table
+__host__ __device__ inline size_t group_cell(int k, int r) {
+#if SCOPA_GROUP_PERM == 1
+    return (size_t)k * kGroupRows + (size_t)((r & 63) * 26 + (r >> 6));
+#elif SCOPA_GROUP_PERM == 2
+    return (size_t)k * kGroupRows + (size_t)((r & 7) * 208 + (r >> 3));
+#else
+    return (size_t)k * kGroupRows + (size_t)r;
+#endif
+}
 constexpr int kClockSamples = 2048, kClockStride = 2048;           // sampled launches kept / uint64 per sample (512 workgroups x 4 phase stamps)
 
 inline int32_t fail(scopa_ctx *ctx, int32_t code, const char *what, hipError_t e = hipSuccess) {

@@ -648,7 +648,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         for (int k = 0; k < 5; k++)
             for (int r = tid; r < I; r += nthr) {
                 const double v = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
-                if (v != 0.0) atomicAdd(&tab[(size_t)k * kDecision + r], v);
+                if (v != 0.0) atomicAdd(&tab[group_cell(k, r)], v);
             }
         if (first0) g_visit[tid] = 0x40000000u + (uint32_t)tid;              // racing writers store the same value
         if (first1) g_visit[tid + nthr] = 0x40000000u + (uint32_t)(tid + nthr);
@@ -753,7 +753,7 @@ k_mccfr_fold(double *__restrict__ g_groups, double *__restrict__ g_delta, int n_
     double d[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
     for (int g = 0; g < kDeltaGroups; g++)
         for (int k = 0; k < 5; k++) {
-            double *q = g_groups + (size_t)g * kDeltaTable + (size_t)k * kDecision + r;
+            double *q = g_groups + (size_t)g * kDeltaTable + group_cell(k, r);
             d[k] += *q;
             *q = 0.0;
         }
@@ -798,12 +798,12 @@ __device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double
 __device__ __forceinline__ double groups_cell_take(double *__restrict__ g_groups, int r, int k) {
     double v[kDeltaGroups];
 #pragma unroll
-    for (int g = 0; g < kDeltaGroups; g++) v[g] = g_groups[(size_t)g * kDeltaTable + (size_t)k * kDecision + r];   // 8 loads in flight
+    for (int g = 0; g < kDeltaGroups; g++) v[g] = g_groups[(size_t)g * kDeltaTable + group_cell(k, r)];   // all loads in flight
     double d = 0.0;
 #pragma unroll
     for (int g = 0; g < kDeltaGroups; g++) {
         d += v[g];                                                                                               // table order
-        if (v[g] != 0.0) g_groups[(size_t)g * kDeltaTable + (size_t)k * kDecision + r] = 0.0;
+        if (v[g] != 0.0) g_groups[(size_t)g * kDeltaTable + group_cell(k, r)] = 0.0;
     }
     return d;
 }
