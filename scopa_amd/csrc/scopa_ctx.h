@@ -47,7 +47,7 @@ struct scopa_ctx {
     double *d_scratch = nullptr;  // root values / uniforms staging
     double *d_sigcdf = nullptr;   // [kDecision][6] sigma | threshold rows of the frozen regret table (48 bytes: the layout the traversal keeps in LDS)
     bool sigcdf_valid = false;    // false whenever d_regret changed outside k_mccfr_apply
-    double *d_groups = nullptr;   // [8 group tables][5][kDecision] float64: where traversal launches add their deltas (scopa_mccfr.hip); all-zero between launches' applies
+    double *d_groups = nullptr;   // [kDeltaGroups group tables][5][kGroupRows] float64: where traversal launches add their deltas (scopa_mccfr.hip); all-zero between launches' applies
     unsigned long long *d_clock = nullptr;   // [2048 sampled launches][512 workgroups][4] phase stamps on the 100 MHz device clock (allocated by scopa_prof_enable)
     uint16_t clock_grid[2048] = {0};         // workgroups of each sampled launch
     double prof_phase_us[3] = {0.0, 0.0, 0.0};   // mean (prologue, walks, epilogue) per workgroup of the samples last folded by scopa_prof_device

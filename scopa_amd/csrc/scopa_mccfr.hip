@@ -25,9 +25,9 @@
 // v as the reference's fma chain over <= 4 leaf payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Every stage
 // gathers what it reads before it stores anything (branch-free loads, slots beyond a node's action count selected away).
 // Everything a pair touches is LDS resident (sigma|threshold rows 35 KB, delta 24 KB, 16 x 2 x 1.4 KB wave scratch, tree maps 4 KB
-// at 738 infosets; one 1024-thread workgroup per CU).  A workgroup finally adds its non-zero cells to one of 8 GROUP TABLES in HBM
+// at 738 infosets; one 1024-thread workgroup per CU).  A workgroup finally adds its non-zero cells to one of 16 GROUP TABLES in HBM
 // with memory-side float64 atomics; k_mccfr_apply_groups (one small launch; k_mccfr_exchange_apply for N > 1, which exchanges the
-// rows with the peers first, scopa_p2p.h; k_mccfr_fold + k_mccfr_apply on the split path) sums the 8 tables in table order and
+// rows with the peers first, scopa_p2p.h; k_mccfr_fold + k_mccfr_apply on the split path) sums the group tables in table order and
 // applies them.  Strategy sums are integer visit counts (sigma is frozen, so strategy_sum += count * sigma).
 //
 // History (rocprofv3, B = 4096 per traverser, profiles/; full table in DESIGN.md section 4): v1 one lane per leaf path + global f64
@@ -512,14 +512,16 @@ __device__ __forceinline__ void lane_table_unpack(const LaneVecs &r, uint32_t ws
 
 // Where a launch leaves its result.  A workgroup's partial delta table (regret increments + traverser-visit counts, LDS) is added
 // to a GROUP table in HBM with memory-side float64 atomics: workgroup b adds into table b % kDeltaGroups.  A group table is
-// [5][kDecision] float64 -- cell-major: dR0 of every infoset, dR1, dR2, dR3, counts -- so that a lane per cell adds, and a thread per
-// infoset row later reads, with consecutive lanes on consecutive addresses.  Only non-zero cells are added (~125 of 3690 per
-// workgroup once the strategies have sharpened).  Why groups: such an atomic costs ~20 ns per (workgroup, 64-byte line) request
-// on the SAME line while different lines proceed in parallel, and with peaked strategies every workgroup touches the same ~100
-// rows -- 256 workgroups on one table would queue 256 deep on every hot line (+2.5 .. 5 us at the end of the launch,
-// benchmarks/micro/atomic_flush.hip), 8 tables make that 32 deep (+0.6 us).  k_mccfr_apply (one small launch) then sums the 8 tables
-// in table order, applies the sum and prepares the next iteration's rows.  This replaced per-workgroup SLABS (256 x 29.5 KB
-// written per launch, read back by a reduce kernel that took 8.3 us of a 22 us iteration).
+// [5][kGroupRows] float64 -- cell-major: dR0 of every infoset, dR1, dR2, dR3, counts -- so that a lane per cell adds, and a lane per
+// cell later reads, with consecutive lanes on consecutive addresses.  Only non-zero cells are added.  Why groups: such an atomic
+// executes at the memory side, one 64-byte line request at a time per line, and with peaked strategies every workgroup touches the
+// same ~100 rows -- 256 workgroups on one table would queue 256 deep on every hot line (+2.5 .. 5 us at the end of the launch,
+// benchmarks/micro/atomic_flush.hip).  How many tables: measured on the kernel itself, 4 / 8 / 16 / 24 / 32 / 64 tables -> 16.85 /
+// 14.65 / 13.5 / 13.3 / 14.1 / 15.2 us per iteration at B = 4096 (more tables: shorter queues, but the apply launch reads them all);
+// permuting rows so that hot rows fall on different lines is slower (a wavefront's adds then touch more lines: requests are what
+// costs).  k_mccfr_apply_groups (one small launch) then sums the tables in table order, applies the sum and prepares the next
+// iteration's rows.  This replaced per-workgroup SLABS (256 x 29.5 KB written per launch, read back by a reduce kernel that took
+// 8.3 us of a 22 us iteration).
 __global__ void __launch_bounds__(1024)
 k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_payoff,
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_groups,
@@ -770,7 +772,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     if (tid < 2) g_counters[tid] += s_vis[tid];
 }
 
-// Split path, after a traversal launch: delta[r][0..4] += the 8 group tables in table order; the group tables are cleared.
+// Split path, after a traversal launch: delta[r][0..4] += the group tables in table order; the group tables are cleared.
 // (The all-reduce payload stays the compact [n_infosets][5] table the caller may have bound.)
 __global__ void __launch_bounds__(256)
 k_mccfr_fold(double *__restrict__ g_groups, double *__restrict__ g_delta, int n_infosets) {
@@ -820,7 +822,7 @@ __device__ __forceinline__ void apply_row_store(int r, ApplyRow &a, const double
     row_store(g_sigcdf + r * kRow, sg, thr);
 }
 
-// one cell (k = 0..3 regret deltas, 4 = visit count) of row r's delta: its 8 group tables summed in table order; non-zero cells are cleared
+// one cell (k = 0..3 regret deltas, 4 = visit count) of row r's delta: its group tables summed in table order; non-zero cells are cleared
 __device__ __forceinline__ double groups_cell_take(double *__restrict__ g_groups, int r, int k) {
     double v[kDeltaGroups];
 #pragma unroll
@@ -839,7 +841,7 @@ __device__ __forceinline__ double groups_cell_take(double *__restrict__ g_groups
 // -- many one-wavefront workgroups spread over the compute units beat fewer, fuller ones for this latency-bound launch.
 constexpr int kApplyLanes = 8, kApplyThreads = 64;
 
-// The apply step after a single-GPU traversal launch: delta = the 8 group tables summed in table order, cleared on the way.  A
+// The apply step after a single-GPU traversal launch: delta = the group tables summed in table order, cleared on the way.  A
 // wavefront (= a workgroup: the rows spread over as many compute units as possible) takes 8 rows, lane = 8 * row + cell: five lanes
 // of a row fetch one cell of its delta each, lane 0 of the row collects them and applies the row -- one memory round trip, few
 // loads per lane.  The launch must find d_sigcdf current (it holds the sigma the traversal sampled with).
@@ -871,7 +873,7 @@ k_mccfr_apply(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret,
     apply_row_store(r, a, d, g_regret, g_strat, g_sigcdf);
 }
 
-// N > 1, after a traversal launch: this rank's delta of an infoset row (its 8 group tables summed in table order, then cleared)
+// N > 1, after a traversal launch: this rank's delta of an infoset row (its group tables summed in table order, then cleared)
 // is exchanged with the peers (scopa_p2p.h), becomes the rank-ordered sum over ranks (identical bits on every rank) and is applied
 // -- the whole multi-GPU iteration stays two launches.  One wavefront per 4 rows, lane = 16 * row + peer; lane 0 of a row applies it.
 __global__ void __launch_bounds__(64)
@@ -1009,7 +1011,7 @@ static int32_t ensure_lane_table(scopa_ctx *ctx) {
 }
 
 // One traversal launch of `nb` traversal pairs [b0, b0 + nb) of iteration `iteration` against the rows in d_sigcdf; the launch
-// adds its deltas into the context's 8 group tables (all-zero whenever no launch's result is pending).
+// adds its deltas into the context's group tables (all-zero whenever no launch's result is pending).
 static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
     // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~870 infosets), fewer for deals
     // with more infosets (the tables alone fit up to 1653, the maximum)
@@ -1153,7 +1155,7 @@ int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration) {
 }
 
 int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
-    // single GPU: two launches per iteration -- the traversal, and the one-thread-per-row apply over its 8 group tables
+    // single GPU: two launches per iteration -- the traversal, and the lane-per-cell apply over its group tables
     if (!ctx) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_iterate: no deal set");
     SC_REQUIRE(ctx, batch > 0 && batch <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_iterate: bad batch");
