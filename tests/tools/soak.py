@@ -16,6 +16,9 @@ for chunk in [1000, 9000, 90000] + [100000] * ((N - 100000) // 100000):
     assert (d, t) == (463 * 4096 * done, 240 * 4096 * done), (d, t, done)
     R, S, _ = ctx.tables_get()
     assert np.isfinite(R).all() and np.isfinite(S).all()
+    # every traverser visit adds a probability vector to strategy_sum: a lost or doubled visit count (wavefronts take pairs from a counter and
+    # pre-flush the delta table concurrently) would show here
+    assert abs(S.sum() - 172.0 * 4096 * done) <= 1e-9 * 172.0 * 4096 * done, (S.sum(), 172.0 * 4096 * done)
     pts.append({"iterations": done, "exploitability": float(ctx.exploitability()["exploitability"]), "seconds": time.perf_counter() - t0})
     print(pts[-1], file=sys.stderr, flush=True)
 print(json.dumps({"batch": 4096, "points": pts, "visits": 463 * 4096 * done, "visits_per_s_incl_host_checks": 463 * 4096 * done / (time.perf_counter() - t0)}))
