@@ -319,9 +319,10 @@ struct SdWave {               // per-wavefront scratch
     float val[2][24];
     float polcur[kG][4];
     scopa_state st[kG];       // packed states of the nodes in flight
-    uint16_t idx[9][24];      // tree index of every frontier node, per ply (ply 8 = leaves)
-    uint16_t pad[8];
+    uint16_t idx[136];        // tree index of every frontier node, per ply (ply 8 = leaves), at idx_at(ply): the frontier is 1, <= 4, 4, <= 12, 12,
+                              // <= 24, 24, 24, 24 wide (either traverser) -- packed, so that TWELVE wavefronts fit beside the two nets: 3 per SIMD
 };
+__host__ __device__ constexpr int idx_at(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 9 : d == 4 ? 21 : d == 5 ? 33 : d == 6 ? 57 : d == 7 ? 81 : 105; }
 static_assert(sizeof(SdWave) % 16 == 0, "SdWave alignment");
 
 __device__ __forceinline__ void sd_sync() {
@@ -332,7 +333,7 @@ __device__ __forceinline__ void sd_sync() {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(640)
+__global__ void __launch_bounds__(768)
 k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_weights,
                  int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
                  long long capacity, long long write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
@@ -396,7 +397,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
     const int first = (int)blockIdx.x * per_wg, count = first < batch ? (batch - first < per_wg ? batch - first : per_wg) : 0;
     for (int c = wave; c < count;) {
         const int tb = first + c;
-        if (lane == 0) ws.idx[0][0] = 0;
+        if (lane == 0) ws.idx[idx_at(0)] = 0;
         sd_sync();
         int width = 1;
         // ---- forward: plies 0..7 ----------------------------------------------------------------------------------------
@@ -412,7 +413,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 // on it or falls back to uniform over it (deep_cfr.py:353-359) -- the child is forced and nothing else of this
                 // node is used (no memory row, no value weight), so its forward pass is skipped: 24 of the 105 / 82 node
                 // evaluations of a traversal
-                if (lane < width) ws.idx[d + 1][lane] = ws.idx[d][lane];
+                if (lane < width) ws.idx[idx_at(d + 1) + lane] = ws.idx[idx_at(d) + lane];
                 sd_sync();
                 continue;
             }
@@ -432,7 +433,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
             const float4 *w3q = reinterpret_cast<const float4 *>(W + kW3);
             for (int g0 = 0; g0 < width; g0 += kG) {
                 // the group's packed states: one global load per node, then every lane reads the state of ITS node (lane % 4)
-                if (lane < kG && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[d][g0 + lane]];
+                if (lane < kG && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[idx_at(d) + g0 + lane]];
                 sd_sync();
                 const bool live = g0 + nj < width;
                 const scopa_state sj = ws.st[nj];
@@ -527,11 +528,11 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 sd_sync();
                 // expand / sample: one lane per node of the group
                 if (lane < kG && g0 + lane < width) {
-                    const int j = g0 + lane, idx = ws.idx[d][j];
+                    const int j = g0 + lane, idx = ws.idx[idx_at(d) + j];
                     float pk[4];
                     for (int k = 0; k < 4; k++) pk[k] = k < nl ? ws.polcur[lane][k] : 0.0f;
                     if (trav_ply) {
-                        for (int k = 0; k < nl; k++) ws.idx[d + 1][j * nl + k] = (uint16_t)(idx * nl + k);
+                        for (int k = 0; k < nl; k++) ws.idx[idx_at(d + 1) + j * nl + k] = (uint16_t)(idx * nl + k);
                         for (int k = 0; k < 4; k++) ws.pol_trav[moff + j][k] = pk[k];
                     } else {
                         float sum = pk[0];
@@ -552,7 +553,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                             for (int k = 0; k < nl; k++) if (cdf[k] / last <= u) a = k + 1;
                             a = a < nl - 1 ? a : nl - 1;
                         }
-                        ws.idx[d + 1][j] = (uint16_t)(idx * nl + a);
+                        ws.idx[idx_at(d + 1) + j] = (uint16_t)(idx * nl + a);
                     }
                 }
                 sd_sync();
@@ -560,7 +561,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
             if (trav_ply) width *= nl;
         }
         // ---- leaves, then backward ---------------------------------------------------------------------------------------
-        if (lane < width) { const int p0 = g_payoff[ws.idx[8][lane]]; ws.val[0][lane] = 0.5f * (float)(traverser == 0 ? p0 : -p0); }
+        if (lane < width) { const int p0 = g_payoff[ws.idx[idx_at(8) + lane]]; ws.val[0][lane] = 0.5f * (float)(traverser == 0 ? p0 : -p0); }
         sd_sync();
         int cur = 0;
 #pragma unroll 1
@@ -574,7 +575,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 const int j = lane;
                 if (!trav_ply) ws.val[cur ^ 1][j] = ws.val[cur][j];
                 else {
-                    const scopa_state s = g_states[level_offset(d) + ws.idx[d][j]];
+                    const scopa_state s = g_states[level_offset(d) + ws.idx[idx_at(d) + j]];
                     float value = 0.0f, cfv[16];
                     for (int c = 0; c < 16; c++) cfv[c] = 0.0f;
                     uint32_t hand_bits = 0, table_bits = 0;
@@ -629,9 +630,9 @@ extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser,
     SC_REQUIRE(ctx, ((uintptr_t)d_weights & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: weights must be 16-byte aligned");
     if (!batch) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 10, the kernel's launch bound)
+    // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 12, the kernel's launch bound: 3 per SIMD)
     int waves = (int)(((size_t)ctx->lds_limit - 64 - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
-    waves = waves > 10 ? 10 : waves;
+    waves = waves > 12 ? 12 : waves;
     SC_REQUIRE(ctx, waves >= 8, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (the weight staging assumes >= 512 threads)");
     const int threads = waves * 64;
     const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
