@@ -313,14 +313,14 @@ constexpr int kW1 = 0, kB1 = 34 * 128, kW2 = kB1 + 128, kB2 = kW2 + 128 * 64, kW
 
 constexpr int kG = 4;         // frontier nodes evaluated together (a "group"); measured: 4 nodes x 10 wavefronts 1.18 ms per iteration, 8 nodes x 6 wavefronts (what LDS then allows) 1.76 ms
 struct SdWave {               // per-wavefront scratch
-    float h1[128][kG];        // hidden layer 1 of the nodes in flight
-    float h2[64][kG];
+    float h1[128][kG];        // hidden layer 1 of the nodes in flight; hidden layer 2 ([64][kG]) takes the first half of the same storage once
+                              // layer 2 has read all of layer 1 (a wavefront's LDS operations execute in order) -- 1 KB less per wavefront
     float pol_trav[41][4];    // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
     float val[2][24];
     float polcur[kG][4];
     scopa_state st[kG];       // packed states of the nodes in flight
     uint16_t idx[136];        // tree index of every frontier node, per ply (ply 8 = leaves), at idx_at(ply): the frontier is 1, <= 4, 4, <= 12, 12,
-                              // <= 24, 24, 24, 24 wide (either traverser) -- packed, so that TWELVE wavefronts fit beside the two nets: 3 per SIMD
+                              // <= 24, 24, 24, 24 wide (either traverser) -- packed, so that SIXTEEN wavefronts fit beside the two nets: 4 per SIMD
 };
 __host__ __device__ constexpr int idx_at(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 9 : d == 4 ? 21 : d == 5 ? 33 : d == 6 ? 57 : d == 7 ? 81 : 105; }
 static_assert(sizeof(SdWave) % 16 == 0, "SdWave alignment");
@@ -333,7 +333,7 @@ __device__ __forceinline__ void sd_sync() {
 }
 }  // namespace
 
-__global__ void __launch_bounds__(768)
+__global__ void __launch_bounds__(1024)
 k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_weights,
                  int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
                  long long capacity, long long write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
@@ -478,7 +478,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                         acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0);
                     }
                     // h2 as k-quads for layer 3: h2q[unit / 4][node][unit % 4]
-                    reinterpret_cast<float4 *>(&ws.h2[0][0])[bq * 4 + nj] =
+                    reinterpret_cast<float4 *>(&ws.h1[0][0])[bq * 4 + nj] =
                         make_float4(fmaxf(acc[0] + W[kB2 + 4 * bq], 0.0f), fmaxf(acc[1] + W[kB2 + 4 * bq + 1], 0.0f),
                                     fmaxf(acc[2] + W[kB2 + 4 * bq + 2], 0.0f), fmaxf(acc[3] + W[kB2 + 4 * bq + 3], 0.0f));
                 }
@@ -488,7 +488,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 {
                     const int ks = bq >> 2, ob = bq & 3;
                     v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                    const float4 *hq = reinterpret_cast<const float4 *>(&ws.h2[0][0]);
+                    const float4 *hq = reinterpret_cast<const float4 *>(&ws.h1[0][0]);   // = hidden layer 2 now
 #pragma unroll
                     for (int t = 0; t < 4; t++) {
                         const int kq = ks * 4 + t;
@@ -630,9 +630,9 @@ extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser,
     SC_REQUIRE(ctx, ((uintptr_t)d_weights & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: weights must be 16-byte aligned");
     if (!batch) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 12, the kernel's launch bound: 3 per SIMD)
+    // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 16, the kernel's launch bound: 4 per SIMD)
     int waves = (int)(((size_t)ctx->lds_limit - 64 - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
-    waves = waves > 12 ? 12 : waves;
+    waves = waves > 16 ? 16 : waves;
     SC_REQUIRE(ctx, waves >= 8, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (the weight staging assumes >= 512 threads)");
     const int threads = waves * 64;
     const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
