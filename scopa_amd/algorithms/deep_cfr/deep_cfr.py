@@ -120,16 +120,23 @@ class AdvantageNetwork:
         self._rng.shuffle(list(range(16)))
         if self.use_graph and self.grad_sync is None:
             return self._train_graphed(n, batch_size, epochs)
+        rows_all = self._sample_rows(n, batch_size, epochs)
         total_loss = 0.0
-        for _ in range(epochs):
-            idx = torch.tensor(self.sample_indices(n, batch_size), device=self.device)
-            total_loss += self._step(self.buffer.logical_to_physical(idx)).item()
+        for e in range(epochs):
+            total_loss += self._step(rows_all[e]).item()
         return total_loss / epochs
+
+    def _sample_rows(self, n, batch_size, epochs):
+        """All `epochs` index batches of one train() call in ONE upload ([epochs, batch] ring rows): the reference draws them one after
+        the other from the same `random` stream (:88), so drawing them up front gives the same batches; a per-step list -> device copy
+        made the optimiser step host-bound."""
+        idx = torch.tensor([self.sample_indices(n, batch_size) for _ in range(epochs)], dtype=torch.long, device=self.device)
+        return self.buffer.logical_to_physical(idx)
 
     def _step(self, rows):
         """One optimiser step on the ring rows `rows` (deep_cfr.py:99-112); returns the loss tensor."""
         states, target_adv, masks = self.buffer.feat[rows], self.buffer.regret[rows], self.buffer.mask[rows]
-        self.optimizer.zero_grad(set_to_none=False)
+        self.optimizer.zero_grad(set_to_none=True)   # fresh gradient tensors each step: no zero-fill and no accumulate-add kernels (9 of ~45 per step)
         pred_adv = self.net(states)
         loss = self.criterion(pred_adv * masks, target_adv * masks)
         loss.backward()
@@ -169,13 +176,13 @@ class AdvantageNetwork:
                                 v.zero_()   # a fresh optimiser: moments and step count start at zero
             self._graphs[batch_size] = (g, rows, loss)
         g, rows, loss = self._graphs[batch_size]
-        losses = []
-        for _ in range(epochs):
-            idx = torch.tensor(self.sample_indices(n, batch_size), device=self.device)
-            rows.copy_(self.buffer.logical_to_physical(idx))
+        rows_all = self._sample_rows(n, batch_size, epochs)
+        losses = torch.empty(epochs, dtype=loss.dtype, device=self.device)
+        for e in range(epochs):
+            rows.copy_(rows_all[e])
             g.replay()
-            losses.append(loss.clone())
-        return float(torch.stack(losses).sum().item()) / epochs
+            losses[e].copy_(loss)
+        return float(losses.sum().item()) / epochs
 
 
 class StrategyBuffer:
