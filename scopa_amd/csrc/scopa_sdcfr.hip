@@ -333,6 +333,13 @@ __device__ __forceinline__ void sd_sync() {
 }
 }  // namespace
 
+#ifdef SCOPA_WALK_STAMPS   // development build only: shader-clock stamps of wavefront 0 of workgroup 0 (tests/tools/sdcfr_stamps.py)
+__device__ unsigned long long g_sd_stamps[16];   // 0 state load | 1 layer 1 | 2 layer 2 | 3 layer 3 + policy | 4 expand / sample | 5 skipped plies | 6 leaves + backward | 7 take | 15 traversals
+#define SD_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_sd_stamps[i] += now_ - sd_prev_; sd_prev_ = now_; } while (0)
+#else
+#define SD_STAMP(i) do { } while (0)
+#endif
+
 __global__ void __launch_bounds__(1024)
 k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_weights,
                  int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
@@ -397,6 +404,9 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
     const int first = (int)blockIdx.x * per_wg, count = first < batch ? (batch - first < per_wg ? batch - first : per_wg) : 0;
     for (int c = wave; c < count;) {
         const int tb = first + c;
+#ifdef SCOPA_WALK_STAMPS
+        unsigned long long sd_prev_ = clock64();
+#endif
         if (lane == 0) ws.idx[idx_at(0)] = 0;
         sd_sync();
         int width = 1;
@@ -415,6 +425,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 // evaluations of a traversal
                 if (lane < width) ws.idx[idx_at(d + 1) + lane] = ws.idx[idx_at(d) + lane];
                 sd_sync();
+                SD_STAMP(5);
                 continue;
             }
             typedef float v4f __attribute__((ext_vector_type(4)));
@@ -435,6 +446,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 // the group's packed states: one global load per node, then every lane reads the state of ITS node (lane % 4)
                 if (lane < kG && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[idx_at(d) + g0 + lane]];
                 sd_sync();
+                SD_STAMP(0);
                 const bool live = g0 + nj < width;
                 const scopa_state sj = ws.st[nj];
                 uint32_t hand_bits = 0, table_bits = 0;
@@ -464,6 +476,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                     h1q[(16 + bq) * 4 + nj] = make_float4(fmaxf(acc1[0], 0.0f), fmaxf(acc1[1], 0.0f), fmaxf(acc1[2], 0.0f), fmaxf(acc1[3], 0.0f));
                 }
                 sd_sync();
+                SD_STAMP(1);
                 // layer 2: K = 128, 64 units = 16 blocks.  Per four inputs: two 16-byte LDS reads and four MFMAs.
                 {
                     v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
@@ -483,6 +496,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                                     fmaxf(acc[2] + W[kB2 + 4 * bq + 2], 0.0f), fmaxf(acc[3] + W[kB2 + 4 * bq + 3], 0.0f));
                 }
                 sd_sync();
+                SD_STAMP(2);
                 // layer 3: K = 64, 16 outputs = 4 blocks; the other factor 4 of the 16 blocks splits K (block = ks * 4 + ob), the four
                 // partial sums are added across lanes afterwards
                 {
@@ -526,6 +540,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                     }
                 }
                 sd_sync();
+                SD_STAMP(3);
                 // expand / sample: one lane per node of the group
                 if (lane < kG && g0 + lane < width) {
                     const int j = g0 + lane, idx = ws.idx[idx_at(d) + j];
@@ -557,6 +572,7 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                     }
                 }
                 sd_sync();
+                SD_STAMP(4);
             }
             if (trav_ply) width *= nl;
         }
@@ -614,11 +630,24 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
         }
         if (lane == 0) root_values[tb] = ws.val[cur][0];
         sd_sync();
+        SD_STAMP(6);
         int got = 0;
         if (lane == 0) got = atomicAdd(s_next, 1);
         c = __builtin_amdgcn_readfirstlane(got);
+        SD_STAMP(7);
+#ifdef SCOPA_WALK_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) g_sd_stamps[15] += 1;
+#endif
     }
 }
+
+#ifdef SCOPA_WALK_STAMPS
+extern "C" int scopa_debug_sdcfr_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sd_stamps), z, sizeof(z)) != hipSuccess) return -1; }
+    return 0;
+}
+#endif
 
 extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_weights, float *d_mem_feat,
                                               float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
