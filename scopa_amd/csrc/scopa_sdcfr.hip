@@ -479,17 +479,19 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
                 SD_STAMP(1);
                 // layer 2: K = 128, 64 units = 16 blocks.  Per four inputs: two 16-byte LDS reads and four MFMAs.
                 {
-                    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
+                    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};   // two independent chains (even / odd k-quads)
                     const float4 *hq = reinterpret_cast<const float4 *>(&ws.h1[0][0]) + nj;
-#pragma unroll 8
-                    for (int kq = 0; kq < 32; kq++) {
-                        const float4 w = w2q[kq * 64];
-                        const float4 h = hq[kq * 4];
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, h.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, h.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, h.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0);
+#pragma unroll 4
+                    for (int kq = 0; kq < 32; kq += 2) {
+                        const float4 w = w2q[kq * 64], wb = w2q[(kq + 1) * 64];
+                        const float4 h = hq[kq * 4], hb = hq[(kq + 1) * 4];
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, h.x, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.x, hb.x, accb, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, h.y, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.y, hb.y, accb, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, h.z, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.z, hb.z, accb, 0, 0, 0);
+                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.w, hb.w, accb, 0, 0, 0);
                     }
+#pragma unroll
+                    for (int i = 0; i < 4; i++) acc[i] += accb[i];
                     // h2 as k-quads for layer 3: h2q[unit / 4][node][unit % 4]
                     reinterpret_cast<float4 *>(&ws.h1[0][0])[bq * 4 + nj] =
                         make_float4(fmaxf(acc[0] + W[kB2 + 4 * bq], 0.0f), fmaxf(acc[1] + W[kB2 + 4 * bq + 1], 0.0f),
