@@ -154,7 +154,8 @@ __device__ __forceinline__ void wave_lds_sync() {
 // 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair j0 = 2 * (p - first block of the level), j0 + 1; its words are
 // x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the traverser node below it.
 // Philox counter = (p, global traversal id, iteration, traverser), key = seed.
-constexpr int kStaticLds = 64 + 9216;   // s_vis, s_one, s_next (+ alignment) and the staged lane table, beside the dynamic LDS
+constexpr int kStaticLds = 64 + 9216;   // k_mccfr_traverse: s_vis, s_one, s_next, s_slice (+ alignment) and the staged lane table, beside the dynamic LDS
+constexpr int kStaticLdsMulti = 64;     // k_mccfr_multi: s_vis, s_one
 
 template <int NP>
 __device__ __forceinline__ void draw_pairs(WaveScratch *ws, int lane, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
@@ -1058,9 +1059,9 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
         b += (((size_t)max_infosets * 4 + 15) & ~(size_t)15) + 1656 * 2 + 576 + (size_t)max_infosets;
         return (b + 15) & ~(size_t)15;
     };
-    while (waves > 1 && need(waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
-    SC_REQUIRE(ctx, need(waves) + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
-    SC_LDS_ATTR(ctx, scopa::kLdsMulti, k_mccfr_multi, ctx->lds_limit - kStaticLds);
+    while (waves > 1 && need(waves) + kStaticLdsMulti > (size_t)ctx->lds_limit) waves -= 2;
+    SC_REQUIRE(ctx, need(waves) + kStaticLdsMulti <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr multi: infoset tables do not fit in LDS");
+    SC_LDS_ATTR(ctx, scopa::kLdsMulti, k_mccfr_multi, ctx->lds_limit - kStaticLdsMulti);
     if (int32_t rc = ensure_lane_table(ctx)) return rc;
     hipLaunchKernelGGL(k_mccfr_multi, dim3(n_deals), dim3(waves * 64), need(waves), ctx->stream, d_infoset, d_payoff, d_key, d_regret, d_strat,
                        d_meta, d_visit, d_counters, (uint32_t)seed, (uint32_t)(seed >> 32), iter0, n_iters, batch, (const uint4 *)ctx->d_lane_tab);
