@@ -511,8 +511,13 @@ __device__ __forceinline__ void lane_table_unpack(const LaneVecs &r, uint32_t ws
     for (int i = 0; i < 3; i++) anc.w[i] = w[kLwAnc + i];
 }
 
+// which group table a workgroup adds into: neighbours in dispatch order -- eight consecutive workgroups, one per XCD -- share a table
+// (b / 8 mod 16: 13.02 us per iteration at B = 4096; b mod 16, which gives every table to ONE XCD: 13.16 -- the adds execute at the
+// memory side either way)
+__device__ __forceinline__ int group_of(unsigned int b) { return (int)((b >> 3) % kDeltaGroups); }
+
 // Where a launch leaves its result.  A workgroup's partial delta table (regret increments + traverser-visit counts, LDS) is added
-// to a GROUP table in HBM with memory-side float64 atomics: workgroup b adds into table b % kDeltaGroups.  A group table is
+// to a GROUP table in HBM with memory-side float64 atomics: workgroup b adds into table group_of(b).  A group table is
 // [5][kGroupRows] float64 -- cell-major: dR0 of every infoset, dR1, dR2, dR3, counts -- so that a lane per cell adds, and a lane per
 // cell later reads, with consecutive lanes on consecutive addresses.  Only non-zero cells are added.  Why groups: such an atomic
 // executes at the memory side, one 64-byte line request at a time per line, and with peaked strategies every workgroup touches the
@@ -652,7 +657,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         const int W = n_waves;
         if ((int)sl < W - W / 4) {
             const int per = (I + W - 1) / W, r0 = (W - 1 - (int)sl) * per, r1 = r0 + per < I ? r0 + per : I;
-            double *tab = g_groups + (size_t)(blockIdx.x % kDeltaGroups) * kDeltaTable;
+            double *tab = g_groups + (size_t)group_of(blockIdx.x) * kDeltaTable;
             for (int r = r0 + lane; r < r1; r += 64) {
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -673,7 +678,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         // infosets first seen by this launch: the loads go out first, their answers are used after the atomics have been issued
         const bool first0 = tid < I && (s_seen[tid] || s_cnt[tid]) && g_visit[tid] == 0u;
         const bool first1 = tid + nthr < I && (s_seen[tid + nthr] || s_cnt[tid + nthr]) && g_visit[tid + nthr] == 0u;
-        double *tab = g_groups + (size_t)(blockIdx.x % kDeltaGroups) * kDeltaTable;
+        double *tab = g_groups + (size_t)group_of(blockIdx.x) * kDeltaTable;
         for (int k = 0; k < 5; k++)
             for (int r = tid; r < I; r += nthr) {
                 const double v = k < 4 ? s_dR[r * 4 + k] : (double)s_cnt[r];
