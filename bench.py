@@ -293,6 +293,7 @@ def main():
                     help="N>1 delta all-reduce: library one-shot peer-memory exchange (validated against RCCL first), or torch.distributed/RCCL")
     ap.add_argument("--exchange-form", choices=["auto", "light", "fenced"], default="auto",
                     help="peer-memory exchange protocol form: light (sc0 sc1 accesses + s_waitcnt) only if it validates on this topology, else fenced")
+    ap.add_argument("--inject-proof-failure", action="store_true", help="testing: treat the first sharded proof as failed, to exercise the fallback from the peer exchange to torch.distributed")
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: all ranks use device 0, the process group is gloo (RCCL refuses two ranks on one device)")
@@ -369,20 +370,39 @@ def main():
     # N > 1: before anything is timed, prove the sharded pipeline on THIS topology -- 10 iterations over `world` ranks must give
     # the tables of the same 10 iterations (same global traversal ids) on one GPU, up to the summation order of the rank deltas
     sharded_check = None
-    if use_dist:
-        run(10)
+
+    def prove_sharded():
+        """True on every rank iff 10 sharded iterations ran without a wait timing out and rank 0 found the one-GPU tables."""
+        ok = 1
+        try:
+            run(10)
+        except Exception as e:                                   # SCOPA_ETIMEOUT: a peer's rows did not arrive within the budget
+            print(f"[bench rank {rank}] sharded proof run failed: {e}", file=sys.stderr, flush=True)
+            ok = 0
         fence()
-        Rn, Sn, _ = ctx.tables_get()
-        if rank == 0:
+        if ok and rank == 0:
+            Rn, Sn, _ = ctx.tables_get()
             ref = _lib.Context(local_rank)
             ref.set_deal(perm)
             ref.mccfr_seed(0x5C09A)
             ref.mccfr_iterate(batch_total, 10)
             R1, S1, _ = ref.tables_get()
             ref.close()
-            sharded_check = bool(np.allclose(Rn, R1, rtol=1e-10, atol=1e-10) and np.allclose(Sn, S1, rtol=1e-10, atol=1e-10))
-        ctx.tables_reset()
+            ok = int(np.allclose(Rn, R1, rtol=1e-10, atol=1e-10) and np.allclose(Sn, S1, rtol=1e-10, atol=1e-10))
+        t = torch.tensor([ok], dtype=torch.int32, device=coll_dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)                 # every rank learns the verdict: they switch paths together
+        ctx.tables_reset()                                       # zero tables, iteration counter back to 0; the bound delta buffer stays bound (set_deal would drop it)
         fence()
+        return bool(t.item())
+
+    if use_dist:
+        sharded_check = prove_sharded() and not args.inject_proof_failure
+        if not sharded_check and ctx.exchange == "p2p" and args.exchange == "auto":
+            # the peer exchange passed its connect-time validation but not the solver-level proof on this topology: drop it, take the
+            # torch.distributed all-reduce (split path) and prove that instead -- a slower valid number beats none
+            ctx.exchange, ctx.exchange_note = "rccl", (ctx.exchange_note + "; dropped after the 10-iteration proof failed, fell back to torch.distributed").lstrip("; ")
+            drv = ShardedMCCFR(ctx, rank, world, ctx.collective_all_reduce, fused_exchange=False, always_exchange=True)
+            sharded_check = prove_sharded()
 
     # ---- (1) pre-phase: >= PRE_PHASE_S of iterations, the same count on every rank (calibrated, max over ranks) ----------------
     run(50)

@@ -163,6 +163,7 @@ def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl", 
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)
 
     ctx.exchange, ctx.exchange_note, ctx.exchange_form = ("rccl" if world > 1 else "none"), "", None
+    ctx.collective_all_reduce = all_reduce   # the torch.distributed path, kept reachable as the fallback when a connected peer exchange is dropped later
     if world > 1 and exchange in ("auto", "p2p"):
         ok, why = connect_peer_exchange(ctx, rank, dist.get_world_size(), torch.device(f"cuda:{local_rank}"), form=exchange_form)
         ctx.exchange_note = why

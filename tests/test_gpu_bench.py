@@ -48,6 +48,17 @@ def test_bench_spawns_its_own_ranks(ctx):
     assert d["decision_visits"] == 463 * 1024 * 5 * d["timing"]["regions"]
 
 
+@pytest.mark.parametrize("extra", [["--exchange", "rccl"], ["--inject-proof-failure"]])
+def test_bench_two_ranks_through_the_collective(ctx, extra):
+    """The split path traverse | torch.distributed all-reduce | apply on two ranks -- chosen outright, and as the fallback bench.py
+    takes when a connected peer exchange does not pass the 10-iteration proof (injected here): valid lines with identical replicas."""
+    d = _bench("--gpus", "2", "--share-gpu", "--steps", "5", "--warmup", "2", "--regions", "3", "--pre-phase-s", "0.05", "--batch", "512", "--no-cpu-baseline", *extra)
+    c = d["config"]
+    assert c["exchange"] == "rccl" and c["replicas_bit_identical"] is True and c["sharded_10_iterations_match_one_gpu"] is True
+    assert ("fell back" in c["exchange_note"]) == (extra == ["--inject-proof-failure"])
+    assert d["decision_visits"] == 463 * 1024 * 5 * d["timing"]["regions"]
+
+
 def test_bench_sdcfr_workload(ctx):
     d = _bench("--workload", "sdcfr", "--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline")
     assert d["dtype"] == "f32" and d["decision_visits"] == (105 + 82) * 256 * 3
