@@ -196,6 +196,10 @@ struct NodeRegs {
 // where ply d's node records start in ws.npk, and the slot of node (traverser, j) of ply d
 __host__ __device__ constexpr int npk_offset(int d) { return d == 0 ? 0 : d == 1 ? 2 : d == 2 ? 8 : d == 3 ? 18 : d == 4 ? 43 : 86; }
 __host__ __device__ constexpr int npk_slot(int trav, int d, int j) { return npk_offset(d) + (trav ? task_nodes(0, d) : 0) + j; }
+static_assert(npk_offset(1) == task_nodes(0, 0) + task_nodes(1, 0) && npk_offset(2) == npk_offset(1) + task_nodes(0, 1) + task_nodes(1, 1) &&
+              npk_offset(3) == npk_offset(2) + task_nodes(0, 2) + task_nodes(1, 2) && npk_offset(4) == npk_offset(3) + task_nodes(0, 3) + task_nodes(1, 3) &&
+              npk_offset(4) + task_nodes(0, 4) + task_nodes(1, 4) <= npk_offset(5) && npk_offset(5) + task_nodes(0, 5) + task_nodes(1, 5) == 166,
+              "record slots of plies 0..5 tile WaveScratch::npk");
 
 // The update step's static knowledge, one row of 6 uint16 per update lane x (0..51: traverser x / 26, level m, node j): for every ply
 // q above the node the ws.npk slot of its ancestor there (low byte) and the action that leads from that ancestor towards the node if

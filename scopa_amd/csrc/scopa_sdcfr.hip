@@ -323,6 +323,9 @@ struct SdWave {               // per-wavefront scratch
                               // <= 24, 24, 24, 24 wide (either traverser) -- packed, so that SIXTEEN wavefronts fit beside the two nets: 4 per SIMD
 };
 __host__ __device__ constexpr int idx_at(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 9 : d == 4 ? 21 : d == 5 ? 33 : d == 6 ? 57 : d == 7 ? 81 : 105; }
+static_assert(idx_at(1) - idx_at(0) >= 1 && idx_at(2) - idx_at(1) >= 4 && idx_at(3) - idx_at(2) >= 4 && idx_at(4) - idx_at(3) >= 12 && idx_at(5) - idx_at(4) >= 12 &&
+              idx_at(6) - idx_at(5) >= 24 && idx_at(7) - idx_at(6) >= 24 && idx_at(8) - idx_at(7) >= 24 && idx_at(8) + 24 <= 136,
+              "every ply's frontier (widest over the two traversers) fits its slice of SdWave::idx");
 static_assert(sizeof(SdWave) % 16 == 0, "SdWave alignment");
 
 __device__ __forceinline__ void sd_sync() {
