@@ -154,7 +154,7 @@ k_cfr_exact(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g
 
 // ---- the scheduled form: whole-tree traversals of one deal -------------------------------------------------------------------
 namespace {
-constexpr int kSchedThreads = 512;     // 128 events per pass: a quad of lanes per event, one lane per action slot
+constexpr int kSchedThreads = 256;     // 64 events per pass: a quad of lanes per event, one lane per action slot (one wavefront per SIMD: 0.099 s per 1000 iterations of the seed-42 deal; 128 threads 0.108, 512 0.107, 1024 0.162)
 
 // value of lane K (0..3) of the caller's quad (4 consecutive lanes), for every lane of the quad: two DPP moves, no LDS
 template <int K>
