@@ -182,7 +182,7 @@ def main_sdcfr(args):
         for p in range(2):
             d._traverse_batch(p, batch)
             with torch.cuda.stream(d._stream):
-                d.advantage_nets[p].train(epochs=epochs)
+                d.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
             d._stream.synchronize()
         d._iteration += 1
 
@@ -244,7 +244,7 @@ def main_sdcfr(args):
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[{3 if world == 1 else 4}]: SDCFR on MiniScopa, {batch} external-sampling traversals per player per iteration per GPU "
-                                      f"(k_sdcfr_traverse fills the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch 128 per player on PyTorch-ROCm",
+                                      f"(k_sdcfr_traverse fills the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch {args.sdcfr_train_batch} per player on PyTorch-ROCm",
                           "batch_per_gpu": batch, "global_batch": batch * world, "iterations": args.steps,
                           "parallelism": f"dp{world}" + (" + 1 gradient all-reduce of 55104 B per optimiser step (RCCL)" if world > 1 else ""),
                           "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)",
@@ -285,6 +285,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed iterations (default 100 for mccfr, 3 for sdcfr)")
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
     ap.add_argument("--sdcfr-epochs", type=int, default=5, help="Adam steps per player per iteration (sdcfr workload)")
+    ap.add_argument("--sdcfr-train-batch", type=int, default=128, help="rows per Adam step (sdcfr workload; the reference trains on 128, SURVEY 8d also asks for a scaled setting of 4096)")
     ap.add_argument("--regions", type=int, default=REGIONS, help="how many times the --steps region is timed (median reported)")
     ap.add_argument("--pre-phase-s", type=float, default=PRE_PHASE_S, help="seconds of untimed iterations before anything is timed (0 for profiler passes that count every dispatch)")
     ap.add_argument("--prof-stride", type=int, default=0, help="bracket every n-th traversal launch with HIP events (0 = so that >= 64 launches are timed)")

@@ -61,6 +61,61 @@ class DeviceMemory:
         return f[0].cpu().numpy(), r[0].cpu().numpy(), m[0].cpu().numpy()
 
 
+_RAW = {}   # the first 32-bit outputs of random.Random() after seed(42) and one 16-element shuffle: the stream every train() call starts from
+
+
+def reference_sample_stream(n, k, calls, rng=None):
+    """`calls` successive `random.sample(range(n), k)` draws from the stream described in AdvantageNetwork.sample_indices, as an int64
+    array [calls, k] -- the same indices CPython's `random` produces, computed with numpy (a 128-sample costs CPython 40 us, 4096 samples
+    1.3 ms, ten times per iteration).  CPython 3.10 `sample`: with n above its set-size threshold, pick i = the next `_randbelow(n)` not
+    picked before; `_randbelow(n)` = the next `getrandbits(n.bit_length())` below n; `getrandbits(b <= 32)` = one MT19937 output >> (32 - b).
+    So a sample is the first k DISTINCT accepted values of the raw stream, in order.  Small n (the pool branch of `sample`) and streams
+    longer than the cached prefix go through `rng` itself (which must then be in the state seed(42) + shuffle(16) leaves)."""
+    import math
+    setsize = 21 + (4 ** math.ceil(math.log(k * 3, 4)) if k > 5 else 0)
+    if not 0 < k <= n:
+        raise ValueError("Sample larger than population or is negative")
+    def slow():
+        r = rng
+        if r is None:
+            r = random.Random(); r.seed(42); r.shuffle(list(range(16)))
+        return np.array([r.sample(range(n), k) for _ in range(calls)], dtype=np.int64)
+    if n <= setsize or n.bit_length() > 32:
+        return slow()
+    if "raw" not in _RAW:
+        r = random.Random(); r.seed(42); r.shuffle(list(range(16)))
+        _RAW["raw"] = np.array([r.getrandbits(32) for _ in range(1 << 17)], dtype=np.uint64)
+    raw, shift = _RAW["raw"], np.uint64(32 - n.bit_length())
+    prefix = min(len(raw), max(1024, 4 * k * calls))        # acceptance is >= 1/2: 4 k calls raw values almost always suffice
+    while True:
+        vals = raw[:prefix] >> shift
+        pos_ok = np.flatnonzero(vals < n)                   # stream positions whose value _randbelow accepts
+        acc = vals[pos_ok].astype(np.int64)
+        out, start, short = np.empty((calls, k), np.int64), 0, False   # start: index into the accepted values where the next call begins
+        for c in range(calls):
+            width = k + (3 * k * k) // (2 * n) + 64          # k picks meet ~k^2 / 2n repeats
+            while True:
+                seg = acc[start:start + width]
+                _, first = np.unique(seg, return_index=True) # first occurrence of every distinct value within the segment
+                if len(first) >= k:
+                    break
+                if start + width >= len(acc):
+                    short = True
+                    break
+                width *= 2
+            if short:
+                break
+            first.sort()
+            take = first[:k]
+            out[c] = seg[take]
+            start += int(take[-1]) + 1                       # the next call goes on behind the k-th pick (rejected raw values in between are skipped either way)
+        if not short:
+            return out
+        if prefix == len(raw):
+            return slow()                                    # beyond the cached stream (huge k x calls): CPython does it
+        prefix = min(len(raw), prefix * 4)
+
+
 class AdvantageNetwork:
     """Advantage net + Adam + memory for one player (deep_cfr.py:24-116)."""
 
@@ -130,7 +185,7 @@ class AdvantageNetwork:
         """All `epochs` index batches of one train() call in ONE upload ([epochs, batch] ring rows): the reference draws them one after
         the other from the same `random` stream (:88), so drawing them up front gives the same batches; a per-step list -> device copy
         made the optimiser step host-bound."""
-        idx = torch.tensor([self.sample_indices(n, batch_size) for _ in range(epochs)], dtype=torch.long, device=self.device)
+        idx = torch.from_numpy(reference_sample_stream(n, batch_size, epochs, self._rng)).to(self.device)
         return self.buffer.logical_to_physical(idx)
 
     def _step(self, rows):
