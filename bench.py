@@ -180,7 +180,7 @@ def main_sdcfr(args):
 
     def step():
         for p in range(2):
-            d._traverse_batch(p, batch)
+            d._traverse_batch(p, batch, sync=False)
             with torch.cuda.stream(d._stream):
                 d.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
             d._stream.synchronize()

@@ -359,18 +359,37 @@ class DeepCFR:
         return mask
 
     # ---- the traversal ----------------------------------------------------------------------------------------------
-    def _packed_weights(self):
-        """Both players' nets as the fused kernel wants them: per net W1^T | b1 | W2^T | b2 | W3^T | b3 (float32)."""
-        parts = []
-        for a in self.advantage_nets:
-            sd = a.net.state_dict()
-            for w, b in (("backbone.0.fc.weight", "backbone.0.fc.bias"), ("backbone.1.fc.weight", "backbone.1.fc.bias"),
-                         ("head.weight", "head.bias")):
-                parts += [sd[w].t().reshape(-1), sd[b].reshape(-1)]
-        return torch.cat(parts).to(torch.float32).contiguous()
+    _PACK_KEYS = (("backbone.0.fc.weight", "backbone.0.fc.bias"), ("backbone.1.fc.weight", "backbone.1.fc.bias"), ("head.weight", "head.bias"))
 
-    def _traverse_batch_fused(self, player, batch, uniforms=None):
-        """One launch: k_sdcfr_traverse (one wavefront per traversal, both MLPs in LDS)."""
+    def _packed_weights(self):
+        """Both players' nets as the fused kernel wants them: per net W1^T | b1 | W2^T | b2 | W3^T | b3 (float32), in one persistent
+        buffer.  A net's half is rebuilt with TWO launches (concatenate its six tensors, gather them through a fixed permutation) and
+        only when the net has changed since (its parameters' version counters: an optimiser step, a load_state_dict) -- it used to be
+        thirteen small copy kernels per traversal launch for both nets."""
+        if getattr(self, "_wpack", None) is None:
+            perm, off = [], 0
+            sd = self.advantage_nets[0].net.state_dict()
+            for w, b in self._PACK_KEYS:
+                o, i = sd[w].shape
+                perm.append(off + (torch.arange(i).view(i, 1) + torch.arange(o).view(1, o) * i).reshape(-1))   # W^T[k][unit] = W[unit][k]
+                off += o * i
+                perm.append(off + torch.arange(o))
+                off += o
+            self._wperm = torch.cat(perm).to(self.device)
+            self._wpack = torch.empty((len(self.advantage_nets), off), dtype=torch.float32, device=self.device)
+            self._wver = [None] * len(self.advantage_nets)
+        for p, a in enumerate(self.advantage_nets):
+            sd = a.net.state_dict()
+            tensors = [sd[k] for pair in self._PACK_KEYS for k in pair]
+            ver = tuple((t.data_ptr(), t._version) for t in tensors)
+            if ver != self._wver[p]:
+                torch.index_select(torch.cat([t.reshape(-1) for t in tensors]).to(torch.float32), 0, self._wperm, out=self._wpack[p])
+                self._wver[p] = ver
+        return self._wpack
+
+    def _traverse_batch_fused(self, player, batch, uniforms=None, sync=True):
+        """One launch: k_sdcfr_traverse (one wavefront per traversal, both MLPs in LDS).  sync=False leaves the launch on the solver's
+        stream (the training loop: the host goes on to draw the training batches while the kernel runs)."""
         ctx, dev = self._engine.ctx, self.device
         mem = self.advantage_nets[player].buffer
         with torch.cuda.stream(self._stream), torch.no_grad():
@@ -393,17 +412,18 @@ class DeepCFR:
                 e1.record(self._stream)
                 timed.append((e0, e1))
             mem.advance(batch * ROWS_PER_TRAVERSAL)
-        self._stream.synchronize()
+        if sync:
+            self._stream.synchronize()
         return vals
 
-    def _traverse_batch(self, player, batch, uniforms=None, advantage_fn=None, fused=None):
+    def _traverse_batch(self, player, batch, uniforms=None, advantage_fn=None, fused=None, sync=True):
         """`batch` external-sampling traversals for `player` from the root; returns the root values [batch] (float32).
         uniforms: optional {ply: float64 tensor [n]} of draws for the opponent plies (replay / tests);
         advantage_fn(cur_player, feats, mask) -> raw advantages, default the current nets (forces the ply-by-ply path)."""
         if fused is None:
             fused = self.fused_traversal
         if fused and advantage_fn is None:
-            return self._traverse_batch_fused(player, batch, uniforms)
+            return self._traverse_batch_fused(player, batch, uniforms, sync=sync)
         ctx, dev = self._engine.ctx, self.device
         mem = self.advantage_nets[player].buffer
         with torch.cuda.stream(self._stream), torch.no_grad():
@@ -485,11 +505,12 @@ class DeepCFR:
         for iteration in range(iterations):
             iteration_losses, iteration_values = [], []
             for player in range(self.num_players):
-                vals = self._traverse_batch(player, self.batch)
-                value = float(vals.mean().item())
+                vals = self._traverse_batch(player, self.batch, sync=False)
                 with torch.cuda.stream(self._stream):
                     loss = self.advantage_nets[player].train(epochs=advantage_epochs)
+                    mean_value = vals.mean()
                 self._stream.synchronize()
+                value = float(mean_value.item())
                 iteration_losses.append(loss)
                 iteration_values.append(value)
                 self.training_history["losses"][player].append(loss)

@@ -294,3 +294,33 @@ def test_traversal_batch_with_device_draws_vs_oracle(dcfr, oracle, trav):
         assert np.array_equal(f.cpu().numpy(), feat) and np.array_equal(m.cpu().numpy(), mask), fused
         np.testing.assert_allclose(r.cpu().numpy(), reg, atol=ATOL, rtol=0)
         np.testing.assert_allclose(vals.cpu().numpy(), ovals, atol=ATOL, rtol=0)
+
+
+def test_packed_weights_follow_the_nets(ctx):
+    """The persistent W^T | b buffer the fused kernel reads is rebuilt exactly when a net changed: after optimiser steps (plain and
+    graph-replayed) and after load_state_dict it equals a fresh pack of the nets' tensors."""
+    import torch
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+
+    def fresh(d):
+        parts = []
+        for a in d.advantage_nets:
+            sd = a.net.state_dict()
+            for w, b in (("backbone.0.fc.weight", "backbone.0.fc.bias"), ("backbone.1.fc.weight", "backbone.1.fc.bias"), ("head.weight", "head.bias")):
+                parts += [sd[w].t().reshape(-1), sd[b].reshape(-1)]
+        return torch.cat(parts).reshape(2, -1)
+
+    for graph in (False, True):
+        torch.manual_seed(3)
+        d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=64, graph_training=graph)
+        assert torch.equal(d._packed_weights(), fresh(d))
+        for p in (0, 1):
+            d._traverse_batch(p, 64)
+        before = d._packed_weights().clone()
+        d.advantage_nets[1].train(batch_size=128, epochs=2)
+        torch.cuda.synchronize()
+        now = d._packed_weights()
+        assert torch.equal(now, fresh(d)) and torch.equal(now[0], before[0]) and not torch.equal(now[1], before[1])
+        d.advantage_nets[0].net.load_state_dict(d.advantage_nets[1].net.state_dict())
+        assert torch.equal(d._packed_weights(), fresh(d)) and torch.equal(d._packed_weights()[0], d._packed_weights()[1])
