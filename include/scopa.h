@@ -186,13 +186,25 @@ int32_t scopa_sdcfr_backward(scopa_ctx *ctx, int32_t ply, int32_t traverser, int
                              const float *d_child_val, float *d_val, const float *d_feats, const float *d_mask, float *d_mem_feat,
                              float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base);
 int32_t scopa_sdcfr_visits(scopa_ctx *ctx, uint64_t *decision_visits);
-/* The same traversal as ONE launch: one wavefront per traversal, both players' advantage MLPs (34-128-64-16 float32) resident
- * in LDS and evaluated in-kernel.  d_weights[2][13776]: per player W1^T[34][128] | b1[128] | W2^T[128][64] | b2[64] |
- * W3^T[64][16] | b3[16].  d_uniforms (optional, tests): [batch][8][24] float64 draws indexed (traversal, ply, slot).
+/* The same traversal as ONE launch: a wavefront walks four traversals together, both players' advantage MLPs (34-128-64-16
+ * float32) resident in LDS and evaluated in-kernel on the matrix cores, sixteen frontier nodes per tile.
+ * d_image[2][SCOPA_SDCFR_IMAGE_FLOATS]: per player the net as scopa_sdcfr_pack_weights lays it out (the operand layout of
+ * v_mfma_f32_16x16x4_f32; the kernel copies it to LDS as it is).  d_uniforms (optional, tests): [batch][8][24] float64 draws
+ * indexed (traversal, ply, slot).  d_mem_feat must be 8-byte, d_mem_regret / d_mem_mask 16-byte aligned.
  * Samples the same actions as the ply-by-ply path (same Philox keying); float32 sums run in a different order. */
-int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_weights, float *d_mem_feat,
+#define SCOPA_SDCFR_IMAGE_FLOATS 13520
+int32_t scopa_sdcfr_image_floats(void);
+/* One advantage net (AdvantageNetwork.net = FlexibleNet(mode="mlp"), nets.py:296-331; torch tensors, row-major W[out][in]:
+ * backbone.0.fc.weight [128][34] / .bias [128], backbone.1.fc.weight [64][128] / .bias [64], head.weight [16][64] / .bias [16],
+ * all float32 device pointers) -> player's half of d_image.  One small launch on the context's stream; call it again
+ * whenever the net changed (an optimiser step, load_state_dict). */
+int32_t scopa_sdcfr_pack_weights(scopa_ctx *ctx, int32_t player, const float *d_w1, const float *d_b1, const float *d_w2,
+                                 const float *d_b2, const float *d_w3, const float *d_b3, float *d_image);
+int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_image, float *d_mem_feat,
                                    float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
                                    float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0);
+/* experiments: traversals a wavefront of the fused kernel walks together (0 = the library's choice, 2 or 4) */
+int32_t scopa_sdcfr_tile_traversals(scopa_ctx *ctx, int32_t traversals_per_wavefront);
 /* features / masks of arbitrary device-resident states for the player to move (DeepCFR.get_policy, :497-504) */
 int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask);
 /* batched evaluation episodes (evaluate_vs_random :367-429; evaluate_agent vanilla_cfr.py:157-216): n copies of the deal's

@@ -138,6 +138,14 @@ class AdvantageNetwork:
         self.buffer = DeviceMemory(memory_size, input_dim, device)
         self._rng = random.Random()
         self.grad_sync = None  # set by DeepCFR for N>1: callable(parameters) averaging the gradients over ranks
+        # Counts the events that change the net's weights THROUGH THIS CLASS: every train() call (eager or graph-replayed -- a
+        # replayed HIP graph updates the parameters without touching their autograd version counters) and every load_state_dict.
+        # DeepCFR keys the traversal kernel's packed weight image on it.
+        self.weights_epoch = 0
+        self.net.register_load_state_dict_post_hook(lambda module, incompatible: self._weights_changed())
+
+    def _weights_changed(self):
+        self.weights_epoch += 1
 
     def get_advantages(self, state_features, legal_actions_mask):
         with torch.no_grad():
@@ -173,6 +181,7 @@ class AdvantageNetwork:
                 return 0.0
         self._rng.seed(42)
         self._rng.shuffle(list(range(16)))
+        self._weights_changed()
         if self.use_graph and self.grad_sync is None:
             return self._train_graphed(n, batch_size, epochs)
         rows_all = self._sample_rows(n, batch_size, epochs)
@@ -359,36 +368,31 @@ class DeepCFR:
         return mask
 
     # ---- the traversal ----------------------------------------------------------------------------------------------
-    _PACK_KEYS = (("backbone.0.fc.weight", "backbone.0.fc.bias"), ("backbone.1.fc.weight", "backbone.1.fc.bias"), ("head.weight", "head.bias"))
+    _PACK_KEYS = ("backbone.0.fc.weight", "backbone.0.fc.bias", "backbone.1.fc.weight", "backbone.1.fc.bias", "head.weight", "head.bias")
 
     def _packed_weights(self):
-        """Both players' nets as the fused kernel wants them: per net W1^T | b1 | W2^T | b2 | W3^T | b3 (float32), in one persistent
-        buffer.  A net's half is rebuilt with TWO launches (concatenate its six tensors, gather them through a fixed permutation) and
-        only when the net has changed since (its parameters' version counters: an optimiser step, a load_state_dict) -- it used to be
-        thirteen small copy kernels per traversal launch for both nets."""
+        """Both players' nets as the fused kernel keeps them in LDS (`scopa_sdcfr_pack_weights`: the operand layout of the
+        16x16x4 MFMA), in one persistent buffer [2][13520].  A net's half is rebuilt -- ONE small launch -- only when the net
+        has changed: `AdvantageNetwork.weights_epoch` counts train() calls (a replayed HIP graph updates the parameters without
+        bumping their autograd version counters, so those alone would leave the image stale from the second graphed train()
+        on) and load_state_dict; the parameters' storage and version counters catch in-place edits made around the class."""
+        ctx = self._engine.ctx
         if getattr(self, "_wpack", None) is None:
-            perm, off = [], 0
-            sd = self.advantage_nets[0].net.state_dict()
-            for w, b in self._PACK_KEYS:
-                o, i = sd[w].shape
-                perm.append(off + (torch.arange(i).view(i, 1) + torch.arange(o).view(1, o) * i).reshape(-1))   # W^T[k][unit] = W[unit][k]
-                off += o * i
-                perm.append(off + torch.arange(o))
-                off += o
-            self._wperm = torch.cat(perm).to(self.device)
-            self._wpack = torch.empty((len(self.advantage_nets), off), dtype=torch.float32, device=self.device)
+            self._wpack = torch.empty((len(self.advantage_nets), _lib.lib().scopa_sdcfr_image_floats()), dtype=torch.float32, device=self.device)
             self._wver = [None] * len(self.advantage_nets)
         for p, a in enumerate(self.advantage_nets):
             sd = a.net.state_dict()
-            tensors = [sd[k] for pair in self._PACK_KEYS for k in pair]
-            ver = tuple((t.data_ptr(), t._version) for t in tensors)
+            tensors = [sd[k] for k in self._PACK_KEYS]
+            ver = (a.weights_epoch,) + tuple((t.data_ptr(), t._version) for t in tensors)
             if ver != self._wver[p]:
-                torch.index_select(torch.cat([t.reshape(-1) for t in tensors]).to(torch.float32), 0, self._wperm, out=self._wpack[p])
+                if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
+                    tensors = [t.to(torch.float32).contiguous() for t in tensors]
+                ctx.sdcfr_pack_weights(p, *(t.data_ptr() for t in tensors), self._wpack.data_ptr())
                 self._wver[p] = ver
         return self._wpack
 
     def _traverse_batch_fused(self, player, batch, uniforms=None, sync=True):
-        """One launch: k_sdcfr_traverse (one wavefront per traversal, both MLPs in LDS).  sync=False leaves the launch on the solver's
+        """One launch: k_sdcfr_traverse (four traversals per wavefront, both MLPs in LDS, forward pass on the matrix cores).  sync=False leaves the launch on the solver's
         stream (the training loop: the host goes on to draw the training batches while the kernel runs)."""
         ctx, dev = self._engine.ctx, self.device
         mem = self.advantage_nets[player].buffer

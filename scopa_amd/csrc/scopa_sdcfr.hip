@@ -293,288 +293,317 @@ int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const 
 
 // =====================================================================================================================
 // Fused traversal: ONE launch per traversal batch instead of ~65 (8 plies x {features, 3 GEMMs + activations, expand} +
-// 8 backward steps).  One WAVEFRONT walks one traversal level-synchronously; both players' advantage MLPs
-// (34-128-64-16, float32, 13 776 parameters = 55 KB each) sit in LDS for the whole launch and the forward pass of the
-// <= 24 frontier nodes of a ply runs inside the wave, kG = 4 nodes at a time, on the matrix cores (v_mfma_f32_4x4x1: 16
-// independent 4x4 outer products per instruction -- 4 hidden units x 4 nodes per lane quad):
-//   layer 1  K = 32 dense 0/1 inputs built from the node's hand/table bit masks (a zero input adds an exact zero), bias and
-//            the constant-1 feature's column as the initial accumulator, 128 units = two halves of 16 blocks
-//   layer 2  K = 128, 64 units = 16 blocks; per four inputs two 16-byte LDS reads (weights and activations both kept as
-//            k-quads) and four MFMAs
-//   layer 3  K = 64, 16 outputs = 4 blocks x 4 K-splits, partial sums added with two cross-lane shuffles; regret matching
-//            (sum of relu(adv)*mask over a node's 16 outputs) stays in the accumulator layout
+// 8 backward steps).  Both players' advantage MLPs (34-128-64-16, float32) sit in LDS for the whole launch and the forward
+// pass runs on the matrix cores with v_mfma_f32_16x16x4_f32 on tiles of SIXTEEN frontier nodes:
+//
+//   * a WAVEFRONT walks T traversals together (T = 4: frontier widths 4,16,16,48,48,96,96 -> 21 tiles at 96 % fill; one
+//     traversal alone is 1,4,4,12,12,24,24 wide and would leave most of a 16-node tile empty), level-synchronously;
+//   * MFMA roles: rows i = units (weights = A operand), columns j = nodes (activations = B operand).  The result layout of
+//     this instruction -- lane l, register r holds row 4*(l/16)+r of column l%16 -- is exactly its B-operand layout for a
+//     K-step that covers the four units {4q + r : q = 0..3}: so the 32 accumulator registers of layer 1 ARE the B operands of
+//     layer 2's 32 K-steps and the 16 of layer 2 are layer 3's.  Activations never leave the registers; the only LDS traffic
+//     of the forward pass is the weights, as one conflict-free 16-byte read per lane per four MFMAs (the weight image is laid
+//     out for that by k_sdcfr_pack: scopa_sdcfr_pack_weights);
+//   * per 16-node tile: 64 + 128 + 16 MFMAs (8, 4 and 2 independent accumulator chains), 16 + 32 + 4 weight reads, 12 bias
+//     reads.  The round-2 kernel (v_mfma_f32_4x4x1, four nodes per group, activations through LDS) needed one 16-byte LDS
+//     read per MFMA and its matrix-core time equalled its LDS-array time; this form reads 6.4 x less per FLOP.
+//   layer 1  K = 32 dense 0/1 inputs from the node's hand/table bit masks (a zero input adds an exact zero); the bias and the
+//            constant-1 feature's column are the initial accumulator (feature 33 is always 0)
+//   layer 2  K = 128, 64 units; layer 3  K = 64, 16 outputs; regret matching (sum of relu(adv)*mask over a node's 16 outputs)
+//            in the accumulator layout + two cross-lane adds
 // Opponent nodes with a single legal action skip the forward pass: their child is forced and nothing else of them is used.
-// then expand / sample exactly as k_sdcfr_expand does (same Philox keying, so the two paths sample identical actions), and
-// after ply 7 the values flow back up inside the wave with the memory rows written straight to the caller's ring.
-// Weights per net, as one float32 buffer: W1^T [34][128] | b1 [128] | W2^T [128][64] | b2 [64] | W3^T [64][16] | b3 [16].
+// Expansion / sampling is exactly k_sdcfr_expand's (same Philox keying, so the two paths sample identical actions); after
+// ply 7 the values flow back up inside the wave and the memory rows go straight to the caller's ring (8- / 16-byte stores).
 namespace {
-constexpr int kNetFloats = 34 * 128 + 128 + 128 * 64 + 64 + 64 * 16 + 16;  // 13 776
-constexpr int kW1 = 0, kB1 = 34 * 128, kW2 = kB1 + 128, kB2 = kW2 + 128 * 64, kW3 = kB2 + 64, kB3 = kW3 + 64 * 16;
+// the net image in LDS, per player (float32), written by k_sdcfr_pack from the torch tensors W[out][in]:
+constexpr int kImgW1 = 0;                 // [8 mt][2 g][64 lanes][4 c] : W1[16 mt + lane%16][4 (4g + c) + lane/16]       4096
+constexpr int kImgC1 = kImgW1 + 4096;     // [128]                      : b1[u] + W1[u][32]  (feature 32 is the constant 1)  128
+constexpr int kImgW2 = kImgC1 + 128;      // [4 nt][8 mt][64 lanes][4 r]: W2[16 nt + lane%16][16 mt + 4 (lane/16) + r]     8192
+constexpr int kImgB2 = kImgW2 + 8192;     // [64]                                                                            64
+constexpr int kImgW3 = kImgB2 + 64;       // [4 nt][64 lanes][4 r]      : W3[lane%16][16 nt + 4 (lane/16) + r]             1024
+constexpr int kImgB3 = kImgW3 + 1024;     // [16]                                                                            16
+constexpr int kImgFloats = kImgB3 + 16;   // 13 520 (the 13 776 parameters less W1's columns 32, 33)
+static_assert(kImgFloats == SCOPA_SDCFR_IMAGE_FLOATS, "include/scopa.h states the image size");
 
-constexpr int kG = 4;         // frontier nodes evaluated together (a "group"); measured: 4 nodes x 10 wavefronts 1.18 ms per iteration, 8 nodes x 6 wavefronts (what LDS then allows) 1.76 ms
-struct SdWave {               // per-wavefront scratch
-    float h1[128][kG];        // hidden layer 1 of the nodes in flight; hidden layer 2 ([64][kG]) takes the first half of the same storage once
-                              // layer 2 has read all of layer 1 (a wavefront's LDS operations execute in order) -- 1 KB less per wavefront
-    float pol_trav[41][4];    // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
-    float val[2][24];
-    float polcur[kG][4];
-    scopa_state st[kG];       // packed states of the nodes in flight
-    uint16_t idx[136];        // tree index of every frontier node, per ply (ply 8 = leaves), at idx_at(ply): the frontier is 1, <= 4, 4, <= 12, 12,
-                              // <= 24, 24, 24, 24 wide (either traverser) -- packed, so that SIXTEEN wavefronts fit beside the two nets: 4 per SIMD
+template <int T>
+struct SdWave {                 // per-wavefront scratch: T traversals in flight
+    float pol_trav[T][41][4];   // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
+    float val[2][T * 24];       // values of the frontier flowing back up (position t * width + j)
+    float pos[16][16];          // relu(adv) * mask of the tile in flight, [node][output]
+    uint32_t ninfo[T * 24][2];  // the current ply's frontier: feature bits | hand nibbles + tree index << 16
+    uint16_t idx[T][136];       // tree index of every frontier node, per ply (ply 8 = leaves), at idx_at(ply): a traversal's frontier is 1, <= 4, 4,
+                                // <= 12, 12, <= 24, 24, 24, 24 wide (either traverser)
 };
 __host__ __device__ constexpr int idx_at(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 9 : d == 4 ? 21 : d == 5 ? 33 : d == 6 ? 57 : d == 7 ? 81 : 105; }
 static_assert(idx_at(1) - idx_at(0) >= 1 && idx_at(2) - idx_at(1) >= 4 && idx_at(3) - idx_at(2) >= 4 && idx_at(4) - idx_at(3) >= 12 && idx_at(5) - idx_at(4) >= 12 &&
               idx_at(6) - idx_at(5) >= 24 && idx_at(7) - idx_at(6) >= 24 && idx_at(8) - idx_at(7) >= 24 && idx_at(8) + 24 <= 136,
               "every ply's frontier (widest over the two traversers) fits its slice of SdWave::idx");
-static_assert(sizeof(SdWave) % 16 == 0, "SdWave alignment");
+static_assert(sizeof(SdWave<4>) % 16 == 0 && sizeof(SdWave<2>) % 16 == 0, "SdWave alignment");
+constexpr int kSdWaves = 8;     // wavefronts per workgroup: two per SIMD (one walks its tiles' matrix phases while the other samples / expands)
 
-__device__ __forceinline__ void sd_sync() {
+__device__ __forceinline__ void sd_sync() {   // a wavefront's LDS operations execute in order: this only stops the compiler (and drains the queue)
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
+
+typedef float v4f __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ v4f to_v4f(float4 x) { v4f r = {x.x, x.y, x.z, x.w}; return r; }
+__device__ __forceinline__ v4f relu4(v4f x) { v4f r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f), fmaxf(x[2], 0.0f), fmaxf(x[3], 0.0f)}; return r; }
 }  // namespace
 
+// feature bits (hand one-hot | table multi-hot << 16) and the mover's hand nibbles of every decision node, BFS order: what a
+// traversal needs of a node's 16-byte state, ready-made (k_sdcfr_features derives them per visit)
+__global__ void __launch_bounds__(256)
+k_sdcfr_nodeinfo(const scopa_state *__restrict__ g_states, uint2 *__restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= kDecision) return;
+    const scopa_state s = g_states[i];
+    const int p = s.step & 1;
+    uint32_t hand_bits = 0, table_bits = 0;
+    for (int k = 0; k < s.nh[p]; k++) hand_bits |= 1u << nib(s.hand[p], k);
+    for (int k = 0; k < s.nt; k++) table_bits |= 1u << nib(s.table, k);
+    out[i] = make_uint2(hand_bits | (table_bits << 16), (uint32_t)s.hand[p]);
+}
+
+// torch tensors (W[out][in] row-major, float32) of one advantage net -> its LDS image (layout above)
+__global__ void __launch_bounds__(256)
+k_sdcfr_pack(const float *__restrict__ w1, const float *__restrict__ b1, const float *__restrict__ w2, const float *__restrict__ b2,
+             const float *__restrict__ w3, const float *__restrict__ b3, float *__restrict__ img) {
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= kImgFloats) return;
+    float v;
+    if (e < kImgC1) {
+        const int mt = e >> 9, g = (e >> 8) & 1, lane = (e >> 2) & 63, c = e & 3;
+        v = w1[(16 * mt + (lane & 15)) * 34 + 4 * (4 * g + c) + (lane >> 4)];
+    } else if (e < kImgW2) {
+        const int u = e - kImgC1;
+        v = b1[u] + w1[u * 34 + 32];
+    } else if (e < kImgB2) {
+        const int i = e - kImgW2, nt = i >> 11, mt = (i >> 8) & 7, lane = (i >> 2) & 63, r = i & 3;
+        v = w2[(16 * nt + (lane & 15)) * 128 + 16 * mt + 4 * (lane >> 4) + r];
+    } else if (e < kImgW3) {
+        v = b2[e - kImgB2];
+    } else if (e < kImgB3) {
+        const int i = e - kImgW3, nt = i >> 8, lane = (i >> 2) & 63, r = i & 3;
+        v = w3[(lane & 15) * 64 + 16 * nt + 4 * (lane >> 4) + r];
+    } else {
+        v = b3[e - kImgB3];
+    }
+    img[e] = v;
+}
+
 #ifdef SCOPA_WALK_STAMPS   // development build only: shader-clock stamps of wavefront 0 of workgroup 0 (tests/tools/sdcfr_stamps.py)
-__device__ unsigned long long g_sd_stamps[16];   // 0 state load | 1 layer 1 | 2 layer 2 | 3 layer 3 + policy | 4 expand / sample | 5 skipped plies | 6 leaves + backward | 7 take | 15 traversals
+__device__ unsigned long long g_sd_stamps[16];   // 0 frontier info | 1 layer 1 | 2 layer 2 | 3 layer 3 + policy | 4 expand / sample | 5 skipped plies | 6 leaves + backward | 7 take | 15 tasks
 #define SD_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_sd_stamps[i] += now_ - sd_prev_; sd_prev_ = now_; } while (0)
 #else
 #define SD_STAMP(i) do { } while (0)
 #endif
 
-__global__ void __launch_bounds__(1024)
-k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_weights,
+template <int T>
+__global__ void __launch_bounds__(kSdWaves * 64)
+k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_image,
                  int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
                  long long capacity, long long write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
                  uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
     extern __shared__ __align__(16) unsigned char smem[];
-    __shared__ int s_next[1];                                               // next traversal of this workgroup not taken yet
-    float *s_w = reinterpret_cast<float *>(smem);                           // [2][kNetFloats]
-    SdWave *s_wave = reinterpret_cast<SdWave *>(s_w + 2 * kNetFloats);      // [wavefronts]
+    __shared__ int s_next[1];                                               // next task of this workgroup not taken yet
+    float *s_w = reinterpret_cast<float *>(smem);                           // [2][kImgFloats]
+    SdWave<T> *s_wave = reinterpret_cast<SdWave<T> *>(s_w + 2 * kImgFloats);   // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     if (tid == 0) s_next[0] = n_waves;
-    for (int i = tid; i < 2 * kNetFloats / 4; i += blockDim.x)
-        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_weights)[i];
+    for (int i = tid; i < 2 * kImgFloats / 4; i += blockDim.x)
+        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image)[i];
     __syncthreads();
-    // The three weight matrices are kept as k-QUADS, Wq[k/4][unit][k%4] (the buffer holds W^T[k][unit]), so that a lane fetches
-    // its unit's weights for four inputs with one 16-byte, conflict-free LDS read -- the A operand of four v_mfma_f32_4x4x1.
-    // In-place permutation through registers: W1 rows 0..31 (rows 32, 33 stay: constant-1 feature, unused feature), W2, W3.
-    {
-        constexpr int kQ1 = 8 * 128, kQ2 = 32 * 64, kQ3 = 16 * 16, kQ = kQ1 + kQ2 + kQ3;   // float4 quads per net
-        constexpr int kPer = (kQ + 511) / 512;                                            // per thread at >= 512 threads
-        float4 t[2][kPer];
-        auto src_of = [&](int net, int e) -> const float * {
-            const float *base = s_w + net * kNetFloats;
-            if (e < kQ1) return base + kW1 + (e >> 7) * 4 * 128 + (e & 127);
-            e -= kQ1;
-            if (e < kQ2) return base + kW2 + (e >> 6) * 4 * 64 + (e & 63);
-            e -= kQ2;
-            return base + kW3 + (e >> 4) * 4 * 16 + (e & 15);
-        };
-        auto stride_of = [&](int e) { return e < kQ1 ? 128 : e < kQ1 + kQ2 ? 64 : 16; };
-        auto dst_of = [&](int net, int e) -> float4 * {
-            float *base = s_w + net * kNetFloats;
-            if (e < kQ1) return reinterpret_cast<float4 *>(base + kW1) + e;
-            e -= kQ1;
-            if (e < kQ2) return reinterpret_cast<float4 *>(base + kW2) + e;
-            return reinterpret_cast<float4 *>(base + kW3) + (e - kQ2);
-        };
-#pragma unroll
-        for (int net = 0; net < 2; net++)
-#pragma unroll
-            for (int r = 0; r < kPer; r++) {
-                const int e = tid + r * (int)blockDim.x;
-                if (e < kQ) { const float *src = src_of(net, e); const int st = stride_of(e); t[net][r] = make_float4(src[0], src[st], src[2 * st], src[3 * st]); }
-            }
-        __syncthreads();
-#pragma unroll
-        for (int net = 0; net < 2; net++)
-#pragma unroll
-            for (int r = 0; r < kPer; r++) {
-                const int e = tid + r * (int)blockDim.x;
-                if (e < kQ) *dst_of(net, e) = t[net][r];
-            }
-        __syncthreads();
-    }
-    SdWave &ws = s_wave[wave];
+    SdWave<T> &ws = s_wave[wave];
+    const int nj = lane & 15, q = lane >> 4;   // this lane's column (node of the tile) and K / row group
 
-    // The workgroup owns traversals [first, first + count) and its wavefronts TAKE them from a counter in LDS (the first one is
-    // static): 10 wavefronts share 4 SIMDs unevenly and the SIMD's arbiter favours its oldest wavefront, so equal shares would leave
-    // the workgroup waiting for its slowest wavefront (scopa_mccfr.hip, main loop, has the measurement).  Which wavefront walks a
-    // traversal does not matter: draws and memory-row positions are keyed by the traversal id.
-    const int per_wg = (batch + (int)gridDim.x - 1) / (int)gridDim.x;
-    const int first = (int)blockIdx.x * per_wg, count = first < batch ? (batch - first < per_wg ? batch - first : per_wg) : 0;
+    // A TASK is T consecutive traversals (the last one of a batch may be short).  The workgroup owns tasks [first, first + count)
+    // and its wavefronts TAKE them from a counter in LDS (the first one is static): the SIMD's arbiter favours its oldest
+    // wavefront, so equal shares would leave the workgroup waiting for its slowest (scopa_mccfr.hip, main loop, has the
+    // measurement).  Which wavefront walks a traversal does not matter: draws and memory-row positions are keyed by its id.
+    const int n_tasks = (batch + T - 1) / T;
+    const int per_wg = (n_tasks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int first = (int)blockIdx.x * per_wg, count = first < n_tasks ? (n_tasks - first < per_wg ? n_tasks - first : per_wg) : 0;
     for (int c = wave; c < count;) {
-        const int tb = first + c;
+        const int tb0 = (first + c) * T;                                    // the task's first traversal (local id within the batch)
+        const int n_live = batch - tb0 < T ? batch - tb0 : T;               // traversals t >= n_live are walked like the others but write nothing
 #ifdef SCOPA_WALK_STAMPS
         unsigned long long sd_prev_ = clock64();
 #endif
-        if (lane == 0) ws.idx[idx_at(0)] = 0;
+        if (lane < T) ws.idx[lane][idx_at(0)] = 0;
         sd_sync();
-        int width = 1;
+        int width = 1;                                                      // a traversal's frontier width at the current ply
         // ---- forward: plies 0..7 ----------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int d = 0; d < kPlies; d++) {
             const int p = d & 1, nl = 4 - (d >> 1);
             const bool trav_ply = p == traverser;
-            const float *W = s_w + p * kNetFloats;
-            const int m = (d - traverser) >> 1;                       // traverser-ply index when trav_ply
+            const int n_nodes = T * width;                                  // position f = t * width + j
+            const int m = (d - traverser) >> 1;                             // traverser-ply index when trav_ply
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
             if (!trav_ply && nl == 1) {
                 // opponent node with ONE legal action (plies 6/7): whatever the advantages are, regret matching either puts all mass
                 // on it or falls back to uniform over it (deep_cfr.py:353-359) -- the child is forced and nothing else of this
                 // node is used (no memory row, no value weight), so its forward pass is skipped: 24 of the 105 / 82 node
                 // evaluations of a traversal
-                if (lane < width) ws.idx[idx_at(d + 1) + lane] = ws.idx[idx_at(d) + lane];
+                for (int f = lane; f < n_nodes; f += 64) {
+                    int t = 0;
+#pragma unroll
+                    for (int k = 1; k < T; k++) t += f >= k * width;
+                    const int j = f - t * width;
+                    ws.idx[t][idx_at(d + 1) + j] = ws.idx[t][idx_at(d) + j];
+                }
                 sd_sync();
                 SD_STAMP(5);
                 continue;
             }
-            typedef float v4f __attribute__((ext_vector_type(4)));
-            static_assert(kG == 4, "the 4x4x1 mapping serves four nodes per group");
-            // The whole forward pass runs on the matrix cores with v_mfma_f32_4x4x1 (16 independent 4x4 outer products per
-            // instruction, K = 1): block b = lane / 4, A = four units' weights for input k (row i = lane % 4), B = input k of the four
-            // nodes in flight (node j = lane % 4), D[i] of lane (b, j) = unit 4b+i of node j.
-            const int bq = lane >> 2, nj = lane & 3;
-            // layer-1 accumulators start from bias + the constant-1 feature's column (feature 33 is 0.0), per 64-unit half
-            v4f bias1[2];
+            // the ply's frontier: feature bits, hand nibbles and tree index of every node, one global load each (the tiles below read LDS)
+            for (int f = lane; f < n_nodes; f += 64) {
+                int t = 0;
 #pragma unroll
-            for (int h = 0; h < 2; h++)
+                for (int k = 1; k < T; k++) t += f >= k * width;
+                const int j = f - t * width;
+                const uint32_t node = ws.idx[t][idx_at(d) + j];
+                const uint2 inf = g_ninfo[level_offset(d) + (int)node];
+                ws.ninfo[f][0] = inf.x;
+                ws.ninfo[f][1] = inf.y | (node << 16);
+            }
+            sd_sync();
+            SD_STAMP(0);
+            const float *W = s_w + p * kImgFloats;
+            const float4 *w1 = reinterpret_cast<const float4 *>(W + kImgW1) + lane;
+            const float4 *c1 = reinterpret_cast<const float4 *>(W + kImgC1) + q;
+            const float4 *w2 = reinterpret_cast<const float4 *>(W + kImgW2) + lane;
+            const float4 *b2 = reinterpret_cast<const float4 *>(W + kImgB2) + q;
+            const float4 *w3 = reinterpret_cast<const float4 *>(W + kImgW3) + lane;
+            const float4 *b3 = reinterpret_cast<const float4 *>(W + kImgB3) + q;
+#pragma unroll 1
+            for (int f0 = 0; f0 < n_nodes; f0 += 16) {
+                const int f = f0 + nj;
+                const bool live = f < n_nodes;
+                const int fc = live ? f : n_nodes - 1;                      // lanes beyond the frontier compute a copy of its last node and store nothing
+                const uint32_t xbits = ws.ninfo[fc][0], hn = ws.ninfo[fc][1];
+                const uint32_t hand = hn & 0xFFFFu, node = hn >> 16;
+                // ---- layer 1: K-step s = 4 g + c covers features 4 s .. 4 s + 3 (k index = lane / 16) --------------------------
+                v4f h1[8];
 #pragma unroll
-                for (int i = 0; i < 4; i++) bias1[h][i] = W[kB1 + 64 * h + 4 * bq + i] + W[kW1 + 32 * 128 + 64 * h + 4 * bq + i];
-            const float4 *w1q = reinterpret_cast<const float4 *>(W + kW1), *w2q = reinterpret_cast<const float4 *>(W + kW2) + lane;
-            const float4 *w3q = reinterpret_cast<const float4 *>(W + kW3);
-            for (int g0 = 0; g0 < width; g0 += kG) {
-                // the group's packed states: one global load per node, then every lane reads the state of ITS node (lane % 4)
-                if (lane < kG && g0 + lane < width) ws.st[lane] = g_states[level_offset(d) + ws.idx[idx_at(d) + g0 + lane]];
-                sd_sync();
-                SD_STAMP(0);
-                const bool live = g0 + nj < width;
-                const scopa_state sj = ws.st[nj];
-                uint32_t hand_bits = 0, table_bits = 0;
-                if (live) {
+                for (int mt = 0; mt < 8; mt++) h1[mt] = to_v4f(c1[mt * 4]);
+                const uint32_t xs = xbits >> q;
 #pragma unroll
-                    for (int k = 0; k < 4; k++) if (k < sj.nh[p]) hand_bits |= 1u << nib(sj.hand[p], k);
+                for (int g = 0; g < 2; g++) {
+                    float4 w[8];
 #pragma unroll
-                    for (int k = 0; k < 8; k++) if (k < sj.nt) table_bits |= 1u << nib(sj.table, k);
+                    for (int mt = 0; mt < 8; mt++) w[mt] = w1[(mt * 2 + g) * 64];
+                    const float x0 = (float)((xs >> (16 * g)) & 1u), x1 = (float)((xs >> (16 * g + 4)) & 1u);
+                    const float x2 = (float)((xs >> (16 * g + 8)) & 1u), x3 = (float)((xs >> (16 * g + 12)) & 1u);
+#pragma unroll
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].x, x0, h1[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].y, x1, h1[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].z, x2, h1[mt]);
+#pragma unroll
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].w, x3, h1[mt]);
                 }
-                const uint32_t xbits = hand_bits | (table_bits << 16);       // the 32 one-hot features of this lane's node
-                // layer 1: K = 32 dense 0/1 inputs (a zero input adds an exact zero), 128 units = two halves of 16 blocks
-                {
-                    v4f acc0 = bias1[0], acc1 = bias1[1];
 #pragma unroll
-                    for (int kq = 0; kq < 8; kq++) {
-                        const float4 wa = w1q[kq * 128 + lane], wb = w1q[kq * 128 + 64 + lane];
-                        const float x0 = (float)((xbits >> (4 * kq)) & 1u), x1 = (float)((xbits >> (4 * kq + 1)) & 1u);
-                        const float x2 = (float)((xbits >> (4 * kq + 2)) & 1u), x3 = (float)((xbits >> (4 * kq + 3)) & 1u);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.x, x0, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.x, x0, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.y, x1, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.y, x1, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.z, x2, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.z, x2, acc1, 0, 0, 0);
-                        acc0 = __builtin_amdgcn_mfma_f32_4x4x1f32(wa.w, x3, acc0, 0, 0, 0); acc1 = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.w, x3, acc1, 0, 0, 0);
-                    }
-                    // h1 as k-quads for layer 2: h1q[unit / 4][node][unit % 4] -- exactly this lane's accumulator vectors
-                    float4 *h1q = reinterpret_cast<float4 *>(&ws.h1[0][0]);
-                    h1q[bq * 4 + nj] = make_float4(fmaxf(acc0[0], 0.0f), fmaxf(acc0[1], 0.0f), fmaxf(acc0[2], 0.0f), fmaxf(acc0[3], 0.0f));
-                    h1q[(16 + bq) * 4 + nj] = make_float4(fmaxf(acc1[0], 0.0f), fmaxf(acc1[1], 0.0f), fmaxf(acc1[2], 0.0f), fmaxf(acc1[3], 0.0f));
-                }
-                sd_sync();
+                for (int mt = 0; mt < 8; mt++) h1[mt] = relu4(h1[mt]);      // register r of tile mt = unit 16 mt + 4 q + r of node nj
                 SD_STAMP(1);
-                // layer 2: K = 128, 64 units = 16 blocks.  Per four inputs: two 16-byte LDS reads and four MFMAs.
-                {
-                    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f}, accb = {0.0f, 0.0f, 0.0f, 0.0f};   // two independent chains (even / odd k-quads)
-                    const float4 *hq = reinterpret_cast<const float4 *>(&ws.h1[0][0]) + nj;
-#pragma unroll 4
-                    for (int kq = 0; kq < 32; kq += 2) {
-                        const float4 w = w2q[kq * 64], wb = w2q[(kq + 1) * 64];
-                        const float4 h = hq[kq * 4], hb = hq[(kq + 1) * 4];
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, h.x, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.x, hb.x, accb, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, h.y, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.y, hb.y, accb, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, h.z, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.z, hb.z, accb, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0); accb = __builtin_amdgcn_mfma_f32_4x4x1f32(wb.w, hb.w, accb, 0, 0, 0);
-                    }
+                // ---- layer 2: K-step (mt, r) covers the units 16 mt + 4 k + r, k = lane / 16: B operand = h1[mt][r] as it stands -----
+                v4f h2[4];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) acc[i] += accb[i];
-                    // h2 as k-quads for layer 3: h2q[unit / 4][node][unit % 4]
-                    reinterpret_cast<float4 *>(&ws.h1[0][0])[bq * 4 + nj] =
-                        make_float4(fmaxf(acc[0] + W[kB2 + 4 * bq], 0.0f), fmaxf(acc[1] + W[kB2 + 4 * bq + 1], 0.0f),
-                                    fmaxf(acc[2] + W[kB2 + 4 * bq + 2], 0.0f), fmaxf(acc[3] + W[kB2 + 4 * bq + 3], 0.0f));
+                for (int nt = 0; nt < 4; nt++) h2[nt] = to_v4f(b2[nt * 4]);
+#pragma unroll
+                for (int mt = 0; mt < 8; mt++) {
+                    float4 w[4];
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) w[nt] = w2[(nt * 8 + mt) * 64];
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].x, h1[mt][0], h2[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].y, h1[mt][1], h2[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].z, h1[mt][2], h2[nt]);
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].w, h1[mt][3], h2[nt]);
                 }
-                sd_sync();
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) h2[nt] = relu4(h2[nt]);
                 SD_STAMP(2);
-                // layer 3: K = 64, 16 outputs = 4 blocks; the other factor 4 of the 16 blocks splits K (block = ks * 4 + ob), the four
-                // partial sums are added across lanes afterwards
+                // ---- layer 3: 16 outputs, K-step (nt, r); two accumulator chains ------------------------------------------------------
+                float adv[4];
                 {
-                    const int ks = bq >> 2, ob = bq & 3;
-                    v4f acc = {0.0f, 0.0f, 0.0f, 0.0f};
-                    const float4 *hq = reinterpret_cast<const float4 *>(&ws.h1[0][0]);   // = hidden layer 2 now
+                    v4f o0 = to_v4f(b3[0]), o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+                    float4 w[4];
 #pragma unroll
-                    for (int t = 0; t < 4; t++) {
-                        const int kq = ks * 4 + t;
-                        const float4 w = w3q[kq * 16 + 4 * ob + nj];          // A role: output 4*ob + (lane % 4)
-                        const float4 h = hq[kq * 4 + nj];                      // B role: node lane % 4
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.x, h.x, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.y, h.y, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.z, h.z, acc, 0, 0, 0);
-                        acc = __builtin_amdgcn_mfma_f32_4x4x1f32(w.w, h.w, acc, 0, 0, 0);
-                    }
-                    float adv[4], pos[4];
+                    for (int nt = 0; nt < 4; nt++) w[nt] = w3[nt * 64];
+                    o0 = mfma16(w[0].x, h2[0][0], o0); o1 = mfma16(w[1].x, h2[1][0], o1);
+                    o0 = mfma16(w[0].y, h2[0][1], o0); o1 = mfma16(w[1].y, h2[1][1], o1);
+                    o0 = mfma16(w[0].z, h2[0][2], o0); o1 = mfma16(w[1].z, h2[1][2], o1);
+                    o0 = mfma16(w[0].w, h2[0][3], o0); o1 = mfma16(w[1].w, h2[1][3], o1);
+                    o0 = mfma16(w[2].x, h2[2][0], o0); o1 = mfma16(w[3].x, h2[3][0], o1);
+                    o0 = mfma16(w[2].y, h2[2][1], o0); o1 = mfma16(w[3].y, h2[3][1], o1);
+                    o0 = mfma16(w[2].z, h2[2][2], o0); o1 = mfma16(w[3].z, h2[3][2], o1);
+                    o0 = mfma16(w[2].w, h2[2][3], o0); o1 = mfma16(w[3].w, h2[3][3], o1);
 #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        float v = acc[i];
-                        v += __shfl_xor(v, 16); v += __shfl_xor(v, 32);        // the four K-splits
-                        adv[i] = v + W[kB3 + 4 * ob + i];
-                    }
-                    // positive_regret_policy over the node's 16 outputs (nets.py:93-101): this lane holds outputs 4*ob .. 4*ob+3 of node nj
-                    float z = 0.0f;
-#pragma unroll
-                    for (int i = 0; i < 4; i++) { pos[i] = (((hand_bits >> (4 * ob + i)) & 1u) && adv[i] > 0.0f) ? adv[i] : 0.0f; z += pos[i]; }
-                    z += __shfl_xor(z, 4); z += __shfl_xor(z, 8);              // the four output groups
-                    const float den = z > 1e-8f ? z : 1e-8f;
-                    if (ks == 0 && live) {
-#pragma unroll
-                        for (int k = 0; k < 4; k++) {
-                            const int c = nib(sj.hand[p], k);
-                            if (k < nl && (c >> 2) == ob) {
-                                float pv = pos[0];
-#pragma unroll
-                                for (int i = 1; i < 4; i++) pv = (c & 3) == i ? pos[i] : pv;
-                                ws.polcur[nj][k] = pv / den;
-                            }
-                        }
-                    }
+                    for (int r = 0; r < 4; r++) adv[r] = o0[r] + o1[r];     // output 4 q + r of node nj
                 }
+                // positive_regret_policy over the node's 16 outputs (nets.py:93-101): relu kills the illegal slots' -1e6
+                float z = 0.0f;
+                {
+                    float4 pv;
+                    float *pp = &pv.x;
+#pragma unroll
+                    for (int r = 0; r < 4; r++) { pp[r] = (((xbits >> (4 * q + r)) & 1u) && adv[r] > 0.0f) ? adv[r] : 0.0f; z += pp[r]; }
+                    z += __shfl_xor(z, 16); z += __shfl_xor(z, 32);        // the four row groups
+                    *reinterpret_cast<float4 *>(&ws.pos[nj][4 * q]) = pv;
+                }
+                const float den = z > 1e-8f ? z : 1e-8f;                   // clamp_min(eps)
                 sd_sync();
                 SD_STAMP(3);
-                // expand / sample: one lane per node of the group
-                if (lane < kG && g0 + lane < width) {
-                    const int j = g0 + lane, idx = ws.idx[idx_at(d) + j];
-                    float pk[4];
-                    for (int k = 0; k < 4; k++) pk[k] = k < nl ? ws.polcur[lane][k] : 0.0f;
-                    if (trav_ply) {
-                        for (int k = 0; k < nl; k++) ws.idx[idx_at(d + 1) + j * nl + k] = (uint16_t)(idx * nl + k);
-                        for (int k = 0; k < 4; k++) ws.pol_trav[moff + j][k] = pk[k];
-                    } else {
-                        float sum = pk[0];
-                        for (int k = 1; k < nl; k++) sum += pk[k];
-                        double u;
-                        if (uniforms) u = uniforms[((size_t)tb * kPlies + d) * 24 + j];
-                        else {
-                            const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)tb, iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
-                            u = u53(x.x0, x.x1);
-                        }
-                        int a;
-                        if (sum == 0.0f) { a = (int)(u * (double)nl); a = a < nl - 1 ? a : nl - 1; }
-                        else {
-                            double c = 0.0, cdf[4];
-                            for (int k = 0; k < nl; k++) { const double pq = (double)(pk[k] / sum); c = k ? c + pq : pq; cdf[k] = c; }
-                            const double last = cdf[nl - 1];
-                            a = 0;
-                            for (int k = 0; k < nl; k++) if (cdf[k] / last <= u) a = k + 1;
-                            a = a < nl - 1 ? a : nl - 1;
-                        }
-                        ws.idx[idx_at(d + 1) + j] = (uint16_t)(idx * nl + a);
+                int t = 0;
+#pragma unroll
+                for (int k = 1; k < T; k++) t += f >= k * width;
+                const int j = f - t * width;
+                if (trav_ply) {
+                    // recurse on ALL legal actions, hand order (:326-336): lane (q, node) takes action q
+                    const float pk = q < nl ? ws.pos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;
+                    if (live) {
+                        ws.pol_trav[t][moff + j][q] = pk;
+                        if (q < nl) ws.idx[t][idx_at(d + 1) + j * nl + q] = (uint16_t)(node * nl + q);
                     }
+                } else {
+                    // opponent: sample ONE action (:347-365); the four lanes of a node draw the same number
+                    float pk[4];
+#pragma unroll
+                    for (int k = 0; k < 4; k++) pk[k] = k < nl ? ws.pos[nj][(hand >> (4 * k)) & 15u] / den : 0.0f;
+                    float sum = pk[0];
+#pragma unroll
+                    for (int k = 1; k < 4; k++) if (k < nl) sum += pk[k];  // action_probs.sum(), float32, left to right
+                    const int tb = tb0 + t;
+                    double u;
+                    if (uniforms) u = (live && t < n_live) ? uniforms[((size_t)tb * kPlies + d) * 24 + j] : 0.0;
+                    else {
+                        const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)tb, iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
+                        u = u53(x.x0, x.x1);
+                    }
+                    int a;
+                    if (sum == 0.0f) { a = (int)(u * (double)nl); a = a < nl - 1 ? a : nl - 1; }   // np.random.choice(legal_actions): uniform
+                    else {                                                                          // p = action_probs / sum: float32 p, float64 cdf
+                        double cs = 0.0, cdf[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const double pq = (double)(pk[k] / sum); cs = k ? cs + pq : pq; cdf[k] = cs; }
+                        double last = cdf[0];
+#pragma unroll
+                        for (int k = 1; k < 4; k++) last = k < nl ? cdf[k] : last;
+                        a = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (k < nl && cdf[k] / last <= u) a = k + 1;
+                        a = a < nl - 1 ? a : nl - 1;
+                    }
+                    if (live && q == 0) ws.idx[t][idx_at(d + 1) + j] = (uint16_t)(node * nl + a);
                 }
                 sd_sync();
                 SD_STAMP(4);
@@ -582,7 +611,13 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
             if (trav_ply) width *= nl;
         }
         // ---- leaves, then backward ---------------------------------------------------------------------------------------
-        if (lane < width) { const int p0 = g_payoff[ws.idx[idx_at(8) + lane]]; ws.val[0][lane] = 0.5f * (float)(traverser == 0 ? p0 : -p0); }
+        for (int f = lane; f < T * width; f += 64) {
+            int t = 0;
+#pragma unroll
+            for (int k = 1; k < T; k++) t += f >= k * width;
+            const int p0 = g_payoff[ws.idx[t][idx_at(8) + f - t * width]];
+            ws.val[0][f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
+        }
         sd_sync();
         int cur = 0;
 #pragma unroll 1
@@ -592,48 +627,58 @@ k_sdcfr_traverse(const scopa_state *__restrict__ g_states, const int8_t *__restr
             if (trav_ply) width /= nl;
             const int m = (d - traverser) >> 1;
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
-            if (lane < width) {
-                const int j = lane;
-                if (!trav_ply) ws.val[cur ^ 1][j] = ws.val[cur][j];
-                else {
-                    const scopa_state s = g_states[level_offset(d) + ws.idx[idx_at(d) + j]];
-                    float value = 0.0f, cfv[16];
-                    for (int c = 0; c < 16; c++) cfv[c] = 0.0f;
-                    uint32_t hand_bits = 0, table_bits = 0;
-                    for (int k = 0; k < nl; k++) {
-                        const float av = ws.val[cur][j * nl + k];
-                        value += ws.pol_trav[moff + j][k] * av;
-                        const int c = nib(s.hand[p], k);
-                        hand_bits |= 1u << c;
+            for (int f = lane; f < T * width; f += 64) {
+                if (!trav_ply) { ws.val[cur ^ 1][f] = ws.val[cur][f]; continue; }   // the sampled child's value is returned unchanged (:363-365)
+                int t = 0;
+#pragma unroll
+                for (int k = 1; k < T; k++) t += f >= k * width;
+                const int j = f - t * width;
+                const uint2 inf = g_ninfo[level_offset(d) + ws.idx[t][idx_at(d) + j]];
+                const uint32_t xbits = inf.x, hand = inf.y;
+                float value = 0.0f, cfv[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) cfv[cc] = 0.0f;           // counterfactual_values = zeros(16) (:324)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < nl) {
+                        const float av = ws.val[cur][(t * width + j) * nl + k];
+                        value += ws.pol_trav[t][moff + j][k] * av;           // value += policy[action] * action_value, float32 (:335)
+                        const int c = (int)((hand >> (4 * k)) & 15u);
 #pragma unroll
                         for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
                     }
-                    for (int k = 0; k < s.nt; k++) table_bits |= 1u << nib(s.table, k);
-                    ws.val[cur ^ 1][j] = value;
+                }
+                ws.val[cur ^ 1][f] = value;
+                if (t < n_live) {
                     float mx = 0.0f, reg[16];
 #pragma unroll
-                    for (int c = 0; c < 16; c++) { reg[c] = cfv[c] - value; const float a = fabsf(reg[c]); mx = a > mx ? a : mx; }
+                    for (int cc = 0; cc < 16; cc++) { reg[cc] = cfv[cc] - value; const float a = fabsf(reg[cc]); mx = a > mx ? a : mx; }   // illegal slots = -value
                     const float den = mx + 1e-8f;
-                    const int T[4] = {41, 10, 3, 1};
-                    int jj = j, rank = T[m] - 1;
-                    for (int qd = m - 1; qd >= 0; qd--) { const int radix = 4 - qd; rank += (jj % radix) * T[qd + 1]; jj /= radix; }
-                    const long long row = (write_base + (long long)tb * 41 + rank) % capacity;
+                    if (mx > 0.0f) {
 #pragma unroll
-                    for (int c = 0; c < 16; c++) {
-                        const float h = (float)((hand_bits >> c) & 1u);
-                        mem_feat[row * 34 + c] = h;
-                        mem_feat[row * 34 + 16 + c] = (float)((table_bits >> c) & 1u);
-                        mem_mask[row * 16 + c] = h;
-                        mem_regret[row * 16 + c] = mx > 0.0f ? reg[c] / den : reg[c];
+                        for (int cc = 0; cc < 16; cc++) reg[cc] = reg[cc] / den;    // add_experience (:73-74)
                     }
-                    mem_feat[row * 34 + 32] = 1.0f;
-                    mem_feat[row * 34 + 33] = 0.0f;
+                    // ring position: the reference appends in DFS post-order; rank of this traverser node within its traversal
+                    const int Tn[4] = {41, 10, 3, 1};          // traverser nodes in the subtree of a traverser node of ply index m
+                    int jj = j, rank = Tn[m] - 1;
+                    for (int qd = m - 1; qd >= 0; qd--) { const int radix = 4 - qd; rank += (jj % radix) * Tn[qd + 1]; jj /= radix; }
+                    const long long row = (write_base + (long long)(tb0 + t) * 41 + rank) % capacity;
+                    float2 *mf = reinterpret_cast<float2 *>(mem_feat + row * 34);          // 136-byte rows: 8-byte aligned
+                    float4 *mm = reinterpret_cast<float4 *>(mem_mask + row * 16), *mr = reinterpret_cast<float4 *>(mem_regret + row * 16);
+#pragma unroll
+                    for (int i = 0; i < 16; i++) mf[i] = make_float2((float)((xbits >> (2 * i)) & 1u), (float)((xbits >> (2 * i + 1)) & 1u));
+                    mf[16] = make_float2(1.0f, 0.0f);
+#pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        mm[i] = make_float4((float)((xbits >> (4 * i)) & 1u), (float)((xbits >> (4 * i + 1)) & 1u), (float)((xbits >> (4 * i + 2)) & 1u), (float)((xbits >> (4 * i + 3)) & 1u));
+                        mr[i] = make_float4(reg[4 * i], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]);
+                    }
                 }
             }
             cur ^= 1;
             sd_sync();
         }
-        if (lane == 0) root_values[tb] = ws.val[cur][0];
+        if (lane < n_live) root_values[tb0 + lane] = ws.val[cur][lane];
         sd_sync();
         SD_STAMP(6);
         int got = 0;
@@ -654,30 +699,68 @@ extern "C" int scopa_debug_sdcfr_stamps(unsigned long long *out16, int reset) {
 }
 #endif
 
-extern "C" int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_weights, float *d_mem_feat,
-                                              float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
-                                              float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0) {
-    if (!ctx || traverser < 0 || traverser > 1 || batch < 0 || (batch && (!d_weights || !d_mem_feat || !d_mem_regret || !d_mem_mask || !d_root_values)))
+extern "C" {
+
+int32_t scopa_sdcfr_image_floats(void) { return kImgFloats; }
+
+int32_t scopa_sdcfr_pack_weights(scopa_ctx *ctx, int32_t player, const float *d_w1, const float *d_b1, const float *d_w2, const float *d_b2,
+                                 const float *d_w3, const float *d_b3, float *d_image) {
+    if (!ctx || player < 0 || player > 1 || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_image) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ((uintptr_t)d_image & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_pack_weights: the image must be 16-byte aligned");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    hipLaunchKernelGGL(k_sdcfr_pack, dim3((kImgFloats + 255) / 256), dim3(256), 0, ctx->stream, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3,
+                       d_image + (size_t)player * kImgFloats);
+    SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+int32_t scopa_sdcfr_tile_traversals(scopa_ctx *ctx, int32_t traversals_per_wavefront) {
+    if (!ctx || (traversals_per_wavefront != 0 && traversals_per_wavefront != 2 && traversals_per_wavefront != 4)) return SCOPA_EINVAL;
+    ctx->sdcfr_tile_t = traversals_per_wavefront;
+    return SCOPA_OK;
+}
+
+int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_image, float *d_mem_feat,
+                                   float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
+                                   float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0) {
+    if (!ctx || traverser < 0 || traverser > 1 || batch < 0 || (batch && (!d_image || !d_mem_feat || !d_mem_regret || !d_mem_mask || !d_root_values)))
         return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_traverse_fused: no deal set");
     SC_REQUIRE(ctx, capacity >= 41 && (int64_t)batch * 41 <= capacity && write_base >= 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: memory ring too small for the batch");
-    SC_REQUIRE(ctx, ((uintptr_t)d_weights & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: weights must be 16-byte aligned");
+    SC_REQUIRE(ctx, ((uintptr_t)d_image & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: the weight image must be 16-byte aligned");
+    SC_REQUIRE(ctx, ((uintptr_t)d_mem_feat & 7) == 0 && ((uintptr_t)d_mem_regret & 15) == 0 && ((uintptr_t)d_mem_mask & 15) == 0, SCOPA_EINVAL,
+               "scopa_sdcfr_traverse_fused: memory rows are stored 8 / 16 bytes at a time: d_mem_feat must be 8-byte, d_mem_regret / d_mem_mask 16-byte aligned");
     if (!batch) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    // 110 KB of weights + one SdWave per wavefront: as many wavefronts as fit (<= 16, the kernel's launch bound: 4 per SIMD)
-    int waves = (int)(((size_t)ctx->lds_limit - 64 - (size_t)2 * kNetFloats * sizeof(float)) / sizeof(SdWave));
-    waves = waves > 16 ? 16 : waves;
-    SC_REQUIRE(ctx, waves >= 8, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (the weight staging assumes >= 512 threads)");
-    const int threads = waves * 64;
-    const size_t lds = (size_t)2 * kNetFloats * sizeof(float) + (size_t)waves * sizeof(SdWave);
+    if (!ctx->d_sdnode) SC_HIP(ctx, hipMalloc(&ctx->d_sdnode, sizeof(uint2) * kDecision));
+    if (!ctx->sdnode_valid) {
+        hipLaunchKernelGGL(k_sdcfr_nodeinfo, dim3((kDecision + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_states, (uint2 *)ctx->d_sdnode);
+        SC_HIP(ctx, hipGetLastError());
+        ctx->sdnode_valid = true;
+    }
+    // T traversals per wavefront: 4 fills the 16-node tiles best (21 tiles for traverser 0's 324 evaluated nodes); with fewer than
+    // 8 tasks of 4 per compute unit a wavefront per SIMD would walk alone, so small batches take 2 (26 tiles, twice the wavefronts)
+    int T = ctx->sdcfr_tile_t;
+    if (T == 0) T = 4;
+    const size_t wave_bytes = T == 4 ? sizeof(SdWave<4>) : sizeof(SdWave<2>);
+    const size_t lds = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kSdWaves * wave_bytes;
     SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
-    SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse, ctx->lds_limit - 64);   // 64: the kernel's static LDS (s_next), beside the dynamic part
-    const int passes = (batch + waves - 1) / waves;
-    const int grid = passes < ctx->n_cus ? passes : ctx->n_cus;
-    hipLaunchKernelGGL(k_sdcfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_states, ctx->d_payoff, d_weights, (int)traverser,
-                       (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, d_root_values, d_uniforms,
-                       (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
+    const int n_tasks = (batch + T - 1) / T;
+    const int grid = n_tasks < ctx->n_cus ? n_tasks : ctx->n_cus;
+    if (T == 4) {
+        SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse<4>, ctx->lds_limit - 64);   // 64: the kernel's static LDS (s_next), beside the dynamic part
+        hipLaunchKernelGGL(k_sdcfr_traverse<4>, dim3(grid), dim3(kSdWaves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, d_image,
+                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, d_root_values,
+                           d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
+    } else {
+        SC_LDS_ATTR(ctx, scopa::kLdsSdcfr2, k_sdcfr_traverse<2>, ctx->lds_limit - 64);
+        hipLaunchKernelGGL(k_sdcfr_traverse<2>, dim3(grid), dim3(kSdWaves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, d_image,
+                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, d_root_values,
+                           d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
+    }
     SC_HIP(ctx, hipGetLastError());
     ctx->sdcfr_visits += (uint64_t)batch * (traverser == 0 ? 105 : 82);
     return SCOPA_OK;
 }
+
+}  // extern "C"

@@ -296,31 +296,88 @@ def test_traversal_batch_with_device_draws_vs_oracle(dcfr, oracle, trav):
         np.testing.assert_allclose(vals.cpu().numpy(), ovals, atol=ATOL, rtol=0)
 
 
+def _weight_image(sd):
+    """The fused kernel's LDS image of one net (include/scopa.h: scopa_sdcfr_pack_weights), built independently with numpy."""
+    w1, b1 = sd["backbone.0.fc.weight"].cpu().numpy(), sd["backbone.0.fc.bias"].cpu().numpy()
+    w2, b2 = sd["backbone.1.fc.weight"].cpu().numpy(), sd["backbone.1.fc.bias"].cpu().numpy()
+    w3, b3 = sd["head.weight"].cpu().numpy(), sd["head.bias"].cpu().numpy()
+    lane = np.arange(64)
+    row, kq = lane & 15, lane >> 4
+    i1 = np.empty((8, 2, 64, 4), np.float32)
+    for mt in range(8):
+        for g in range(2):
+            for c in range(4):
+                i1[mt, g, :, c] = w1[16 * mt + row, 4 * (4 * g + c) + kq]
+    i2 = np.empty((4, 8, 64, 4), np.float32)
+    for nt in range(4):
+        for mt in range(8):
+            for r in range(4):
+                i2[nt, mt, :, r] = w2[16 * nt + row, 16 * mt + 4 * kq + r]
+    i3 = np.empty((4, 64, 4), np.float32)
+    for nt in range(4):
+        for r in range(4):
+            i3[nt, :, r] = w3[row, 16 * nt + 4 * kq + r]
+    return np.concatenate([i1.reshape(-1), (b1 + w1[:, 32]).astype(np.float32), i2.reshape(-1), b2, i3.reshape(-1), b3])
+
+
 def test_packed_weights_follow_the_nets(ctx):
-    """The persistent W^T | b buffer the fused kernel reads is rebuilt exactly when a net changed: after optimiser steps (plain and
-    graph-replayed) and after load_state_dict it equals a fresh pack of the nets' tensors."""
+    """The persistent weight image the fused kernel reads is rebuilt exactly when a net changed: after optimiser steps (plain and
+    graph-REPLAYED -- a replay leaves the parameters' autograd version counters alone, so the second and later train() calls of a
+    graph-trained net are the case that matters) and after load_state_dict it equals a fresh pack of the nets' tensors."""
     import torch
     from scopa_amd.envs import load_game
     from scopa_amd.algorithms.deep_cfr import DeepCFR
 
     def fresh(d):
-        parts = []
-        for a in d.advantage_nets:
-            sd = a.net.state_dict()
-            for w, b in (("backbone.0.fc.weight", "backbone.0.fc.bias"), ("backbone.1.fc.weight", "backbone.1.fc.bias"), ("head.weight", "head.bias")):
-                parts += [sd[w].t().reshape(-1), sd[b].reshape(-1)]
-        return torch.cat(parts).reshape(2, -1)
+        return np.stack([_weight_image(a.net.state_dict()) for a in d.advantage_nets])
+
+    def packed(d):
+        with torch.cuda.stream(d._stream):
+            w = d._packed_weights()
+        d._stream.synchronize()
+        return w.cpu().numpy()
 
     for graph in (False, True):
         torch.manual_seed(3)
         d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=64, graph_training=graph)
-        assert torch.equal(d._packed_weights(), fresh(d))
+        assert packed(d).shape == (2, 13520) and np.array_equal(packed(d), fresh(d))
         for p in (0, 1):
             d._traverse_batch(p, 64)
-        before = d._packed_weights().clone()
-        d.advantage_nets[1].train(batch_size=128, epochs=2)
-        torch.cuda.synchronize()
-        now = d._packed_weights()
-        assert torch.equal(now, fresh(d)) and torch.equal(now[0], before[0]) and not torch.equal(now[1], before[1])
+        for call in range(3):                              # call 0 captures the graph, calls 1 and 2 replay it
+            before = packed(d).copy()
+            with torch.cuda.stream(d._stream):
+                d.advantage_nets[1].train(batch_size=128, epochs=2)
+            d._stream.synchronize()
+            now = packed(d)
+            assert np.array_equal(now, fresh(d)), (graph, call)
+            assert np.array_equal(now[0], before[0]) and not np.array_equal(now[1], before[1]), (graph, call)
         d.advantage_nets[0].net.load_state_dict(d.advantage_nets[1].net.state_dict())
-        assert torch.equal(d._packed_weights(), fresh(d)) and torch.equal(d._packed_weights()[0], d._packed_weights()[1])
+        assert np.array_equal(packed(d), fresh(d)) and np.array_equal(packed(d)[0], packed(d)[1])
+        with torch.no_grad():                              # an in-place edit made around the class
+            d.advantage_nets[0].net.head.bias.add_(1.0)
+        assert np.array_equal(packed(d), fresh(d))
+
+
+def test_graph_training_and_eager_training_give_the_same_nets(ctx):
+    """Three whole DeepCFR.train iterations with the optimiser step replayed as a HIP graph against the same three with eager
+    steps: the traversals of iterations 1 and 2 read the nets the previous iteration trained (a stale weight image would
+    freeze them at iteration 0's), so memory rows, losses and final weights agree."""
+    import torch
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    runs = []
+    for graph in (False, True):
+        torch.manual_seed(11)
+        d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=64, graph_training=graph)
+        d.train(iterations=3, advantage_epochs=3, eval_freq=100)
+        mem = d.advantage_nets[0].buffer
+        f, r, m = mem.rows(torch.arange(len(mem), device="cuda:0"))
+        runs.append((d.training_history, [v.cpu().numpy() for a in d.advantage_nets for v in a.net.state_dict().values()], f.cpu().numpy(), r.cpu().numpy()))
+    (h0, w0, f0, r0), (h1, w1, f1, r1) = runs
+    same = (f0 == f1).all(1)                                               # the same actions were sampled in every iteration (a draw within
+    assert same.mean() > 0.98                                              # float32 rounding of a cdf step may flip: a handful of rows at most)
+    np.testing.assert_allclose(r0[same], r1[same], atol=2e-4, rtol=0)
+    np.testing.assert_allclose(np.array(h0["losses"]), np.array(h1["losses"]), atol=1e-5, rtol=1e-4)
+    for a, b in zip(w0, w1):
+        np.testing.assert_allclose(a, b, atol=2e-5, rtol=0)                # fused Adam (graph mode) vs foreach Adam: same rule, float32 rounding
+    assert not np.array_equal(r0[:64 * 41], r0[2 * 64 * 41:3 * 64 * 41])  # and iteration 2's regrets differ from iteration 0's: the nets moved
