@@ -326,32 +326,41 @@ constexpr int kImgFloats = kImgB3 + 16;   // 13 520 (the 13 776 parameters less 
 static_assert(kImgFloats == SCOPA_SDCFR_IMAGE_FLOATS, "include/scopa.h states the image size");
 
 template <int T>
-struct SdWave {                 // per-wavefront scratch: T traversals in flight
+struct alignas(16) SdWave {     // per-wavefront scratch: T traversals in flight; a frontier node is addressed by its POSITION f = t * width + j
     float pol_trav[T][41][4];   // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
-    float val[2][T * 24];       // values of the frontier flowing back up (position t * width + j)
+    uint32_t hr[T][41];         // the same nodes' hand nibbles | DFS post-order rank << 16 (the backward pass needs nothing else of them)
+    float val[T * 24];          // values of the frontier flowing back up, by position; a traverser ply replaces them IN PLACE: node f reads its
+                                // children f nl + k >= f and the wavefront's 64 lanes read before any of them writes (LDS executes its operations in
+                                // order); a second round (positions >= 64) reads positions >= 64 nl, which the first round did not write
     float pos[16][16];          // relu(adv) * mask of the tile in flight, [node][output]
-    uint32_t ninfo[T * 24][2];  // the current ply's frontier: feature bits | hand nibbles + tree index << 16
-    uint16_t idx[T][136];       // tree index of every frontier node, per ply (ply 8 = leaves), at idx_at(ply): a traversal's frontier is 1, <= 4, 4,
-                                // <= 12, 12, <= 24, 24, 24, 24 wide (either traverser)
+    uint16_t idx[2][T * 24];    // tree index of the frontier nodes of the current / the next ply
 };
-__host__ __device__ constexpr int idx_at(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 9 : d == 4 ? 21 : d == 5 ? 33 : d == 6 ? 57 : d == 7 ? 81 : 105; }
-static_assert(idx_at(1) - idx_at(0) >= 1 && idx_at(2) - idx_at(1) >= 4 && idx_at(3) - idx_at(2) >= 4 && idx_at(4) - idx_at(3) >= 12 && idx_at(5) - idx_at(4) >= 12 &&
-              idx_at(6) - idx_at(5) >= 24 && idx_at(7) - idx_at(6) >= 24 && idx_at(8) - idx_at(7) >= 24 && idx_at(8) + 24 <= 136,
-              "every ply's frontier (widest over the two traversers) fits its slice of SdWave::idx");
 static_assert(sizeof(SdWave<4>) % 16 == 0 && sizeof(SdWave<2>) % 16 == 0, "SdWave alignment");
+constexpr int kSdNodeSlots = (kDecision + 1) & ~1;   // the node table in LDS, padded to 16 bytes
 constexpr int kSdWaves = 8;     // wavefronts per workgroup: two per SIMD (one walks its tiles' matrix phases while the other samples / expands)
 
-__device__ __forceinline__ void sd_sync() {   // a wavefront's LDS operations execute in order: this only stops the compiler (and drains the queue)
+// A wavefront's LDS operations execute in order, so lane A's store is seen by lane B's later load without any wait; this only
+// keeps the compiler from moving LDS accesses across the point (the wait for a load's data is the compiler's own s_waitcnt).
+__device__ __forceinline__ void sd_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_s_waitcnt(0xc07f);
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
+typedef unsigned v2u __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ v4f mfma16(float a, float b, v4f c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ v4f to_v4f(float4 x) { v4f r = {x.x, x.y, x.z, x.w}; return r; }
-__device__ __forceinline__ v4f relu4(v4f x) { v4f r = {fmaxf(x[0], 0.0f), fmaxf(x[1], 0.0f), fmaxf(x[2], 0.0f), fmaxf(x[3], 0.0f)}; return r; }
+__device__ __forceinline__ float relu(float x) { return __builtin_amdgcn_fmed3f(x, 0.0f, __builtin_huge_valf()); }   // one v_max (fmaxf costs two: it quiets NaNs first)
+// x + (the same register of lane ^ 16), then + lane ^ 32: gfx950's row swaps instead of two trips through the LDS crossbar
+__device__ __forceinline__ float sum_row_groups(float x) {
+    const unsigned xi = __float_as_uint(x);
+    const v2u a = __builtin_amdgcn_permlane16_swap(xi, xi, false, false);     // rows (16 lanes) 1 <-> 0 and 3 <-> 2 of the two copies
+    const float s = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    const unsigned si = __float_as_uint(s);
+    const v2u b = __builtin_amdgcn_permlane32_swap(si, si, false, false);     // upper half <-> lower half
+    return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
 }  // namespace
 
 // feature bits (hand one-hot | table multi-hot << 16) and the mover's hand nibbles of every decision node, BFS order: what a
@@ -396,8 +405,10 @@ k_sdcfr_pack(const float *__restrict__ w1, const float *__restrict__ b1, const f
 }
 
 #ifdef SCOPA_WALK_STAMPS   // development build only: shader-clock stamps of wavefront 0 of workgroup 0 (tests/tools/sdcfr_stamps.py)
-__device__ unsigned long long g_sd_stamps[16];   // 0 frontier info | 1 layer 1 | 2 layer 2 | 3 layer 3 + policy | 4 expand / sample | 5 skipped plies | 6 leaves + backward | 7 take | 15 tasks
-#define SD_STAMP(i) do { const unsigned long long now_ = clock64(); if (blockIdx.x == 0 && threadIdx.x == 0) g_sd_stamps[i] += now_ - sd_prev_; sd_prev_ = now_; } while (0)
+__device__ unsigned long long g_sd_stamps[16];   // 1 layer 1 | 2 layer 2 | 3 layer 3 + policy | 4 expand / sample | 6 leaves + backward | 7 take | 13 shader clocks, 14 100 MHz ticks of whole tasks | 15 tasks
+// stamps accumulate in registers and reach memory once per task (a global read-modify-write per stamp cost more than the stages it
+// timed); sched_barrier pins the clock read where it is written (the scheduler otherwise moves MFMAs across it)
+#define SD_STAMP(i) do { __builtin_amdgcn_sched_barrier(0); const unsigned long long now_ = clock64(); sd_acc_[i] += now_ - sd_prev_; sd_prev_ = now_; __builtin_amdgcn_sched_barrier(0); } while (0)
 #else
 #define SD_STAMP(i) do { } while (0)
 #endif
@@ -406,17 +417,19 @@ template <int T>
 __global__ void __launch_bounds__(kSdWaves * 64)
 k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_image,
                  int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
-                 long long capacity, long long write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
+                 uint32_t capacity, uint32_t write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
                  uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_next[1];                                               // next task of this workgroup not taken yet
     float *s_w = reinterpret_cast<float *>(smem);                           // [2][kImgFloats]
-    SdWave<T> *s_wave = reinterpret_cast<SdWave<T> *>(s_w + 2 * kImgFloats);   // [wavefronts]
+    uint2 *s_node = reinterpret_cast<uint2 *>(s_w + 2 * kImgFloats);        // [kDecision (+1 pad)]: feature bits | hand nibbles of every decision node
+    SdWave<T> *s_wave = reinterpret_cast<SdWave<T> *>(s_node + kSdNodeSlots);   // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
     if (tid == 0) s_next[0] = n_waves;
     for (int i = tid; i < 2 * kImgFloats / 4; i += blockDim.x)
         reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image)[i];
-    __syncthreads();
+    for (int i = tid; i < kDecision; i += blockDim.x) s_node[i] = g_ninfo[i];   // 13 KB: with it in LDS the forward pass makes no global load at all, so
+    __syncthreads();                                                            // nothing ever waits behind the memory-row stores (one vmcnt queue)
     SdWave<T> &ws = s_wave[wave];
     const int nj = lane & 15, q = lane >> 4;   // this lane's column (node of the tile) and K / row group
 
@@ -430,49 +443,32 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
     for (int c = wave; c < count;) {
         const int tb0 = (first + c) * T;                                    // the task's first traversal (local id within the batch)
         const int n_live = batch - tb0 < T ? batch - tb0 : T;               // traversals t >= n_live are walked like the others but write nothing
+        // ring row of the task's first memory row: write_base < capacity and 41 * batch <= capacity (checked on the host), so one
+        // conditional subtraction each replaces the 64-bit modulo per row
+        uint32_t row0 = write_base + 41u * (uint32_t)tb0;
+        row0 = row0 >= capacity ? row0 - capacity : row0;
 #ifdef SCOPA_WALK_STAMPS
-        unsigned long long sd_prev_ = clock64();
+        unsigned long long sd_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long sd_t0_ = clock64(), sd_r0_ = wall_clock64();
+        unsigned long long sd_prev_ = sd_t0_;
 #endif
-        if (lane < T) ws.idx[lane][idx_at(0)] = 0;
-        sd_sync();
-        int width = 1;                                                      // a traversal's frontier width at the current ply
+        if (lane < T) ws.idx[0][lane] = 0;
+        sd_order();
+        int width = 1, cb = 0;                                              // a traversal's frontier width at the current ply; which half of ws.idx holds it
         // ---- forward: plies 0..7 ----------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int d = 0; d < kPlies; d++) {
             const int p = d & 1, nl = 4 - (d >> 1);
             const bool trav_ply = p == traverser;
-            const int n_nodes = T * width;                                  // position f = t * width + j
+            // opponent node with ONE legal action (plies 6/7): whatever the advantages are, regret matching either puts all mass on it
+            // or falls back to uniform over it (deep_cfr.py:353-359) -- the child is forced (same position, same index within the
+            // next ply) and nothing else of this node is used (no memory row, no value weight): its forward pass is skipped, 24
+            // of the 105 / 82 node evaluations of a traversal
+            if (!trav_ply && nl == 1) continue;
+            const int n_nodes = T * width;
             const int m = (d - traverser) >> 1;                             // traverser-ply index when trav_ply
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
-            if (!trav_ply && nl == 1) {
-                // opponent node with ONE legal action (plies 6/7): whatever the advantages are, regret matching either puts all mass
-                // on it or falls back to uniform over it (deep_cfr.py:353-359) -- the child is forced and nothing else of this
-                // node is used (no memory row, no value weight), so its forward pass is skipped: 24 of the 105 / 82 node
-                // evaluations of a traversal
-                for (int f = lane; f < n_nodes; f += 64) {
-                    int t = 0;
-#pragma unroll
-                    for (int k = 1; k < T; k++) t += f >= k * width;
-                    const int j = f - t * width;
-                    ws.idx[t][idx_at(d + 1) + j] = ws.idx[t][idx_at(d) + j];
-                }
-                sd_sync();
-                SD_STAMP(5);
-                continue;
-            }
-            // the ply's frontier: feature bits, hand nibbles and tree index of every node, one global load each (the tiles below read LDS)
-            for (int f = lane; f < n_nodes; f += 64) {
-                int t = 0;
-#pragma unroll
-                for (int k = 1; k < T; k++) t += f >= k * width;
-                const int j = f - t * width;
-                const uint32_t node = ws.idx[t][idx_at(d) + j];
-                const uint2 inf = g_ninfo[level_offset(d) + (int)node];
-                ws.ninfo[f][0] = inf.x;
-                ws.ninfo[f][1] = inf.y | (node << 16);
-            }
-            sd_sync();
-            SD_STAMP(0);
+            const uint2 *nodes_d = s_node + level_offset(d);
             const float *W = s_w + p * kImgFloats;
             const float4 *w1 = reinterpret_cast<const float4 *>(W + kImgW1) + lane;
             const float4 *c1 = reinterpret_cast<const float4 *>(W + kImgC1) + q;
@@ -480,73 +476,128 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
             const float4 *b2 = reinterpret_cast<const float4 *>(W + kImgB2) + q;
             const float4 *w3 = reinterpret_cast<const float4 *>(W + kImgW3) + lane;
             const float4 *b3 = reinterpret_cast<const float4 *>(W + kImgB3) + q;
+            // layer 1's first step and bias do not depend on the tile: they are fetched for the NEXT tile under the current tile's
+            // last MFMAs, so that a tile's first MFMA does not wait for them behind the previous tile's expansion
+            float4 wa[8], c1v[8];
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++) wa[mt] = w1[(mt * 2 + 0) * 64];
+#pragma unroll
+            for (int mt = 0; mt < 8; mt++) c1v[mt] = c1[mt * 4];
+            // ... and so is the next tile's node (tree index, then its feature bits / hand nibbles: two dependent LDS reads)
+            uint32_t node_nx = ws.idx[cb][nj < n_nodes ? nj : n_nodes - 1];
+            uint2 inf_nx = nodes_d[node_nx];
 #pragma unroll 1
             for (int f0 = 0; f0 < n_nodes; f0 += 16) {
                 const int f = f0 + nj;
                 const bool live = f < n_nodes;
-                const int fc = live ? f : n_nodes - 1;                      // lanes beyond the frontier compute a copy of its last node and store nothing
-                const uint32_t xbits = ws.ninfo[fc][0], hn = ws.ninfo[fc][1];
-                const uint32_t hand = hn & 0xFFFFu, node = hn >> 16;
+                const uint32_t xbits = inf_nx.x, hand = inf_nx.y, node = node_nx;   // lanes beyond the frontier compute a copy of its last node and store nothing
+                // Weights are fetched one step AHEAD of the MFMAs that use them (a step = 32 / 16 MFMAs = 1024 / 512 matrix-pipe
+                // cycles, an LDS read returns in ~130): written in that order and pinned with sched_barrier, because left alone the
+                // scheduler issues a step's reads only two or three MFMAs before their first use and every step stalls on them.
                 // ---- layer 1: K-step s = 4 g + c covers features 4 s .. 4 s + 3 (k index = lane / 16) --------------------------
                 v4f h1[8];
+                float4 wb[8];
 #pragma unroll
-                for (int mt = 0; mt < 8; mt++) h1[mt] = to_v4f(c1[mt * 4]);
+                for (int mt = 0; mt < 8; mt++) h1[mt] = to_v4f(c1v[mt]);
+#pragma unroll
+                for (int mt = 0; mt < 8; mt++) wb[mt] = w1[(mt * 2 + 1) * 64];
+                __builtin_amdgcn_sched_barrier(0);
                 const uint32_t xs = xbits >> q;
+                {
+                    const float x0 = (float)(xs & 1u), x1 = (float)((xs >> 4) & 1u), x2 = (float)((xs >> 8) & 1u), x3 = (float)((xs >> 12) & 1u);
 #pragma unroll
-                for (int g = 0; g < 2; g++) {
-                    float4 w[8];
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wa[mt].x, x0, h1[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < 8; mt++) w[mt] = w1[(mt * 2 + g) * 64];
-                    const float x0 = (float)((xs >> (16 * g)) & 1u), x1 = (float)((xs >> (16 * g + 4)) & 1u);
-                    const float x2 = (float)((xs >> (16 * g + 8)) & 1u), x3 = (float)((xs >> (16 * g + 12)) & 1u);
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wa[mt].y, x1, h1[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].x, x0, h1[mt]);
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wa[mt].z, x2, h1[mt]);
 #pragma unroll
-                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].y, x1, h1[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].z, x2, h1[mt]);
-#pragma unroll
-                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].w, x3, h1[mt]);
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wa[mt].w, x3, h1[mt]);
                 }
-#pragma unroll
-                for (int mt = 0; mt < 8; mt++) h1[mt] = relu4(h1[mt]);      // register r of tile mt = unit 16 mt + 4 q + r of node nj
-                SD_STAMP(1);
-                // ---- layer 2: K-step (mt, r) covers the units 16 mt + 4 k + r, k = lane / 16: B operand = h1[mt][r] as it stands -----
+                // layer 2's first step and its bias
                 v4f h2[4];
+                float4 u0[4], u1[4];
+#pragma unroll
+                for (int nt = 0; nt < 4; nt++) u0[nt] = w2[(nt * 8 + 0) * 64];
 #pragma unroll
                 for (int nt = 0; nt < 4; nt++) h2[nt] = to_v4f(b2[nt * 4]);
+                __builtin_amdgcn_sched_barrier(0);
+                {
+                    const float x0 = (float)((xs >> 16) & 1u), x1 = (float)((xs >> 20) & 1u), x2 = (float)((xs >> 24) & 1u), x3 = (float)((xs >> 28) & 1u);
 #pragma unroll
-                for (int mt = 0; mt < 8; mt++) {
-                    float4 w[4];
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wb[mt].x, x0, h1[mt]);
 #pragma unroll
-                    for (int nt = 0; nt < 4; nt++) w[nt] = w2[(nt * 8 + mt) * 64];
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wb[mt].y, x1, h1[mt]);
 #pragma unroll
-                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].x, h1[mt][0], h2[nt]);
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wb[mt].z, x2, h1[mt]);
 #pragma unroll
-                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].y, h1[mt][1], h2[nt]);
-#pragma unroll
-                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].z, h1[mt][2], h2[nt]);
-#pragma unroll
-                    for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].w, h1[mt][3], h2[nt]);
+                    for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(wb[mt].w, x3, h1[mt]);
                 }
+                SD_STAMP(1);
+                // ---- layer 2: K-step (mt, r) covers the units 16 mt + 4 k + r, k = lane / 16: B operand = relu(h1[mt][r]) as it stands ----
+                // (register r of tile mt = unit 16 mt + 4 q + r of node nj)
+                float4 w3r[4];
+                v4f o0, o1 = {0.0f, 0.0f, 0.0f, 0.0f};
 #pragma unroll
-                for (int nt = 0; nt < 4; nt++) h2[nt] = relu4(h2[nt]);
+                for (int mt = 0; mt < 8; mt += 2) {
+#pragma unroll
+                    for (int nt = 0; nt < 4; nt++) u1[nt] = w2[(nt * 8 + mt + 1) * 64];
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const float a0 = relu(h1[mt][0]), a1 = relu(h1[mt][1]), a2 = relu(h1[mt][2]), a3 = relu(h1[mt][3]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u0[nt].x, a0, h2[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u0[nt].y, a1, h2[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u0[nt].z, a2, h2[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u0[nt].w, a3, h2[nt]);
+                    }
+                    if (mt + 2 < 8) {
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) u0[nt] = w2[(nt * 8 + mt + 2) * 64];
+                    } else {
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) w3r[nt] = w3[nt * 64];
+                        o0 = to_v4f(b3[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    {
+                        const float a0 = relu(h1[mt + 1][0]), a1 = relu(h1[mt + 1][1]), a2 = relu(h1[mt + 1][2]), a3 = relu(h1[mt + 1][3]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u1[nt].x, a0, h2[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u1[nt].y, a1, h2[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u1[nt].z, a2, h2[nt]);
+#pragma unroll
+                        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(u1[nt].w, a3, h2[nt]);
+                    }
+                }
                 SD_STAMP(2);
                 // ---- layer 3: 16 outputs, K-step (nt, r); two accumulator chains ------------------------------------------------------
                 float adv[4];
                 {
-                    v4f o0 = to_v4f(b3[0]), o1 = {0.0f, 0.0f, 0.0f, 0.0f};
-                    float4 w[4];
+                    float g[4][4];
 #pragma unroll
-                    for (int nt = 0; nt < 4; nt++) w[nt] = w3[nt * 64];
-                    o0 = mfma16(w[0].x, h2[0][0], o0); o1 = mfma16(w[1].x, h2[1][0], o1);
-                    o0 = mfma16(w[0].y, h2[0][1], o0); o1 = mfma16(w[1].y, h2[1][1], o1);
-                    o0 = mfma16(w[0].z, h2[0][2], o0); o1 = mfma16(w[1].z, h2[1][2], o1);
-                    o0 = mfma16(w[0].w, h2[0][3], o0); o1 = mfma16(w[1].w, h2[1][3], o1);
-                    o0 = mfma16(w[2].x, h2[2][0], o0); o1 = mfma16(w[3].x, h2[3][0], o1);
-                    o0 = mfma16(w[2].y, h2[2][1], o0); o1 = mfma16(w[3].y, h2[3][1], o1);
-                    o0 = mfma16(w[2].z, h2[2][2], o0); o1 = mfma16(w[3].z, h2[3][2], o1);
-                    o0 = mfma16(w[2].w, h2[2][3], o0); o1 = mfma16(w[3].w, h2[3][3], o1);
+                    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+                        for (int r = 0; r < 4; r++) g[nt][r] = relu(h2[nt][r]);
+                    o0 = mfma16(w3r[0].x, g[0][0], o0); o1 = mfma16(w3r[1].x, g[1][0], o1);
+                    o0 = mfma16(w3r[0].y, g[0][1], o0); o1 = mfma16(w3r[1].y, g[1][1], o1);
+                    o0 = mfma16(w3r[0].z, g[0][2], o0); o1 = mfma16(w3r[1].z, g[1][2], o1);
+                    o0 = mfma16(w3r[0].w, g[0][3], o0); o1 = mfma16(w3r[1].w, g[1][3], o1);
+                    o0 = mfma16(w3r[2].x, g[2][0], o0); o1 = mfma16(w3r[3].x, g[3][0], o1);
+                    o0 = mfma16(w3r[2].y, g[2][1], o0); o1 = mfma16(w3r[3].y, g[3][1], o1);
+                    o0 = mfma16(w3r[2].z, g[2][2], o0); o1 = mfma16(w3r[3].z, g[3][2], o1);
+                    o0 = mfma16(w3r[2].w, g[2][3], o0); o1 = mfma16(w3r[3].w, g[3][3], o1);
+#pragma unroll
+                    for (int mt = 0; mt < 8; mt++) wa[mt] = w1[(mt * 2 + 0) * 64];     // the next tile's first step (above)
+#pragma unroll
+                    for (int mt = 0; mt < 8; mt++) c1v[mt] = c1[mt * 4];
+                    { const int fn = f + 16; node_nx = ws.idx[cb][fn < n_nodes ? fn : n_nodes - 1]; inf_nx = nodes_d[node_nx]; }
+                    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 4; r++) adv[r] = o0[r] + o1[r];     // output 4 q + r of node nj
                 }
@@ -557,11 +608,11 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     float *pp = &pv.x;
 #pragma unroll
                     for (int r = 0; r < 4; r++) { pp[r] = (((xbits >> (4 * q + r)) & 1u) && adv[r] > 0.0f) ? adv[r] : 0.0f; z += pp[r]; }
-                    z += __shfl_xor(z, 16); z += __shfl_xor(z, 32);        // the four row groups
                     *reinterpret_cast<float4 *>(&ws.pos[nj][4 * q]) = pv;
+                    z = sum_row_groups(z);                                 // the four row groups of the node's column
                 }
                 const float den = z > 1e-8f ? z : 1e-8f;                   // clamp_min(eps)
-                sd_sync();
+                sd_order();
                 SD_STAMP(3);
                 int t = 0;
 #pragma unroll
@@ -572,7 +623,27 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     const float pk = q < nl ? ws.pos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;
                     if (live) {
                         ws.pol_trav[t][moff + j][q] = pk;
-                        if (q < nl) ws.idx[t][idx_at(d + 1) + j * nl + q] = (uint16_t)(node * nl + q);
+                        if (q < nl) ws.idx[cb ^ 1][f * nl + q] = (uint16_t)(node * nl + q);
+                        // the node's memory row (:339-346): where, and everything of it that does not wait for the values -- features
+                        // and mask -- now, four lanes to a row; the regrets follow in the backward pass.
+                        // Ring position: the reference appends in DFS post-order; rank of this traverser node within its traversal
+                        const int Tn[4] = {41, 10, 3, 1};                  // traverser nodes in the subtree of a traverser node of ply index m
+                        int jj = j, rank = Tn[m] - 1;
+                        for (int qd = m - 1; qd >= 0; qd--) { const int radix = 4 - qd; rank += (jj % radix) * Tn[qd + 1]; jj /= radix; }
+                        if (q == 0) ws.hr[t][moff + j] = hand | ((uint32_t)rank << 16);
+                        if (t < n_live) {
+                            uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)rank;
+                            row = row >= capacity ? row - capacity : row;
+                            float2 *mf = reinterpret_cast<float2 *>(mem_feat + (size_t)row * 34);      // 136-byte rows: 8-byte aligned
+#pragma unroll
+                            for (int i = 0; i < 4; i++) {
+                                const int ch = q + 4 * i;                  // 8-byte piece ch = features 2 ch, 2 ch + 1
+                                mf[ch] = make_float2((float)((xbits >> (2 * ch)) & 1u), (float)((xbits >> (2 * ch + 1)) & 1u));
+                            }
+                            if (q == 0) mf[16] = make_float2(1.0f, 0.0f);  // float(player == current_player), unused feature
+                            reinterpret_cast<float4 *>(mem_mask + (size_t)row * 16)[q] =
+                                make_float4((float)((xbits >> (4 * q)) & 1u), (float)((xbits >> (4 * q + 1)) & 1u), (float)((xbits >> (4 * q + 2)) & 1u), (float)((xbits >> (4 * q + 3)) & 1u));
+                        }
                     }
                 } else {
                     // opponent: sample ONE action (:347-365); the four lanes of a node draw the same number
@@ -600,55 +671,51 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                         for (int k = 1; k < 4; k++) last = k < nl ? cdf[k] : last;
                         a = 0;
 #pragma unroll
-                        for (int k = 0; k < 4; k++) if (k < nl && cdf[k] / last <= u) a = k + 1;
-                        a = a < nl - 1 ? a : nl - 1;
+                        for (int k = 0; k < 3; k++) if (k < nl - 1 && cdf[k] / last <= u) a = k + 1;   // (cdf[nl - 1] / last = 1 > u: never)
                     }
-                    if (live && q == 0) ws.idx[t][idx_at(d + 1) + j] = (uint16_t)(node * nl + a);
+                    if (live && q == 0) ws.idx[cb ^ 1][f] = (uint16_t)(node * nl + a);
                 }
-                sd_sync();
+                sd_order();
                 SD_STAMP(4);
             }
+            cb ^= 1;
             if (trav_ply) width *= nl;
         }
         // ---- leaves, then backward ---------------------------------------------------------------------------------------
         for (int f = lane; f < T * width; f += 64) {
-            int t = 0;
-#pragma unroll
-            for (int k = 1; k < T; k++) t += f >= k * width;
-            const int p0 = g_payoff[ws.idx[t][idx_at(8) + f - t * width]];
-            ws.val[0][f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
+            const int p0 = g_payoff[ws.idx[cb][f]];
+            ws.val[f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
         }
-        sd_sync();
-        int cur = 0;
+        sd_order();
 #pragma unroll 1
         for (int d = kPlies - 1; d >= 0; d--) {
             const int p = d & 1, nl = 4 - (d >> 1);
-            const bool trav_ply = p == traverser;
-            if (trav_ply) width /= nl;
+            if (p != traverser) continue;                                  // opponent ply: the sampled child's value is returned unchanged (:363-365), same position
+            width /= nl;
             const int m = (d - traverser) >> 1;
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
             for (int f = lane; f < T * width; f += 64) {
-                if (!trav_ply) { ws.val[cur ^ 1][f] = ws.val[cur][f]; continue; }   // the sampled child's value is returned unchanged (:363-365)
                 int t = 0;
 #pragma unroll
                 for (int k = 1; k < T; k++) t += f >= k * width;
                 const int j = f - t * width;
-                const uint2 inf = g_ninfo[level_offset(d) + ws.idx[t][idx_at(d) + j]];
-                const uint32_t xbits = inf.x, hand = inf.y;
+                const uint32_t hr = ws.hr[t][moff + j], hand = hr & 0xFFFFu, rank = hr >> 16;
+                const float4 pol = *reinterpret_cast<const float4 *>(&ws.pol_trav[t][moff + j][0]);
+                const float pl[4] = {pol.x, pol.y, pol.z, pol.w};
                 float value = 0.0f, cfv[16];
 #pragma unroll
                 for (int cc = 0; cc < 16; cc++) cfv[cc] = 0.0f;           // counterfactual_values = zeros(16) (:324)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k < nl) {
-                        const float av = ws.val[cur][(t * width + j) * nl + k];
-                        value += ws.pol_trav[t][moff + j][k] * av;           // value += policy[action] * action_value, float32 (:335)
+                        const float av = ws.val[f * nl + k];
+                        value += pl[k] * av;                                 // value += policy[action] * action_value, float32 (:335)
                         const int c = (int)((hand >> (4 * k)) & 15u);
 #pragma unroll
                         for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
                     }
                 }
-                ws.val[cur ^ 1][f] = value;
+                ws.val[f] = value;
                 if (t < n_live) {
                     float mx = 0.0f, reg[16];
 #pragma unroll
@@ -658,35 +725,27 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
 #pragma unroll
                         for (int cc = 0; cc < 16; cc++) reg[cc] = reg[cc] / den;    // add_experience (:73-74)
                     }
-                    // ring position: the reference appends in DFS post-order; rank of this traverser node within its traversal
-                    const int Tn[4] = {41, 10, 3, 1};          // traverser nodes in the subtree of a traverser node of ply index m
-                    int jj = j, rank = Tn[m] - 1;
-                    for (int qd = m - 1; qd >= 0; qd--) { const int radix = 4 - qd; rank += (jj % radix) * Tn[qd + 1]; jj /= radix; }
-                    const long long row = (write_base + (long long)(tb0 + t) * 41 + rank) % capacity;
-                    float2 *mf = reinterpret_cast<float2 *>(mem_feat + row * 34);          // 136-byte rows: 8-byte aligned
-                    float4 *mm = reinterpret_cast<float4 *>(mem_mask + row * 16), *mr = reinterpret_cast<float4 *>(mem_regret + row * 16);
+                    uint32_t row = row0 + 41u * (uint32_t)t + rank;
+                    row = row >= capacity ? row - capacity : row;
+                    float4 *mr = reinterpret_cast<float4 *>(mem_regret + (size_t)row * 16);
 #pragma unroll
-                    for (int i = 0; i < 16; i++) mf[i] = make_float2((float)((xbits >> (2 * i)) & 1u), (float)((xbits >> (2 * i + 1)) & 1u));
-                    mf[16] = make_float2(1.0f, 0.0f);
-#pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        mm[i] = make_float4((float)((xbits >> (4 * i)) & 1u), (float)((xbits >> (4 * i + 1)) & 1u), (float)((xbits >> (4 * i + 2)) & 1u), (float)((xbits >> (4 * i + 3)) & 1u));
-                        mr[i] = make_float4(reg[4 * i], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]);
-                    }
+                    for (int i = 0; i < 4; i++) mr[i] = make_float4(reg[4 * i], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]);
                 }
             }
-            cur ^= 1;
-            sd_sync();
+            sd_order();
         }
-        if (lane < n_live) root_values[tb0 + lane] = ws.val[cur][lane];
-        sd_sync();
+        if (lane < n_live) root_values[tb0 + lane] = ws.val[lane];
+        sd_order();
         SD_STAMP(6);
         int got = 0;
         if (lane == 0) got = atomicAdd(s_next, 1);
         c = __builtin_amdgcn_readfirstlane(got);
         SD_STAMP(7);
 #ifdef SCOPA_WALK_STAMPS
-        if (blockIdx.x == 0 && threadIdx.x == 0) g_sd_stamps[15] += 1;
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int i = 0; i < 8; i++) g_sd_stamps[i] += sd_acc_[i];
+            g_sd_stamps[13] += clock64() - sd_t0_; g_sd_stamps[14] += wall_clock64() - sd_r0_; g_sd_stamps[15] += 1;
+        }
 #endif
     }
 }
@@ -726,7 +785,9 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
     if (!ctx || traverser < 0 || traverser > 1 || batch < 0 || (batch && (!d_image || !d_mem_feat || !d_mem_regret || !d_mem_mask || !d_root_values)))
         return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_traverse_fused: no deal set");
-    SC_REQUIRE(ctx, capacity >= 41 && (int64_t)batch * 41 <= capacity && write_base >= 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: memory ring too small for the batch");
+    SC_REQUIRE(ctx, capacity >= 41 && (int64_t)batch * 41 <= capacity, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: memory ring too small for the batch");
+    SC_REQUIRE(ctx, write_base >= 0 && write_base < capacity && capacity < ((int64_t)1 << 30), SCOPA_EINVAL,
+               "scopa_sdcfr_traverse_fused: write_base must lie in [0, capacity) and capacity below 2^30 rows");
     SC_REQUIRE(ctx, ((uintptr_t)d_image & 15) == 0, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: the weight image must be 16-byte aligned");
     SC_REQUIRE(ctx, ((uintptr_t)d_mem_feat & 7) == 0 && ((uintptr_t)d_mem_regret & 15) == 0 && ((uintptr_t)d_mem_mask & 15) == 0, SCOPA_EINVAL,
                "scopa_sdcfr_traverse_fused: memory rows are stored 8 / 16 bytes at a time: d_mem_feat must be 8-byte, d_mem_regret / d_mem_mask 16-byte aligned");
@@ -743,19 +804,19 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
     int T = ctx->sdcfr_tile_t;
     if (T == 0) T = 4;
     const size_t wave_bytes = T == 4 ? sizeof(SdWave<4>) : sizeof(SdWave<2>);
-    const size_t lds = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kSdWaves * wave_bytes;
+    const size_t lds = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kSdNodeSlots * sizeof(uint2) + (size_t)kSdWaves * wave_bytes;
     SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
     const int n_tasks = (batch + T - 1) / T;
     const int grid = n_tasks < ctx->n_cus ? n_tasks : ctx->n_cus;
     if (T == 4) {
         SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse<4>, ctx->lds_limit - 64);   // 64: the kernel's static LDS (s_next), beside the dynamic part
         hipLaunchKernelGGL(k_sdcfr_traverse<4>, dim3(grid), dim3(kSdWaves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, d_image,
-                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, d_root_values,
+                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, (uint32_t)write_base, d_root_values,
                            d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
     } else {
         SC_LDS_ATTR(ctx, scopa::kLdsSdcfr2, k_sdcfr_traverse<2>, ctx->lds_limit - 64);
         hipLaunchKernelGGL(k_sdcfr_traverse<2>, dim3(grid), dim3(kSdWaves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, d_image,
-                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (long long)capacity, (long long)write_base, d_root_values,
+                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, (uint32_t)write_base, d_root_values,
                            d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
     }
     SC_HIP(ctx, hipGetLastError());

@@ -11,8 +11,10 @@ from scopa_amd.envs import load_game
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 d = DeepCFR(load_game("mini_scopa"), device="cuda:0", batch=B)
+if os.environ.get("SCOPA_SDCFR_T"):
+    d._engine.ctx.sdcfr_tile_traversals(int(os.environ["SCOPA_SDCFR_T"]))
 lib = ctypes.CDLL(os.environ["SCOPA_HIP_LIBRARY"])
-names = ["state load", "layer 1", "layer 2", "layer 3 + policy", "expand / sample", "skipped plies", "leaves + backward", "take next"]
+names = ["frontier info", "layer 1", "layer 2", "layer 3 + policy", "expand / sample", "skipped plies", "leaves + backward", "take next"]
 for p in (0, 1):
     d._traverse_batch(p, B); torch.cuda.synchronize()
     out = np.zeros(16, np.uint64)
@@ -22,6 +24,7 @@ for p in (0, 1):
     torch.cuda.synchronize()
     lib.scopa_debug_sdcfr_stamps(out.ctypes.data_as(ctypes.c_void_p), 1)
     n = float(out[15]); tot = float(out[:8].sum()) / n
-    print(f"traverser {p}, B={B}: {int(n)} traversals of wave 0; {tot:.0f} clocks per traversal")
+    print(f"traverser {p}, B={B}: {int(n)} tasks (4 traversals each unless SCOPA_SDCFR_T=2) of wave 0; {tot:.0f} clocks per task")
+    print(f"  shader clock while a task runs: {float(out[13]) / max(float(out[14]), 1.0) * 100.0:.0f} MHz ({float(out[13]) / n:.0f} clocks per task incl. stamping)")
     for k, nm in enumerate(names):
         print(f"  {nm:18s} {float(out[k]) / n:9.0f}  {100 * float(out[k]) / n / tot:5.1f} %")
