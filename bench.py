@@ -140,11 +140,13 @@ def cpu_baseline_sdcfr(nets, target_s=10.0):
             "reference_python_visits_per_s": "930-2900 (BASELINE.md section 2: reference DeepCFR._external_sampling_cfr, 1 Xeon core)"}
 
 
-def main_sdcfr(args):
+def run_sdcfr(args, emit=True):
     """--workload sdcfr: BASELINE configs[3] (N = 1) / configs[4] (N > 1).  A step is one iteration of DeepCFR.train
     (deep_cfr.py:431-495) without its evaluation: per player, `batch` external-sampling traversals in one launch of
     k_sdcfr_traverse filling the device-resident memory ring, then the advantage net's Adam epochs on PyTorch-ROCm
-    (N > 1: traversal ids sharded by rank, one flat gradient all-reduce per optimiser step)."""
+    (N > 1: traversal ids sharded by rank, one flat gradient all-reduce per optimiser step).
+    emit=False (the default `python bench.py` run, N = 1): returns the record instead of printing it -- it becomes the "sdcfr"
+    sub-record of the one JSON line, measured in the same process after the MCCFR measurement."""
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -176,6 +178,8 @@ def main_sdcfr(args):
     sys.stdout.flush()
     os.dup2(_so, 1)
     ctx = d._engine.ctx
+    if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):       # kernel experiments: task shape of k_sdcfr_traverse
+        ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))
     epochs = args.sdcfr_epochs
 
     def step():
@@ -225,6 +229,7 @@ def main_sdcfr(args):
     assert visits == (105 + 82) * batch * args.steps * world
     kern_ms = [a.elapsed_time(b) for a, b in d.kernel_events]
     d.kernel_events = None
+    out = None
     if rank == 0:
         kern_s = 1e-3 * sum(kern_ms) / max(len(kern_ms), 1)              # one launch = one player's batch
         v_launch = (105 + 82) / 2.0 * batch                              # visits per launch, averaged over the two traversers
@@ -233,7 +238,9 @@ def main_sdcfr(args):
         alg_b = 412.0
         bounds = {"mfma-f32": {"achieved": flop_visit * fwd_launch / kern_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
                                "how": "27 136 FLOP (one 34-128-64-16 forward) x forward passes per launch (81 / 58 of the 105 / 82 visits of a traversal) / kernel time "
-                                      "against the f32 matrix peak (v_mfma_f32_4x4x1 runs at the f32 vector rate)"},
+                                      "against the f32 matrix peak at 2.4 GHz (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD; the kernel pads tiles of 16 nodes: it issues "
+                                      "4.5 % more FLOP than counted here).  The shader clock holds ~2.15 GHz while this kernel runs (in-kernel s_memtime / s_memrealtime, "
+                                      "profiles/r03_sdcfr_stamps.txt), i.e. 0.89 of this peak is the most the clock allows"},
                   "hbm-algorithmic": {"achieved": alg_b * v_launch / kern_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                                       "how": "SURVEY 8(d): 412 B per visit (state, features, mask, advantages, memory rows) x visits per launch / kernel time"}}
         for b in bounds.values():
@@ -252,8 +259,9 @@ def main_sdcfr(args):
                "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms)},
                "roofline": {"bound": top, "achieved": bounds[top]["achieved"], "peak": bounds[top]["peak"], "unit": bounds[top]["unit"], "frac": bounds[top]["frac"],
                             "traffic": None, "kernel": "k_sdcfr_traverse", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,
-                            "note": "kernel time from events recorded on the kernel's stream around each launch; both nets (2 x 55 KB) and the per-wavefront frontier "
-                                    "live in LDS, HBM sees the 41 x 264 B memory rows per traversal; the kernel is bound by dependent MFMA / LDS latency at 2.5 waves per SIMD"},
+                            "note": "kernel time from events recorded on the kernel's stream around each launch; both nets (2 x 54 KB as MFMA operand images), the "
+                                    "node table and the per-team frontier live in LDS, activations stay in registers (an accumulator tile is the next layer's B operand), "
+                                    "HBM sees the 41 x 264 B memory rows per traversal; SQ counter passes: profiles/r03_pmc_sq_sdcfr_traverse.json"},
                "decision_visits": visits}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sdcfr(nets)
@@ -261,10 +269,13 @@ def main_sdcfr(args):
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)
-        print(json.dumps(out), flush=True)
+        if emit:
+            print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    ctx.sdcfr_visits()            # also asks the library whether a team barrier of the fused kernel ever gave up (raises if so)
+    return out
 
 
 def load_profile_json(name):
@@ -290,6 +301,8 @@ def main():
     ap.add_argument("--pre-phase-s", type=float, default=PRE_PHASE_S, help="seconds of untimed iterations before anything is timed (0 for profiler passes that count every dispatch)")
     ap.add_argument("--prof-stride", type=int, default=0, help="bracket every n-th traversal launch with HIP events (0 = so that >= 64 launches are timed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-sdcfr", action="store_true", help="N = 1 mccfr run: leave out the SDCFR sub-record (BASELINE configs[3], measured after the MCCFR workload in the same process)")
+    ap.add_argument("--sdcfr-steps", type=int, default=20, help="timed SDCFR iterations of that sub-record")
     ap.add_argument("--exchange", choices=["auto", "p2p", "rccl"], default="auto",
                     help="N>1 delta all-reduce: library one-shot peer-memory exchange (validated against RCCL first), or torch.distributed/RCCL")
     ap.add_argument("--exchange-form", choices=["auto", "light", "fenced"], default="auto",
@@ -307,7 +320,8 @@ def main():
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus, sys.argv[1:]))
     if args.workload == "sdcfr":
-        return main_sdcfr(args)
+        run_sdcfr(args)
+        return
 
     import numpy as np
     import torch
@@ -343,7 +357,7 @@ def main():
     coll_dev = torch.device("cpu") if args.share_gpu else dev     # where small collectives' tensors live
 
     perm = _lib.deal_py_seed(42)
-    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, world=2 if use_dist else 1, rank=rank,
+    ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, distributed=use_dist, rank=rank,
                                                       exchange=args.exchange, exchange_form=args.exchange_form)
     batch_total = args.batch * world
     # --force-dist with one rank still takes the exchange step (always_exchange), so the N>1 code path can be timed on one GPU
@@ -427,7 +441,6 @@ def main():
     stride = args.prof_stride if args.prof_stride > 0 else max(1, (args.steps * regions) // 64)
     d0, _ = ctx.counters()
     ctx.prof_enable(stride)
-    dev_n0, dev_ms0 = 0, 0.0
     times = []
     for _ in range(regions):
         fence()
@@ -497,7 +510,7 @@ def main():
             "bound": top, "achieved": bounds[top]["achieved"] if top else None, "peak": bounds[top]["peak"] if top else None,
             "unit": bounds[top]["unit"] if top else None, "frac": bounds[top]["frac"] if top else None, "traffic": traffic,
             "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
-            "kernel_avg_us_device_clock": 1e3 * (dev_ms1 - dev_ms0) / max(dev_n1 - dev_n0, 1), "launches_device_clock": dev_n1 - dev_n0,
+            "kernel_avg_us_device_clock": 1e3 * dev_ms1 / max(dev_n1, 1), "launches_device_clock": dev_n1,
             "workgroup_phase_us": {"prologue": phases[0], "walks": phases[1], "epilogue": phases[2]},
             "bounds": bounds,
             "bound_note": "the kernel's working set (frozen strategy rows, delta table, tree maps) is LDS-resident by design, so the resources that can "
@@ -511,7 +524,8 @@ def main():
             "timing_note": "kernel_avg_us: HIP start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL) of every "
                            "prof-stride-th launch on the kernel's stream -- the kernel's own begin/end timestamps, what rocprofv3 "
                            "reports as its duration; kernel_avg_us_device_clock: first workgroup start -> last workgroup end on the "
-                           "100 MHz device clock, every launch of the timed regions (launch ramp and end-of-kernel write-back excluded)",
+                           "100 MHz device clock over the SAMPLED launches (the same prof-stride; the library keeps the last 2048 samples and "
+                           "skips launches of more than 512 workgroups): launch ramp and end-of-kernel write-back excluded; prof_stride = " + str(stride),
         }
         out = {
             "metric": "MiniScopa infoset-traversals/sec", "value": visits_per_region / med, "unit": "infoset-traversals/s",
@@ -561,6 +575,14 @@ def main():
                 out["large_batch"] = {"batch_per_gpu": big, "value": (ctx.counters()[0] - c0) / dtb, "ms_per_step": 1e3 * dtb / 1000}
             except Exception as e:
                 out["large_batch"] = {"error": repr(e)}
+        if world == 1 and not use_dist and not args.no_sdcfr:
+            # BASELINE configs[3] under the same clock: SDCFR at 4096 traversals per player, its own step definition and roofline block
+            try:
+                sub = argparse.Namespace(**vars(args))
+                sub.workload, sub.batch, sub.steps, sub.warmup, sub.gpus = "sdcfr", 4096, max(20, args.sdcfr_steps), 3, 1
+                out["sdcfr"] = run_sdcfr(sub, emit=False)
+            except Exception as e:
+                out["sdcfr"] = {"error": repr(e)}
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

@@ -203,8 +203,9 @@ int32_t scopa_sdcfr_pack_weights(scopa_ctx *ctx, int32_t player, const float *d_
 int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_image, float *d_mem_feat,
                                    float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
                                    float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0);
-/* experiments: traversals a wavefront of the fused kernel walks together (0 = the library's choice, 2 or 4) */
-int32_t scopa_sdcfr_tile_traversals(scopa_ctx *ctx, int32_t traversals_per_wavefront);
+/* experiments: traversals per task of the fused kernel (0 = the library's choice, 2 or 4) and wavefronts that share a task's
+ * tiles (0 = the library's choice, 1..3).  Results do not depend on either. */
+int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task);
 /* features / masks of arbitrary device-resident states for the player to move (DeepCFR.get_policy, :497-504) */
 int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask);
 /* batched evaluation episodes (evaluate_vs_random :367-429; evaluate_agent vanilla_cfr.py:157-216): n copies of the deal's

@@ -26,7 +26,7 @@ SYMBOLS = [
     "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_mode", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
-    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tile_traversals", "scopa_features_from_states",
+    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
     "scopa_multi_cfr_exact_iterate_lanes", "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
@@ -130,7 +130,7 @@ def lib():
         "scopa_sdcfr_traverse_fused": (i32, [vp, i32, i32, vp, vp, vp, vp, i64, i64, vp, vp, u32, u32]),
         "scopa_sdcfr_image_floats": (i32, []),
         "scopa_sdcfr_pack_weights": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
-        "scopa_sdcfr_tile_traversals": (i32, [vp, i32]),
+        "scopa_sdcfr_tuning": (i32, [vp, i32, i32]),
         "scopa_features_from_states": (i32, [vp, vp, i64, vp, vp]),
         "scopa_eval_init_states": (i32, [vp, vp, i64]),
         "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
@@ -401,8 +401,9 @@ class Context:
         self._ck(self._L.scopa_sdcfr_pack_weights(self._h, player, *(C.c_void_p(x) for x in (w1_ptr, b1_ptr, w2_ptr, b2_ptr, w3_ptr, b3_ptr, image_ptr))),
                  "scopa_sdcfr_pack_weights")
 
-    def sdcfr_tile_traversals(self, t):
-        self._ck(self._L.scopa_sdcfr_tile_traversals(self._h, t), "scopa_sdcfr_tile_traversals")
+    def sdcfr_tuning(self, traversals_per_task=0, wavefronts_per_task=0):
+        """experiments: task shape of the fused traversal kernel (0 = the library's choice); results do not depend on it"""
+        self._ck(self._L.scopa_sdcfr_tuning(self._h, traversals_per_task, wavefronts_per_task), "scopa_sdcfr_tuning")
 
     def sdcfr_traverse_fused(self, traverser, batch, weights_ptr, mem_feat_ptr, mem_regret_ptr, mem_mask_ptr, capacity, write_base,
                              root_values_ptr, uniforms_ptr, iteration, b0):

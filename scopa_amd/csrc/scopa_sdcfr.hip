@@ -212,6 +212,12 @@ int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, 
 int32_t scopa_sdcfr_visits(scopa_ctx *ctx, uint64_t *decision_visits) {
     if (!ctx || !decision_visits) return SCOPA_EINVAL;
     *decision_visits = ctx->sdcfr_visits;
+    // the fused kernel's team barriers give up after about a second and say so here (d_counters[5]): waits for the stream
+    unsigned long long err = 0;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    SC_HIP(ctx, hipMemcpyAsync(&err, ctx->d_counters + 5, sizeof err, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    SC_REQUIRE(ctx, err == 0, SCOPA_ETIMEOUT, "scopa_sdcfr_visits: a team barrier of k_sdcfr_traverse timed out -- the traversal results since the last check are invalid");
     return SCOPA_OK;
 }
 
@@ -325,19 +331,26 @@ constexpr int kImgB3 = kImgW3 + 1024;     // [16]                               
 constexpr int kImgFloats = kImgB3 + 16;   // 13 520 (the 13 776 parameters less W1's columns 32, 33)
 static_assert(kImgFloats == SCOPA_SDCFR_IMAGE_FLOATS, "include/scopa.h states the image size");
 
-template <int T>
-struct alignas(16) SdWave {     // per-wavefront scratch: T traversals in flight; a frontier node is addressed by its POSITION f = t * width + j
+template <int T, int W>
+struct alignas(16) SdTeam {     // scratch of one TEAM (W wavefronts walking one task = T traversals); a frontier node is addressed by its POSITION f = t * width + j
     float pol_trav[T][41][4];   // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
     uint32_t hr[T][41];         // the same nodes' hand nibbles | DFS post-order rank << 16 (the backward pass needs nothing else of them)
-    float val[T * 24];          // values of the frontier flowing back up, by position; a traverser ply replaces them IN PLACE: node f reads its
-                                // children f nl + k >= f and the wavefront's 64 lanes read before any of them writes (LDS executes its operations in
-                                // order); a second round (positions >= 64) reads positions >= 64 nl, which the first round did not write
-    float pos[16][16];          // relu(adv) * mask of the tile in flight, [node][output]
+    float val[W > 1 ? 2 : 1][T * 24];   // values of the frontier flowing back up, by position.  A team's wavefronts work on a ply's positions side by
+                                // side: two buffers.  A solo wavefront replaces them IN PLACE: node f reads its children f nl + k >= f, the 64 lanes read
+                                // before any of them writes (LDS executes a wavefront's operations in order), and a second round (positions >= 64) reads
+                                // positions >= 64 nl, which the first round did not write
     uint16_t idx[2][T * 24];    // tree index of the frontier nodes of the current / the next ply
+    uint32_t bar;               // arrivals at the team's barriers so far (monotonic)
+    int32_t task;               // the task the team walks next
+    uint32_t pad[2];
 };
-static_assert(sizeof(SdWave<4>) % 16 == 0 && sizeof(SdWave<2>) % 16 == 0, "SdWave alignment");
+struct alignas(16) SdPos { float pos[16][16]; };   // per wavefront: relu(adv) * mask of the tile in flight, [node][output]
+static_assert(sizeof(SdTeam<4, 1>) % 16 == 0 && sizeof(SdTeam<2, 1>) % 16 == 0 && sizeof(SdTeam<4, 2>) % 16 == 0 && sizeof(SdTeam<2, 2>) % 16 == 0, "SdTeam alignment");
 constexpr int kSdNodeSlots = (kDecision + 1) & ~1;   // the node table in LDS, padded to 16 bytes
-constexpr int kSdWaves = 8;     // wavefronts per workgroup: two per SIMD (one walks its tiles' matrix phases while the other samples / expands)
+static_assert(kTerminal % 16 == 0, "the payoff table in LDS keeps the team scratch behind it 16-byte aligned and is copied four bytes at a time");
+// wavefronts per workgroup: solo wavefronts (W = 1) need a scratch each and eight fit beside the two nets; teams share theirs, so
+// twelve wavefronts (three per SIMD, 168 registers each) fit as six teams of two or four teams of three
+__host__ __device__ constexpr int sd_waves(int W) { return W == 1 ? 8 : 12; }
 
 // A wavefront's LDS operations execute in order, so lane A's store is seen by lane B's later load without any wait; this only
 // keeps the compiler from moving LDS accesses across the point (the wait for a load's data is the compiler's own s_waitcnt).
@@ -345,6 +358,26 @@ __device__ __forceinline__ void sd_order() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// Barrier of the W wavefronts of a team (W = 1: only the compiler-level ordering).  Arrival = one LDS atomic; LDS executes a
+// wavefront's operations in order, so everything a wavefront wrote to LDS before arriving is in place when its arrival is seen.
+// All W wavefronts of a team belong to one workgroup (resident together) and execute the same sequence of barriers.
+// The wait is bounded (about a second): a wavefront that gives up reports it in *g_err and goes on, so that a defect can end in a
+// wrong result that the host refuses (scopa_sdcfr_visits / scopa_ctx_synchronize report SCOPA_ETIMEOUT) but never in a hung GPU.
+template <int W>
+__device__ __forceinline__ void team_barrier(uint32_t *bar, uint32_t &phase, int lane, uint32_t *g_err) {
+    sd_order();
+    if (W > 1) {
+        phase += W;
+        if (lane == 0) atomicAdd(bar, 1u);
+        int spins = 0;
+        while ((int32_t)(*reinterpret_cast<volatile uint32_t *>(bar) - phase) < 0) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > (1 << 23)) { if (lane == 0) atomicOr(g_err, 1u); break; }
+        }
+        sd_order();
+    }
 }
 
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -413,34 +446,49 @@ __device__ unsigned long long g_sd_stamps[16];   // 1 layer 1 | 2 layer 2 | 3 la
 #define SD_STAMP(i) do { } while (0)
 #endif
 
-template <int T>
-__global__ void __launch_bounds__(kSdWaves * 64)
+// REPLAY: the opponent draws come from the caller's uniforms (tests) instead of Philox.  A template parameter and not a run-time
+// branch because the compiler cannot tell a global LOAD pending in one arm from none: with the branch in the loop it waited for
+// vmcnt(0) at the end of every tile and before every draw -- i.e. for the memory-row STORES of the tiles before (one counter).
+template <int T, int W, bool REPLAY>
+__global__ void __launch_bounds__(sd_waves(W) * 64)
 k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float *__restrict__ g_image,
                  int traverser, int batch, float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask,
                  uint32_t capacity, uint32_t write_base, float *__restrict__ root_values, const double *__restrict__ uniforms,
-                 uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
+                 uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t *__restrict__ g_err) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_next[1];                                               // next task of this workgroup not taken yet
     float *s_w = reinterpret_cast<float *>(smem);                           // [2][kImgFloats]
     uint2 *s_node = reinterpret_cast<uint2 *>(s_w + 2 * kImgFloats);        // [kDecision (+1 pad)]: feature bits | hand nibbles of every decision node
-    SdWave<T> *s_wave = reinterpret_cast<SdWave<T> *>(s_node + kSdNodeSlots);   // [wavefronts]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6;
-    if (tid == 0) s_next[0] = n_waves;
+    constexpr int kTeams = sd_waves(W) / W;
+    int8_t *s_payoff = reinterpret_cast<int8_t *>(s_node + kSdNodeSlots);   // [kTerminal]: rewards x 2 of player 0 at the leaves
+    SdTeam<T, W> *s_team = reinterpret_cast<SdTeam<T, W> *>(s_payoff + kTerminal);   // [kTeams]
+    SdPos *s_pos = reinterpret_cast<SdPos *>(s_team + kTeams);               // [wavefronts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int team = wave / W, wr = wave % W;                               // consecutive wavefronts form a team: they sit on different SIMDs
+    if (tid == 0) s_next[0] = kTeams;
+    if (tid < kTeams) s_team[tid].bar = 0;
     for (int i = tid; i < 2 * kImgFloats / 4; i += blockDim.x)
         reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image)[i];
-    for (int i = tid; i < kDecision; i += blockDim.x) s_node[i] = g_ninfo[i];   // 13 KB: with it in LDS the forward pass makes no global load at all, so
-    __syncthreads();                                                            // nothing ever waits behind the memory-row stores (one vmcnt queue)
-    SdWave<T> &ws = s_wave[wave];
+    for (int i = tid; i < kDecision; i += blockDim.x) s_node[i] = g_ninfo[i];   // 13 KB + 576 B: with them in LDS a task makes no global load at all, so
+    for (int i = tid; i < kTerminal / 4; i += blockDim.x)                       // nothing ever waits behind the memory-row stores (one vmcnt queue)
+        reinterpret_cast<uint32_t *>(s_payoff)[i] = reinterpret_cast<const uint32_t *>(g_payoff)[i];
+    __syncthreads();
+    SdTeam<T, W> &ws = s_team[team];
+    float (*wpos)[16] = s_pos[wave].pos;
+    uint32_t phase = 0;                        // arrivals the team's barrier counter shows once everybody has reached this wavefront's latest barrier
     const int nj = lane & 15, q = lane >> 4;   // this lane's column (node of the tile) and K / row group
 
-    // A TASK is T consecutive traversals (the last one of a batch may be short).  The workgroup owns tasks [first, first + count)
-    // and its wavefronts TAKE them from a counter in LDS (the first one is static): the SIMD's arbiter favours its oldest
-    // wavefront, so equal shares would leave the workgroup waiting for its slowest (scopa_mccfr.hip, main loop, has the
-    // measurement).  Which wavefront walks a traversal does not matter: draws and memory-row positions are keyed by its id.
+    // A TASK is T consecutive traversals (the last one of a batch may be short), walked by a TEAM of W wavefronts that share the
+    // tiles of every ply (tile i goes to wavefront i mod W) and meet at a team barrier between plies: a ply's tiles are independent
+    // of each other, and a single wavefront's task is a chain of 21 tiles of which a small batch (one task per SIMD at 4096
+    // traversals) hides nothing.  The workgroup owns tasks [first, first + count) and its teams TAKE them from a counter in LDS
+    // (the first one is static): the SIMD's arbiter favours its oldest wavefront, so equal shares would leave the workgroup
+    // waiting for its slowest (scopa_mccfr.hip, main loop, has the measurement).  Who walks a traversal does not matter: draws
+    // and memory-row positions are keyed by its id.
     const int n_tasks = (batch + T - 1) / T;
     const int per_wg = (n_tasks + (int)gridDim.x - 1) / (int)gridDim.x;
     const int first = (int)blockIdx.x * per_wg, count = first < n_tasks ? (n_tasks - first < per_wg ? n_tasks - first : per_wg) : 0;
-    for (int c = wave; c < count;) {
+    for (int c = team; c < count;) {
         const int tb0 = (first + c) * T;                                    // the task's first traversal (local id within the batch)
         const int n_live = batch - tb0 < T ? batch - tb0 : T;               // traversals t >= n_live are walked like the others but write nothing
         // ring row of the task's first memory row: write_base < capacity and 41 * batch <= capacity (checked on the host), so one
@@ -452,8 +500,8 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
         const unsigned long long sd_t0_ = clock64(), sd_r0_ = wall_clock64();
         unsigned long long sd_prev_ = sd_t0_;
 #endif
-        if (lane < T) ws.idx[0][lane] = 0;
-        sd_order();
+        if (wr == 0 && lane < T) ws.idx[0][lane] = 0;
+        team_barrier<W>(&ws.bar, phase, lane, g_err);
         int width = 1, cb = 0;                                              // a traversal's frontier width at the current ply; which half of ws.idx holds it
         // ---- forward: plies 0..7 ----------------------------------------------------------------------------------------
 #pragma unroll 1
@@ -468,14 +516,15 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
             const int n_nodes = T * width;
             const int m = (d - traverser) >> 1;                             // traverser-ply index when trav_ply
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
-            const uint2 *nodes_d = s_node + level_offset(d);
-            const float *W = s_w + p * kImgFloats;
-            const float4 *w1 = reinterpret_cast<const float4 *>(W + kImgW1) + lane;
-            const float4 *c1 = reinterpret_cast<const float4 *>(W + kImgC1) + q;
-            const float4 *w2 = reinterpret_cast<const float4 *>(W + kImgW2) + lane;
-            const float4 *b2 = reinterpret_cast<const float4 *>(W + kImgB2) + q;
-            const float4 *w3 = reinterpret_cast<const float4 *>(W + kImgW3) + lane;
-            const float4 *b3 = reinterpret_cast<const float4 *>(W + kImgB3) + q;
+            const uint2 *nodes_d = s_node + (d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 21 : d == 4 ? 69 : d == 5 ? 213 : d == 6 ? 501 : 1077);   // level_offset(d) as
+                                                                                  // selects: the table lookup is a scalar memory load per ply
+            const float *Wn = s_w + p * kImgFloats;
+            const float4 *w1 = reinterpret_cast<const float4 *>(Wn + kImgW1) + lane;
+            const float4 *c1 = reinterpret_cast<const float4 *>(Wn + kImgC1) + q;
+            const float4 *w2 = reinterpret_cast<const float4 *>(Wn + kImgW2) + lane;
+            const float4 *b2 = reinterpret_cast<const float4 *>(Wn + kImgB2) + q;
+            const float4 *w3 = reinterpret_cast<const float4 *>(Wn + kImgW3) + lane;
+            const float4 *b3 = reinterpret_cast<const float4 *>(Wn + kImgB3) + q;
             // layer 1's first step and bias do not depend on the tile: they are fetched for the NEXT tile under the current tile's
             // last MFMAs, so that a tile's first MFMA does not wait for them behind the previous tile's expansion
             float4 wa[8], c1v[8];
@@ -484,10 +533,10 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
 #pragma unroll
             for (int mt = 0; mt < 8; mt++) c1v[mt] = c1[mt * 4];
             // ... and so is the next tile's node (tree index, then its feature bits / hand nibbles: two dependent LDS reads)
-            uint32_t node_nx = ws.idx[cb][nj < n_nodes ? nj : n_nodes - 1];
+            uint32_t node_nx = ws.idx[cb][16 * wr + nj < n_nodes ? 16 * wr + nj : n_nodes - 1];
             uint2 inf_nx = nodes_d[node_nx];
 #pragma unroll 1
-            for (int f0 = 0; f0 < n_nodes; f0 += 16) {
+            for (int f0 = 16 * wr; f0 < n_nodes; f0 += 16 * W) {
                 const int f = f0 + nj;
                 const bool live = f < n_nodes;
                 const uint32_t xbits = inf_nx.x, hand = inf_nx.y, node = node_nx;   // lanes beyond the frontier compute a copy of its last node and store nothing
@@ -596,7 +645,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     for (int mt = 0; mt < 8; mt++) wa[mt] = w1[(mt * 2 + 0) * 64];     // the next tile's first step (above)
 #pragma unroll
                     for (int mt = 0; mt < 8; mt++) c1v[mt] = c1[mt * 4];
-                    { const int fn = f + 16; node_nx = ws.idx[cb][fn < n_nodes ? fn : n_nodes - 1]; inf_nx = nodes_d[node_nx]; }
+                    { const int fn = f + 16 * W; node_nx = ws.idx[cb][fn < n_nodes ? fn : n_nodes - 1]; inf_nx = nodes_d[node_nx]; }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                     for (int r = 0; r < 4; r++) adv[r] = o0[r] + o1[r];     // output 4 q + r of node nj
@@ -608,7 +657,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     float *pp = &pv.x;
 #pragma unroll
                     for (int r = 0; r < 4; r++) { pp[r] = (((xbits >> (4 * q + r)) & 1u) && adv[r] > 0.0f) ? adv[r] : 0.0f; z += pp[r]; }
-                    *reinterpret_cast<float4 *>(&ws.pos[nj][4 * q]) = pv;
+                    *reinterpret_cast<float4 *>(&wpos[nj][4 * q]) = pv;
                     z = sum_row_groups(z);                                 // the four row groups of the node's column
                 }
                 const float den = z > 1e-8f ? z : 1e-8f;                   // clamp_min(eps)
@@ -620,16 +669,21 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                 const int j = f - t * width;
                 if (trav_ply) {
                     // recurse on ALL legal actions, hand order (:326-336): lane (q, node) takes action q
-                    const float pk = q < nl ? ws.pos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;
+                    const float pk = q < nl ? wpos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;
                     if (live) {
                         ws.pol_trav[t][moff + j][q] = pk;
                         if (q < nl) ws.idx[cb ^ 1][f * nl + q] = (uint16_t)(node * nl + q);
                         // the node's memory row (:339-346): where, and everything of it that does not wait for the values -- features
                         // and mask -- now, four lanes to a row; the regrets follow in the backward pass.
                         // Ring position: the reference appends in DFS post-order; rank of this traverser node within its traversal
-                        const int Tn[4] = {41, 10, 3, 1};                  // traverser nodes in the subtree of a traverser node of ply index m
-                        int jj = j, rank = Tn[m] - 1;
-                        for (int qd = m - 1; qd >= 0; qd--) { const int radix = 4 - qd; rank += (jj % radix) * Tn[qd + 1]; jj /= radix; }
+                        // = (41, 10, 3, 1)[m] - 1 + the digits of j (radices 4, 3, 2 from the top) times (10, 3, 1): written out per m with
+                        // constant divisors -- as a loop over a table it cost a scalar memory load per digit (each draining the LDS queue with
+                        // it: one lgkm counter) and a division by a run-time radix
+                        int rank;
+                        {
+                            const int jh = m == 3 ? j >> 1 : j, j1 = m >= 2 ? jh / 3 : jh, j2 = jh - 3 * j1;
+                            rank = m == 0 ? 40 : m == 1 ? 9 + 10 * j : m == 2 ? 2 + 3 * j2 + 10 * j1 : (j & 1) + 3 * j2 + 10 * j1;
+                        }
                         if (q == 0) ws.hr[t][moff + j] = hand | ((uint32_t)rank << 16);
                         if (t < n_live) {
                             uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)rank;
@@ -649,13 +703,13 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     // opponent: sample ONE action (:347-365); the four lanes of a node draw the same number
                     float pk[4];
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = k < nl ? ws.pos[nj][(hand >> (4 * k)) & 15u] / den : 0.0f;
+                    for (int k = 0; k < 4; k++) pk[k] = k < nl ? wpos[nj][(hand >> (4 * k)) & 15u] / den : 0.0f;
                     float sum = pk[0];
 #pragma unroll
                     for (int k = 1; k < 4; k++) if (k < nl) sum += pk[k];  // action_probs.sum(), float32, left to right
                     const int tb = tb0 + t;
                     double u;
-                    if (uniforms) u = (live && t < n_live) ? uniforms[((size_t)tb * kPlies + d) * 24 + j] : 0.0;
+                    if (REPLAY) u = (live && t < n_live) ? uniforms[((size_t)tb * kPlies + d) * 24 + j] : 0.0;
                     else {
                         const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)tb, iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
                         u = u53(x.x0, x.x1);
@@ -680,13 +734,15 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
             }
             cb ^= 1;
             if (trav_ply) width *= nl;
+            team_barrier<W>(&ws.bar, phase, lane, g_err);                          // the next ply reads what every wavefront of the team expanded
         }
         // ---- leaves, then backward ---------------------------------------------------------------------------------------
-        for (int f = lane; f < T * width; f += 64) {
-            const int p0 = g_payoff[ws.idx[cb][f]];
-            ws.val[f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
+        for (int f = lane + 64 * wr; f < T * width; f += 64 * W) {
+            const int p0 = s_payoff[ws.idx[cb][f]];
+            ws.val[0][f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
         }
-        sd_order();
+        team_barrier<W>(&ws.bar, phase, lane, g_err);
+        int cur = 0;
 #pragma unroll 1
         for (int d = kPlies - 1; d >= 0; d--) {
             const int p = d & 1, nl = 4 - (d >> 1);
@@ -694,7 +750,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
             width /= nl;
             const int m = (d - traverser) >> 1;
             const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
-            for (int f = lane; f < T * width; f += 64) {
+            for (int f = lane + 64 * wr; f < T * width; f += 64 * W) {
                 int t = 0;
 #pragma unroll
                 for (int k = 1; k < T; k++) t += f >= k * width;
@@ -708,14 +764,14 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k < nl) {
-                        const float av = ws.val[f * nl + k];
+                        const float av = ws.val[cur][f * nl + k];
                         value += pl[k] * av;                                 // value += policy[action] * action_value, float32 (:335)
                         const int c = (int)((hand >> (4 * k)) & 15u);
 #pragma unroll
                         for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
                     }
                 }
-                ws.val[f] = value;
+                ws.val[cur ^ (W > 1)][f] = value;
                 if (t < n_live) {
                     float mx = 0.0f, reg[16];
 #pragma unroll
@@ -732,14 +788,22 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     for (int i = 0; i < 4; i++) mr[i] = make_float4(reg[4 * i], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]);
                 }
             }
-            sd_order();
+            cur ^= (W > 1);
+            team_barrier<W>(&ws.bar, phase, lane, g_err);
         }
-        if (lane < n_live) root_values[tb0 + lane] = ws.val[lane];
-        sd_order();
+        if (wr == 0 && lane < n_live) root_values[tb0 + lane] = ws.val[cur][lane];
         SD_STAMP(6);
-        int got = 0;
-        if (lane == 0) got = atomicAdd(s_next, 1);
-        c = __builtin_amdgcn_readfirstlane(got);
+        // the team's next task: its first wavefront takes it (everybody has passed the barrier above, so the scratch is free)
+        if (W == 1) {
+            int got = 0;
+            if (lane == 0) got = atomicAdd(s_next, 1);
+            c = __builtin_amdgcn_readfirstlane(got);
+        } else {
+            if (wr == 0 && lane == 0) ws.task = atomicAdd(s_next, 1);
+            team_barrier<W>(&ws.bar, phase, lane, g_err);
+            c = __builtin_amdgcn_readfirstlane(*reinterpret_cast<volatile int32_t *>(&ws.task));
+            team_barrier<W>(&ws.bar, phase, lane, g_err);                          // nobody overwrites ws.task before all have read it
+        }
         SD_STAMP(7);
 #ifdef SCOPA_WALK_STAMPS
         if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -773,9 +837,11 @@ int32_t scopa_sdcfr_pack_weights(scopa_ctx *ctx, int32_t player, const float *d_
     return SCOPA_OK;
 }
 
-int32_t scopa_sdcfr_tile_traversals(scopa_ctx *ctx, int32_t traversals_per_wavefront) {
-    if (!ctx || (traversals_per_wavefront != 0 && traversals_per_wavefront != 2 && traversals_per_wavefront != 4)) return SCOPA_EINVAL;
-    ctx->sdcfr_tile_t = traversals_per_wavefront;
+int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task) {
+    if (!ctx || (traversals_per_task != 0 && traversals_per_task != 2 && traversals_per_task != 4) || wavefronts_per_task < 0 || wavefronts_per_task > 3)
+        return SCOPA_EINVAL;
+    ctx->sdcfr_tile_t = traversals_per_task;
+    ctx->sdcfr_team_w = wavefronts_per_task;
     return SCOPA_OK;
 }
 
@@ -799,26 +865,32 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         SC_HIP(ctx, hipGetLastError());
         ctx->sdnode_valid = true;
     }
-    // T traversals per wavefront: 4 fills the 16-node tiles best (21 tiles for traverser 0's 324 evaluated nodes); with fewer than
-    // 8 tasks of 4 per compute unit a wavefront per SIMD would walk alone, so small batches take 2 (26 tiles, twice the wavefronts)
-    int T = ctx->sdcfr_tile_t;
-    if (T == 0) T = 4;
-    const size_t wave_bytes = T == 4 ? sizeof(SdWave<4>) : sizeof(SdWave<2>);
-    const size_t lds = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kSdNodeSlots * sizeof(uint2) + (size_t)kSdWaves * wave_bytes;
+    // T traversals per task: 4 fills the 16-node tiles best (21 tiles for traverser 0's 324 evaluated nodes; 2: 26 tiles for twice
+    // the tasks).  W wavefronts per task: 1 = solo wavefronts, eight per compute unit; 2 / 3 = teams, twelve wavefronts per compute unit.
+    const int T = (ctx->sdcfr_tile_t && !d_uniforms) ? ctx->sdcfr_tile_t : 4;   // (replayed draws: the default shape only)
+    const int W = (ctx->sdcfr_team_w && !d_uniforms) ? ctx->sdcfr_team_w : 1;   // measured: solo wavefronts 110 / 620 us at 4096 / 32768 traversals, teams of two 121 / 788, of three 117 / 753
+    const int n_waves = sd_waves(W), n_teams = n_waves / W;
+    const size_t team_bytes = T == 4 ? (W == 1 ? sizeof(SdTeam<4, 1>) : sizeof(SdTeam<4, 2>)) : (W == 1 ? sizeof(SdTeam<2, 1>) : sizeof(SdTeam<2, 2>));
+    const size_t lds = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kSdNodeSlots * sizeof(uint2) + (size_t)kTerminal + (size_t)n_teams * team_bytes + (size_t)n_waves * sizeof(SdPos);
     SC_REQUIRE(ctx, lds + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS");
     const int n_tasks = (batch + T - 1) / T;
     const int grid = n_tasks < ctx->n_cus ? n_tasks : ctx->n_cus;
-    if (T == 4) {
-        SC_LDS_ATTR(ctx, scopa::kLdsSdcfr, k_sdcfr_traverse<4>, ctx->lds_limit - 64);   // 64: the kernel's static LDS (s_next), beside the dynamic part
-        hipLaunchKernelGGL(k_sdcfr_traverse<4>, dim3(grid), dim3(kSdWaves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, d_image,
-                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, (uint32_t)write_base, d_root_values,
-                           d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
-    } else {
-        SC_LDS_ATTR(ctx, scopa::kLdsSdcfr2, k_sdcfr_traverse<2>, ctx->lds_limit - 64);
-        hipLaunchKernelGGL(k_sdcfr_traverse<2>, dim3(grid), dim3(kSdWaves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, d_image,
-                           (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, (uint32_t)write_base, d_root_values,
-                           d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);
-    }
+#define SD_LAUNCH(TT, WW, RR, BIT)                                                                                                                      \
+    do {                                                                                                                                              \
+        SC_LDS_ATTR(ctx, BIT, (k_sdcfr_traverse<TT, WW, RR>), ctx->lds_limit - 64);   /* 64: the kernel's static LDS, beside the dynamic part */      \
+        hipLaunchKernelGGL((k_sdcfr_traverse<TT, WW, RR>), dim3(grid), dim3(n_waves * 64), lds, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, \
+                           d_image, (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, (uint32_t)write_base,       \
+                           d_root_values, d_uniforms, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0,                                \
+                           reinterpret_cast<uint32_t *>(ctx->d_counters + 5));                                                                        \
+    } while (0)
+    if (d_uniforms) SD_LAUNCH(4, 1, true, scopa::kLdsSdcfr7);
+    else if (T == 4 && W == 1) SD_LAUNCH(4, 1, false, scopa::kLdsSdcfr);
+    else if (T == 4 && W == 2) SD_LAUNCH(4, 2, false, scopa::kLdsSdcfr2);
+    else if (T == 4 && W == 3) SD_LAUNCH(4, 3, false, scopa::kLdsSdcfr3);
+    else if (T == 2 && W == 1) SD_LAUNCH(2, 1, false, scopa::kLdsSdcfr4);
+    else if (T == 2 && W == 2) SD_LAUNCH(2, 2, false, scopa::kLdsSdcfr5);
+    else SD_LAUNCH(2, 3, false, scopa::kLdsSdcfr6);
+#undef SD_LAUNCH
     SC_HIP(ctx, hipGetLastError());
     ctx->sdcfr_visits += (uint64_t)batch * (traverser == 0 ? 105 : 82);
     return SCOPA_OK;

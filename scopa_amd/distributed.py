@@ -21,10 +21,17 @@ class ShardedMCCFR:
     fused_exchange=True (a validated peer-memory exchange is connected, see connect_peer_exchange): the engine's
     mccfr_iterate_sharded(b0, nb, n) runs whole iterations in the library, the exchange inside the reduce+apply kernel."""
 
-    def __init__(self, engine, rank, world, all_reduce=None, fused_exchange=False, always_exchange=False):
+    def __init__(self, engine, rank, world, all_reduce=None, fused_exchange=False, always_exchange=False, replica_check=None,
+                 check_every=4096):
+        """replica_check: callable that raises when the ranks' tables differ (make_gpu_engine leaves one in ctx.replica_check).
+        It is called every `check_every` iterations of run() when the connected exchange is the LIGHT protocol form, whose
+        store ordering rests on measured behaviour rather than on fences (scopa_p2p.h): a rare stale row would otherwise
+        corrupt the summed deltas silently.  The fenced form and the collective need no such check."""
         self.engine, self.rank, self.world = engine, int(rank), int(world)
         self.all_reduce = all_reduce if all_reduce is not None else (lambda: None)
         self.fused_exchange, self.always_exchange = bool(fused_exchange), bool(always_exchange)
+        self.replica_check = replica_check if replica_check is not None else getattr(engine, "replica_check", None)
+        self.check_every = int(check_every)
 
     def iteration(self, batch_total):
         b0, nb = shard_range(batch_total, self.rank, self.world)
@@ -40,19 +47,28 @@ class ShardedMCCFR:
     def run(self, batch_total, n_iters):
         if self.fused_exchange:
             b0, nb = shard_range(batch_total, self.rank, self.world)
-            self.engine.mccfr_iterate_sharded(b0, nb, int(n_iters))
+            guarded = self.replica_check is not None and getattr(self.engine, "exchange_form", None) == "light" and self.check_every > 0
+            left = int(n_iters)
+            while left > 0:
+                k = min(left, self.check_every) if guarded else left
+                self.engine.mccfr_iterate_sharded(b0, nb, k)
+                left -= k
+                if guarded and (left > 0 or k == self.check_every):
+                    self.replica_check()
             return
         for _ in range(int(n_iters)):
             self.iteration(batch_total)
 
 
-def connect_peer_exchange(ctx, rank, world, device, rounds=32, form="auto"):
+def connect_peer_exchange(ctx, rank, world, device, rounds=32, form="fenced"):
     """Set up the library's one-shot peer-memory all-reduce (scopa_p2p_*, include/scopa.h) between the `world` ranks of an
     initialised torch.distributed group (one process per GPU, one node) and PROVE it before use: `rounds` exchanges of
     rank-distinct random payloads must equal, bit for bit, the rank-ordered sum computed from an all-gather through
     torch.distributed (RCCL), on every rank, with no wait timing out.  form: "fenced" = the textbook protocol (system-scope
-    release / acquire fences), "light" = sc0 sc1 accesses ordered by s_waitcnt alone (4.5 us less per iteration), "auto" =
-    light if it passes the validation on this topology, else fenced (validated the same way).  Returns (ok, reason); every
+    release / acquire fences) -- correct by construction and the DEFAULT; "light" = sc0 sc1 accesses ordered by s_waitcnt alone
+    (4.5 us less per iteration; rests on the fabric acknowledging a remote store only once it is visible, which the architecture
+    does not promise: an explicit opt-in, and ShardedMCCFR.run then compares the replicas' tables periodically); "auto" = light
+    if it passes the validation on this topology, else fenced (validated the same way).  Returns (ok, reason); every
     rank returns the same answer (each verdict is itself all-reduced), so the ranks switch paths together; the form in
     use is left in ctx.exchange_form."""
     import numpy as np
@@ -140,11 +156,13 @@ def connect_peer_exchange(ctx, rank, world, device, rounds=32, form="auto"):
     return False, why
 
 
-def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl", exchange_form="auto"):
+def make_gpu_engine(local_rank, perm16, seed, distributed=False, rank=0, exchange="rccl", exchange_form="fenced"):
     """Context on `local_rank` launching on a dedicated torch stream, with a torch-owned delta tensor bound as the
-    all-reduce payload.  Returns (ctx, delta_tensor, stream, all_reduce).  exchange: "rccl" = torch.distributed.all_reduce;
-    "p2p" = the library's one-shot peer-memory all-reduce (raises if it cannot be validated); "auto" = p2p if it validates on
-    every rank, else rccl.  The path in use is recorded in `ctx.exchange`."""
+    all-reduce payload.  Returns (ctx, delta_tensor, stream, all_reduce).  distributed: a torch.distributed process group is
+    up and the exchange step is wanted (its size is read from the group; a group of one rank is allowed, for timing the N > 1
+    code path on one GPU).  exchange: "rccl" = torch.distributed.all_reduce; "p2p" = the library's one-shot peer-memory
+    all-reduce (raises if it cannot be validated); "auto" = p2p if it validates on every rank, else rccl.  The path in use is
+    recorded in `ctx.exchange`, the protocol form in `ctx.exchange_form`; `ctx.replica_check()` raises if the ranks' tables differ."""
     import torch
     import torch.distributed as dist
     from . import _lib
@@ -162,9 +180,22 @@ def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl", 
         with torch.cuda.stream(stream):
             dist.all_reduce(delta, op=dist.ReduceOp.SUM)
 
-    ctx.exchange, ctx.exchange_note, ctx.exchange_form = ("rccl" if world > 1 else "none"), "", None
+    def replica_check():
+        import hashlib
+        import numpy as np
+        R, S, _ = ctx.tables_get()
+        h = np.frombuffer(hashlib.sha256(R.tobytes() + S.tobytes()).digest()[:8], dtype=np.uint8).copy()
+        dev = torch.device("cpu") if dist.get_backend() == "gloo" else torch.device(f"cuda:{local_rank}")
+        mine = torch.from_numpy(h).to(dev)
+        parts = [torch.zeros(8, dtype=torch.uint8, device=dev) for _ in range(dist.get_world_size())]
+        dist.all_gather(parts, mine)
+        if not all(bool((x == mine).all().item()) for x in parts):
+            raise RuntimeError("ShardedMCCFR: the ranks' regret / strategy tables differ -- the delta exchange delivered different sums to different ranks")
+
+    ctx.exchange, ctx.exchange_note, ctx.exchange_form = ("rccl" if distributed else "none"), "", None
     ctx.collective_all_reduce = all_reduce   # the torch.distributed path, kept reachable as the fallback when a connected peer exchange is dropped later
-    if world > 1 and exchange in ("auto", "p2p"):
+    ctx.replica_check = replica_check if distributed else None
+    if distributed and exchange in ("auto", "p2p"):
         ok, why = connect_peer_exchange(ctx, rank, dist.get_world_size(), torch.device(f"cuda:{local_rank}"), form=exchange_form)
         ctx.exchange_note = why
         if ok:
@@ -172,7 +203,7 @@ def make_gpu_engine(local_rank, perm16, seed, world=1, rank=0, exchange="rccl", 
             return ctx, delta, stream, ctx.p2p_allreduce_delta
         if exchange == "p2p":
             raise RuntimeError(f"peer-memory exchange unavailable: {why}")
-    return ctx, delta, stream, (all_reduce if world > 1 else (lambda: None))
+    return ctx, delta, stream, (all_reduce if distributed else (lambda: None))
 
 
 # ---- SDCFR data parallelism (BASELINE configs[4]) ---------------------------------------------------------------------

@@ -11,8 +11,8 @@ from scopa_amd.envs import load_game
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 d = DeepCFR(load_game("mini_scopa"), device="cuda:0", batch=B)
-if os.environ.get("SCOPA_SDCFR_T"):
-    d._engine.ctx.sdcfr_tile_traversals(int(os.environ["SCOPA_SDCFR_T"]))
+if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):
+    d._engine.ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))
 lib = ctypes.CDLL(os.environ["SCOPA_HIP_LIBRARY"])
 names = ["frontier info", "layer 1", "layer 2", "layer 3 + policy", "expand / sample", "skipped plies", "leaves + backward", "take next"]
 for p in (0, 1):

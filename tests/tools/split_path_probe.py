@@ -12,7 +12,7 @@ def worker(rank, world, iters, batch_total, port):
     from scopa_amd import _lib
     from scopa_amd.distributed import ShardedMCCFR, make_gpu_engine
     perm = _lib.deal_py_seed(42)
-    ctx, delta, stream, all_reduce = make_gpu_engine(0, perm, seed=0x5C09A, world=world, rank=rank, exchange="rccl")
+    ctx, delta, stream, all_reduce = make_gpu_engine(0, perm, seed=0x5C09A, distributed=world > 1, rank=rank, exchange="rccl")
     drv = ShardedMCCFR(ctx, rank, world, all_reduce, fused_exchange=False, always_exchange=True)
     ref = None
     if rank == 0:

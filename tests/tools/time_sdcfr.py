@@ -11,8 +11,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 torch.manual_seed(0)
 from scopa_amd.envs import load_game
 solver = DeepCFR(load_game("mini_scopa"), device="cuda:0", batch=B)
-if os.environ.get("SCOPA_SDCFR_T"):
-    solver._engine.ctx.sdcfr_tile_traversals(int(os.environ["SCOPA_SDCFR_T"]))   # traversals per wavefront: 2 or 4 (0 = library's choice)
+if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):
+    solver._engine.ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))   # traversals / wavefronts per task
 for p in (0, 1):
     solver._traverse_batch(p, B)
 torch.cuda.synchronize()
@@ -23,4 +23,4 @@ for _ in range(3):
         solver._traverse_batch(0, B); solver._traverse_batch(1, B)
     torch.cuda.synchronize()
     best = min(best, (time.perf_counter() - t0) / (2 * N))
-print(f"{os.environ.get('SCOPA_HIP_LIBRARY', 'default')} T={os.environ.get('SCOPA_SDCFR_T', 'auto')}: B={B} {best * 1e6:.1f} us per traversal launch ({B * 93.5 / best:.3e} visits/s)")
+print(f"{os.environ.get('SCOPA_HIP_LIBRARY', 'default')} T={os.environ.get('SCOPA_SDCFR_T', 'auto')} W={os.environ.get('SCOPA_SDCFR_W', 'auto')}: B={B} {best * 1e6:.1f} us per traversal launch ({B * 93.5 / best:.3e} visits/s)")
