@@ -122,6 +122,26 @@ def spawn_ranks(n, argv):
     return rc
 
 
+def rank_roster(world, rank, local, per_rank_ms=None):
+    """What lets a reader of the JSON line see N real ranks: every rank's (rank, pid, device index, device uuid / PCI bus id, device
+    name[, its own ms_per_step]), gathered through the process group; world_size is the group's own answer."""
+    import torch
+    import torch.distributed as dist
+    p = torch.cuda.get_device_properties(local)
+    uuid = getattr(p, "uuid", None)
+    me = {"rank": rank, "pid": os.getpid(), "device_index": local, "device_uuid": str(uuid) if uuid is not None else None,
+          "pci_bus_id": "%04x:%02x:%02x" % (getattr(p, "pci_domain_id", 0), getattr(p, "pci_bus_id", 0), getattr(p, "pci_device_id", 0)),
+          "device_name": p.name, "host": socket.gethostname()}
+    if per_rank_ms is not None:
+        me["ms_per_step"] = per_rank_ms
+    if world <= 1 or not dist.is_initialized():
+        return {"world_size": 1, "ranks": [me]}
+    got = [None] * dist.get_world_size()
+    dist.all_gather_object(got, me)
+    return {"world_size": dist.get_world_size(), "backend": dist.get_backend(), "ranks": got,
+            "distinct_devices": len({(g["host"], g["pci_bus_id"], g["device_uuid"]) for g in got})}
+
+
 def cpu_baseline_sdcfr(nets, target_s=10.0):
     """The oracle's SDCFR traversal (og_sdcfr_traverse: one traversal after the other, a batch-1 MLP forward per node, as the
     reference does) with the SAME weights on one host core, bounded sample."""
@@ -212,6 +232,7 @@ def run_sdcfr(args, emit=True):
         step()
     fence()
     elapsed = time.perf_counter() - t0
+    own_ms = 1e3 * elapsed / args.steps                          # this rank's own clock; `elapsed` becomes the maximum over ranks below
     if world > 1:
         tm = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.share_gpu else f"cuda:{local}")
         dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -225,6 +246,7 @@ def run_sdcfr(args, emit=True):
         assert replicas_identical, "SDCFR replicas' advantage nets differ after the run"
     else:
         replicas_identical = None
+    roster = rank_roster(world, rank, local, own_ms)
     visits = (ctx.sdcfr_visits() - v0) * world
     assert visits == (105 + 82) * batch * args.steps * world
     kern_ms = [a.elapsed_time(b) for a, b in d.kernel_events]
@@ -262,7 +284,7 @@ def run_sdcfr(args, emit=True):
                             "note": "kernel time from events recorded on the kernel's stream around each launch; both nets (2 x 54 KB as MFMA operand images), the "
                                     "node table and the per-team frontier live in LDS, activations stay in registers (an accumulator tile is the next layer's B operand), "
                                     "HBM sees the 41 x 264 B memory rows per traversal; SQ counter passes: profiles/r03_pmc_sq_sdcfr_traverse.json"},
-               "decision_visits": visits}
+               "decision_visits": visits, "world": roster}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sdcfr(nets)
             out["gpu_over_cpu_1core_traversal_only"] = out["traversal_only"]["visits_per_s_per_gpu"] / out["cpu_baseline"]["value"]
@@ -357,8 +379,16 @@ def main():
     coll_dev = torch.device("cpu") if args.share_gpu else dev     # where small collectives' tensors live
 
     perm = _lib.deal_py_seed(42)
+    exchange_choice, forced_note = args.exchange, ""
+    if args.share_gpu and world > 3 and args.exchange == "auto":
+        # rehearsal with more than three ranks on ONE device: a rank spinning in the peer exchange's poll loop holds the device while
+        # the peers' traversal launches wait behind it (the exchange assumes co-resident peers, as on one GPU per rank) -- round 2's
+        # 4-rank rehearsal burnt its 5 s wait budgets before falling back.  Go to the collective directly.
+        exchange_choice, forced_note = "rccl", "shared-GPU rehearsal with more than 3 ranks: the collective was chosen outright (the peer exchange needs co-resident peers)"
     ctx, delta, stream, all_reduce = make_gpu_engine(local_rank, perm, seed=0x5C09A, distributed=use_dist, rank=rank,
-                                                      exchange=args.exchange, exchange_form=args.exchange_form)
+                                                      exchange=exchange_choice, exchange_form=args.exchange_form)
+    if forced_note:
+        ctx.exchange_note = forced_note
     batch_total = args.batch * world
     # --force-dist with one rank still takes the exchange step (always_exchange), so the N>1 code path can be timed on one GPU
     drv = ShardedMCCFR(ctx, rank, world, all_reduce, fused_exchange=(use_dist and ctx.exchange == "p2p"), always_exchange=use_dist)
@@ -412,7 +442,7 @@ def main():
 
     if use_dist:
         sharded_check = prove_sharded() and not args.inject_proof_failure
-        if not sharded_check and ctx.exchange == "p2p" and args.exchange == "auto":
+        if not sharded_check and ctx.exchange == "p2p" and exchange_choice == "auto":
             # the peer exchange passed its connect-time validation but not the solver-level proof on this topology: drop it, take the
             # torch.distributed all-reduce (split path) and prove that instead -- a slower valid number beats none
             ctx.exchange, ctx.exchange_note = "rccl", (ctx.exchange_note + "; dropped after the 10-iteration proof failed, fell back to torch.distributed").lstrip("; ")
@@ -441,19 +471,21 @@ def main():
     stride = args.prof_stride if args.prof_stride > 0 else max(1, (args.steps * regions) // 64)
     d0, _ = ctx.counters()
     ctx.prof_enable(stride)
-    times = []
+    times, own_times = [], []
     for _ in range(regions):
         fence()
         t0 = time.perf_counter()
         run(args.steps)
         fence()
-        times.append(all_max(time.perf_counter() - t0))
+        own_times.append(time.perf_counter() - t0)             # this rank's own clock around the region ...
+        times.append(all_max(own_times[-1]))                    # ... and the maximum over ranks, which is what counts
     launches, kernel_ms = ctx.prof_read()
     dev_n1, dev_ms1 = ctx.prof_device()
     phases = ctx.prof_phases()
     ctx.prof_enable(0)
     d1, _ = ctx.counters()
     med = sorted(times)[len(times) // 2]
+    roster = rank_roster(world if use_dist else 1, rank, local_rank, 1e3 * sorted(own_times)[len(own_times) // 2] / args.steps)
 
     if use_dist:
         cnt = torch.tensor([d1 - d0], dtype=torch.float64, device=coll_dev)
@@ -547,6 +579,7 @@ def main():
                        "pre_phase_iterations": n_pre, "pre_phase_s": pre_s},
             "roofline": roofline,
             "decision_visits": visits,
+            "world": roster,
             # the other half of BASELINE's metric ("exploitability vs iters"): where the average strategy stands after this run
             "exploitability": {"iterations": int(ctx.mccfr_iteration()), "traversals_per_iteration": 2 * batch_total,
                                "value": float(ctx.exploitability()["exploitability"]),

@@ -97,6 +97,54 @@ def test_two_ranks_reproduce_one_rank(tmp_path):
     np.testing.assert_allclose(single.S, ref.S, rtol=1e-12, atol=1e-12)
 
 
+def test_eight_ranks_reproduce_one_rank(tmp_path):
+    """BASELINE configs[2]'s rank count: EIGHT gloo processes (one per host core) through the same driver -- shard_range x 8,
+    one all-reduce of the [738][5] delta per iteration, every rank applying the sum -- reproduce the one-rank tables; the eight
+    replicas end bit-identical.  (Batch 8 x 37 + 3: uneven shards; the GPU box admits at most five ranks on its one device,
+    tests/test_gpu_bench.py, so the eight-rank control flow is exercised here.)"""
+    import torch.multiprocessing as mp
+    batch, iters, world = 8 * 37 + 3, 3, 8
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    out = str(tmp_path / "rank{rank}.npz")
+    mp.spawn(_worker, args=(world, port, batch, iters, out), nprocs=world, join=True)
+    single = OracleEngine(seed=31337)
+    from scopa_amd.distributed import ShardedMCCFR, shard_range
+    assert [shard_range(batch, r, world)[1] for r in range(world)] == [38, 38, 38, 37, 37, 37, 37, 37]
+    ShardedMCCFR(single, 0, 1).run(batch, iters)
+    reps = [np.load(out.format(rank=r)) for r in range(world)]
+    for r in range(1, world):
+        assert np.array_equal(reps[0]["R"], reps[r]["R"]) and np.array_equal(reps[0]["S"], reps[r]["S"]), r
+    np.testing.assert_allclose(reps[0]["R"], single.R, rtol=1e-12, atol=1e-12)
+    np.testing.assert_allclose(reps[0]["S"], single.S, rtol=1e-12, atol=1e-12)
+
+
+def test_light_form_is_guarded_by_periodic_replica_checks():
+    """ShardedMCCFR.run under the LIGHT protocol form of the peer exchange calls the replica check every check_every iterations
+    (and never under the fenced form or the collective): a divergence raises instead of corrupting the tables silently."""
+    from scopa_amd.distributed import ShardedMCCFR
+
+    class Eng:
+        def __init__(self, form):
+            self.exchange_form, self.calls, self.checks = form, [], 0
+        def mccfr_iterate_sharded(self, b0, nb, n):
+            self.calls.append(n)
+        def replica_check(self):
+            self.checks += 1
+
+    e = Eng("light")
+    ShardedMCCFR(e, 0, 2, fused_exchange=True, check_every=100).run(64, 250)
+    assert e.calls == [100, 100, 50] and e.checks == 2
+    e = Eng("fenced")
+    ShardedMCCFR(e, 0, 2, fused_exchange=True, check_every=100).run(64, 250)
+    assert e.calls == [250] and e.checks == 0
+    bad = Eng("light")
+    bad.replica_check = lambda: (_ for _ in ()).throw(RuntimeError("tables differ"))
+    with pytest.raises(RuntimeError):
+        ShardedMCCFR(bad, 0, 2, fused_exchange=True, check_every=10).run(64, 25)
+
+
 # ---- SDCFR data parallelism: gradient averaging keeps replicas identical (BASELINE configs[4]) -----------------------
 def _grad_worker(rank, world, port, out):
     import torch

@@ -24,7 +24,16 @@ def _bench(*args, timeout=300):
 
 
 def test_bench_line_contract_n1(ctx):
-    d = _bench("--gpus", "1", "--steps", "10", "--warmup", "2", "--regions", "5", "--pre-phase-s", "0.05", "--no-cpu-baseline")
+    d = _bench("--gpus", "1", "--steps", "10", "--warmup", "2", "--regions", "5", "--pre-phase-s", "0.05", "--no-cpu-baseline", "--sdcfr-steps", "20")
+    # the default invocation carries BASELINE configs[3] as a sub-record: SDCFR at 4096 traversals per player, >= 20 timed iterations
+    sd = d["sdcfr"]
+    assert "error" not in sd, sd
+    assert sd["steps"] >= 20 and sd["config"]["batch_per_gpu"] == 4096 and sd["dtype"] == "f32"
+    assert sd["decision_visits"] == (105 + 82) * 4096 * sd["steps"] and sd["ms_per_step"] > 0
+    assert sd["roofline"]["kernel"] == "k_sdcfr_traverse" and 0.0 < sd["roofline"]["frac"] <= 1.0 and sd["traversal_only"]["launches_timed"] == 2 * sd["steps"]
+    assert set(sd["roofline"]["bounds"]) == {"mfma-f32", "hbm-algorithmic"}
+    w = d["world"]
+    assert w["world_size"] == 1 and len(w["ranks"]) == 1 and w["ranks"][0]["rank"] == 0 and w["ranks"][0]["ms_per_step"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
               "config", "roofline"):
         assert k in d, k
@@ -46,6 +55,22 @@ def test_bench_spawns_its_own_ranks(ctx):
     assert d["n_gpus"] == 2 and c["global_batch"] == 1024 and c["batch_per_gpu"] == 512
     assert c["exchange"] in ("p2p", "rccl") and c["replicas_bit_identical"] is True and c["sharded_10_iterations_match_one_gpu"] is True
     assert d["decision_visits"] == 463 * 1024 * 5 * d["timing"]["regions"]
+    w = d["world"]                                   # the roster: what the process group itself says about its ranks
+    assert w["world_size"] == 2 and [r["rank"] for r in w["ranks"]] == [0, 1] and len({r["pid"] for r in w["ranks"]}) == 2
+    assert all(r["ms_per_step"] > 0 and r["device_index"] == 0 for r in w["ranks"]) and w["distinct_devices"] == 1   # --share-gpu: one device, and the line says so
+
+
+def test_bench_five_ranks_rehearsal_goes_through_the_collective(ctx):
+    """The 8-GPU control flow at the rank count the one-GPU box admits (its process guard allows six GPU processes: five ranks + this
+    test): `--gpus 5 --share-gpu` started plainly.  With more than three ranks on one device the peer exchange is not even tried
+    (its poll loops assume co-resident peers): the run goes through the torch.distributed all-reduce, proves the sharded
+    pipeline against the one-GPU tables, and ends with identical replicas and the exact visit count."""
+    d = _bench("--gpus", "5", "--share-gpu", "--steps", "4", "--warmup", "1", "--regions", "3", "--pre-phase-s", "0.05", "--batch", "256", "--no-cpu-baseline", timeout=600)
+    c = d["config"]
+    assert d["n_gpus"] == 5 and c["global_batch"] == 5 * 256 and c["exchange"] == "rccl" and "chosen outright" in c["exchange_note"]
+    assert c["replicas_bit_identical"] is True and c["sharded_10_iterations_match_one_gpu"] is True
+    assert d["decision_visits"] == 463 * 5 * 256 * 4 * d["timing"]["regions"]
+    assert d["world"]["world_size"] == 5 and sorted(r["rank"] for r in d["world"]["ranks"]) == list(range(5))
 
 
 @pytest.mark.parametrize("extra", [["--exchange", "rccl"], ["--inject-proof-failure"]])

@@ -259,6 +259,46 @@ def test_mccfr_config2_rank_shard_vs_oracle(ctx, sl, oracle, b0, nb):
     np.testing.assert_allclose(sub[:, :4], sR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(sR).max()))
 
 
+def test_mccfr_config2_whole_iteration_on_one_gpu(ctx, sl, oracle):
+    """BASELINE configs[2] in one piece: the 262 144-traversal iteration as the eight ranks of the 8-GPU run would split it --
+    eight launches mccfr_traverse(it, r * 32768, 32768), r = 0..7 (shard_range's partition) -- into one delta, ONE mccfr_apply,
+    then a second iteration on the tables that left; against the oracle's og_mccfr_batched over all 262 144 pairs per iteration
+    (MCCFRTrainer.iteration, mc_cfr.py:88-92, with tables frozen per iteration): visit counts exact, strategy tables to 1e-12,
+    regret tables to 1e-11 relative.  What the 8-GPU run adds to this is only where the eight partial deltas are summed."""
+    from scopa_amd.distributed import shard_range
+    total, world = 262144, 8
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    R, S, L = t.tables()
+    t.cfr_exact(R, S, L, 2)                       # a table with structure, not all zeros
+    ctx.tables_set(regret=R, strategy=S)
+    seed = 0x5C09A
+    ctx.mccfr_seed(seed)
+    Ro, So = R.copy(), S.copy()
+    d0, t0 = ctx.counters()
+    for it in range(2):
+        assert ctx.mccfr_iteration() == it
+        for r in range(world):
+            b0, nb = shard_range(total, r, world)
+            assert (b0, nb) == (r * 32768, 32768)
+            ctx.mccfr_traverse(it, b0, nb)
+        delta = ctx.mccfr_delta_get()
+        assert delta[:, 4].sum() == 172 * total and delta[0, 4] == total   # traverser visits: 86 + 86 per pair; the root once per pair
+        ctx.mccfr_apply()
+        visits = t.mccfr_batched(Ro, So, seed, it, 1, total)
+        assert visits == 463 * total
+        Rg, Sg, _ = ctx.tables_get()
+        # 262 144 pairs' increments added in another order (float64 atomics): the weights reach / sampling probability of the
+        # reference's update span many orders of magnitude (|regret| up to 1e12 here), so sums cancel: 1e-11 relative
+        np.testing.assert_allclose(Rg, Ro, rtol=1e-11, atol=1e-12 * max(1.0, np.abs(Ro).max()))
+        np.testing.assert_allclose(Sg, So, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(So).max()))
+        Ro, So = Rg.copy(), Sg.copy()             # the next iteration starts from the SAME tables on both sides (its integer sampling
+                                                  # thresholds are a function of the rounded regrets)
+    d1, t1 = ctx.counters()
+    assert (d1 - d0, t1 - t0) == (2 * 463 * total, 2 * 240 * total)
+    assert ctx.mccfr_iteration() == 2
+
+
 def test_two_contexts_are_independent(sl, oracle):
     """include/scopa.h: distinct contexts are independent.  Every entry point whose kernel needs more than the default 64 KB of
     dynamic LDS (the cap is raised per context = per device, not once per process) runs on a first AND on a second context."""
