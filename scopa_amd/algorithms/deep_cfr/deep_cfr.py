@@ -502,6 +502,9 @@ class DeepCFR:
         rnd = float(raw["scopas"][ar, 1 - seat_h].mean()) if n else 0.0
         self.training_history["eval_rewards"].append(avg_reward)
         self.training_history["eval_scopas"].append([trained, rnd])
+        from ..evaluation import match_halves
+        self.last_eval_by_seat = match_halves(rewards[ar, seat_h], raw["scopas"][ar, seat_h].astype(np.float64),
+                                              raw["scopas"][ar, 1 - seat_h].astype(np.float64), seat_h) if n else []
         return avg_reward, [trained, rnd]
 
     # ---- training loop (deep_cfr.py:431-495) -------------------------------------------------------------------------

@@ -87,5 +87,19 @@ def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16
     o_sc = raw["scopas"][ar, 1 - seat_h].astype(np.float64)
     stats = {"trained_avg": float(t_sc.mean()), "opponent_avg": float(o_sc.mean()),
              "difference": float(t_sc.mean() - o_sc.mean()), "data_collected": n > 0,
-             "reward_std_error": float(mine.std() / np.sqrt(max(n, 1)))}
+             "reward_std_error": float(mine.std() / np.sqrt(max(n, 1))),
+             "by_seat": match_halves(mine, t_sc, o_sc, seat_h)}
     return float(mine.mean()), stats
+
+
+def match_halves(reward, own_scopas, opp_scopas, seat):
+    """The two halves of a seat-swapped match apart (the trained agent in seat 0 / in seat 1): episodes, mean reward and its standard
+    error, mean scopas of either side -- what an exact tree enumeration of "policy vs uniform from that seat" can be held against."""
+    out = []
+    for s in (0, 1):
+        k = seat == s
+        m = int(k.sum())
+        out.append({"episodes": m, "reward": float(reward[k].mean()) if m else 0.0,
+                    "reward_std_error": float(reward[k].std() / np.sqrt(m)) if m else 0.0,
+                    "trained_scopas": float(own_scopas[k].mean()) if m else 0.0, "opponent_scopas": float(opp_scopas[k].mean()) if m else 0.0})
+    return out

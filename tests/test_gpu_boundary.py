@@ -262,3 +262,107 @@ def test_device_clock_profile_of_sampled_traversal_launches(ctx, sl):
     ctx.prof_enable(0)
     per_launch_us = 1e3 * ms1 / 7
     assert 1.0 < per_launch_us < 500.0      # a 100 MHz clock span of a kernel that takes ~10 us
+
+
+# ---- exact expectations of "policy vs uniform random" by tree enumeration (test-side, over the oracle's flat tree) -------------------
+def _exact_match(tree, policy_of_node, seat):
+    """The trained agent sits in `seat` and plays policy_of_node(node) -> probabilities of the node's legal actions (hand order); the
+    other seat plays uniformly.  Enumerates the oracle's tree: -> (E reward, Var reward, E scopas trained, E scopas opponent)."""
+    st = tree.states()
+    reach = np.zeros(tree.n_nodes)
+    reach[0] = 1.0
+    e_r = e_r2 = e_t = e_o = 0.0
+    for n in range(tree.n_nodes):                      # DFS order: a parent comes before its children
+        if reach[n] == 0.0:
+            continue
+        if tree.term[n]:
+            r = tree.r2[n, seat] / 2.0
+            e_r += reach[n] * r
+            e_r2 += reach[n] * r * r
+            e_t += reach[n] * st["scopas"][n, seat]
+            e_o += reach[n] * st["scopas"][n, 1 - seat]
+            continue
+        k = int(tree.nlegal[n])
+        p = policy_of_node(n) if tree.player[n] == seat else np.full(k, 1.0 / k)
+        for a in range(k):
+            reach[tree.child[n, a]] = reach[n] * p[a]
+    return e_r, e_r2 - e_r * e_r, e_t, e_o
+
+
+def _check_halves(by_seat, exact, what):
+    for seat in (0, 1):
+        got, (er, var, et, eo) = by_seat[seat], exact[seat]
+        se = np.sqrt(var / got["episodes"])
+        assert abs(got["reward"] - er) < 4 * se, (what, seat, got["reward"], er, se)
+        assert abs(got["trained_scopas"] - et) < 4 * np.sqrt(max(et, 0.05) / got["episodes"]) + 1e-3, (what, seat, got["trained_scopas"], et)
+        assert abs(got["opponent_scopas"] - eo) < 4 * np.sqrt(max(eo, 0.05) / got["episodes"]) + 1e-3, (what, seat, got["opponent_scopas"], eo)
+        assert abs(got["reward_std_error"] - se) < 0.05 * se
+
+
+def test_device_evaluator_against_exact_tree_enumeration(game, oracle):
+    """evaluate_agent on the device (vanilla_cfr.py:157-216: trained vs uniform random, seats swapped at half time) against the EXACT
+    expectation of every half, obtained by enumerating the tree: expected reward (within 4 standard errors of 10^6 episodes per seat,
+    about 0.005) and expected scopas of either side, for three policies -- uniform, the average policy of 30 vanilla-CFR iterations,
+    the average policy of batched MCCFR.  A policy row applied to the wrong infoset, seat or action slot moves these by tenths."""
+    from scopa_amd.algorithms import CFRTrainer, MCCFRTrainer, evaluate_agent_device
+    t = oracle.Tree(seed=42)
+    tr = CFRTrainer(game)
+    uni = np.zeros((t.n_infosets, 4))
+    for i, n in enumerate(t.infoset_nlegal):
+        uni[i, :n] = 1.0 / n
+    tr.train(steps=30)
+    cfr30 = tr._engine.ctx.exploitability(return_policy=True)["policy"]
+    mc = MCCFRTrainer(game, batch=256, seed=11)
+    mc.train(iterations=40)
+    mcavg = mc._engine.ctx.exploitability(return_policy=True)["policy"]
+    assert np.abs(cfr30 - uni).max() > 0.3 and np.abs(mcavg - cfr30).max() > 0.05         # three different policies
+    for what, P in (("uniform", uni), ("cfr30", cfr30), ("mccfr", mcavg)):
+        exact = [_exact_match(t, lambda n, P=P: P[t.infoset[n], :t.nlegal[n]], seat) for seat in (0, 1)]
+        avg, st = evaluate_agent_device(tr, num_episodes=2_000_000, policy=P, stream_id=21)
+        _check_halves(st["by_seat"], exact, what)
+        assert abs(avg - 0.5 * (exact[0][0] + exact[1][0])) < 4 * np.sqrt(0.25 * (exact[0][1] + exact[1][1]) / 1e6)
+    # the oracle's own policy value is the same enumeration: trained in seat 0 with uniform rows for player 1's infosets
+    mixed = np.where((t.infoset_player == 0)[:, None], cfr30, uni)
+    assert abs(t.policy_value(mixed) - _exact_match(t, lambda n: cfr30[t.infoset[n], :t.nlegal[n]], 0)[0]) < 1e-12
+
+
+def test_deep_cfr_evaluate_vs_random_against_exact_tree_enumeration(game, oracle, golden):
+    """DeepCFR.evaluate_vs_random (deep_cfr.py:367-429) with scripted nets -- the reference run's saved advantage nets as the only
+    snapshot of either player -- against the exact expectation of each half: the policy of a node is
+    positive_regret_policy(net(features), mask) (nets.py:93-101), uniform over the legal actions when nothing is positive, computed
+    here on the CPU from the oracle's states; 10^6 episodes per seat."""
+    import torch
+    from scopa_amd.algorithms.deep_cfr import DeepCFR, FlexibleNet
+    from scopa_amd.algorithms.deep_cfr.nets import positive_regret_policy
+    g = golden.npz("sdcfr.npz")
+    d = DeepCFR(game, num_players=2, device="cuda:0")
+    cpu_nets = []
+    for p in range(2):
+        sd = {str(k): torch.from_numpy(g[f"net{p}__{k}"]) for k in g[f"net{p}_names"]}
+        snap = FlexibleNet(mode="mlp", input_shape=(34,), output_dim=16, mlp_hidden=[128, 64]).to("cuda:0")
+        snap.load_state_dict(sd)
+        d.strategy_buffers[p].add_strategy(snap, 1)
+        c = FlexibleNet(mode="mlp", input_shape=(34,), output_dim=16, mlp_hidden=[128, 64])
+        c.load_state_dict(sd)
+        cpu_nets.append(c)
+    t = oracle.Tree(seed=42)
+    st = t.states()
+    pol = {}
+    with torch.no_grad():
+        for n in range(t.n_nodes):
+            if t.term[n]:
+                continue
+            p, k = int(t.player[n]), int(t.nlegal[n])
+            f, m = np.zeros(34, np.float32), np.zeros(16, np.float32)
+            hand = [int(c) for c in st["hands"][n, p, :st["nh"][n, p]]]
+            f[hand] = 1.0
+            m[hand] = 1.0
+            f[[16 + int(c) for c in st["table"][n, :st["nt"][n]]]] = 1.0
+            f[32] = 1.0
+            pr = positive_regret_policy(cpu_nets[p](torch.from_numpy(f)[None]), torch.from_numpy(m)[None])[0].numpy().astype(np.float64)
+            w = np.maximum(pr[[int(a) for a in t.legal[n, :k]]], 0.0)
+            pol[n] = w / w.sum() if w.sum() > 0 else np.full(k, 1.0 / k)       # k_eval_step: no positive mass -> uniform (:394-395)
+    exact = [_exact_match(t, lambda n: pol[n], seat) for seat in (0, 1)]
+    assert abs(exact[0][0] + 0.9201388888888888) + abs(exact[1][0] - 0.9201388888888888) > 0.05   # not the uniform policy's values (SURVEY 4 KAT)
+    d.evaluate_vs_random(2_000_000)
+    _check_halves(d.last_eval_by_seat, exact, "sdcfr nets")
