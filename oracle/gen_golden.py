@@ -21,6 +21,8 @@ Fixtures (consumers: tests/, oracle pinning):
   mccfr_frozen.npz    MCCFRTrainer._sample driven with frozen strategies and path-keyed draws: batched-MCCFR deltas (mc_cfr.py:37-86)
   evaluate.json       evaluate_agent results under np.random.seed(k)              (vanilla_cfr.py:157-216, mc_cfr.py:146-206)
   sdcfr.npz           DeepCFR features/masks/traversal rows with saved weights    (deep_cfr.py:213-365)
+  exploitability.json an independent best response over the reference's own state / policy objects for three reference-made policies
+                      (cross-check of og_exploitability / k_exploitability; not a pin: the reference publishes no value)
 """
 import json
 import os
@@ -705,7 +707,122 @@ def gen_tracker(ns):
     print("tracker: runs", d["num_runs"], "eval points", len(d["runs"][0]["eval_iterations"]))
 
 
-ALL = dict(vanilla_experiment=gen_vanilla_experiment, experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+def gen_exploitability(ns):
+    """An INDEPENDENT exploitability, written here against the reference's own objects only -- states through clone / apply_action /
+    information_state_string / returns (openspiel_mini_scopa.py:17-115), policies through the reference's own policy classes'
+    action_probabilities (vanilla_cfr.py:122-155, mc_cfr.py:104-144) -- following the procedural definition OpenSpiel's
+    exploitability(game, policy) uses (the call the reference makes at vanilla_cfr.py:112-118; OpenSpiel itself is not installed):
+    best response of player i = per information-state string argmax_a sum_{h in I} cf_reach(h) * value(h.a) (first maximum in
+    legal-action order), values of the other player's nodes = sum_a pi(a|h) value(h.a); exploitability = (BR_0 + BR_1) / 2 in this
+    zero-sum game (NashConv / 2).  It shares no code with oracle/scopa_oracle.c or the kernels; agreement is a cross-check, not a pin:
+    the reference publishes no exploitability value (parity unpinned)."""
+    import pyspiel
+    game = pyspiel.load_game("mini_scopa")
+
+    def best_response_value(policy, br):
+        infosets = {}                                        # information-state string -> [(state, counterfactual reach)] in DFS order
+
+        def collect(state, reach):
+            if state.is_terminal():
+                return
+            p = state.current_player()
+            if p == br:
+                infosets.setdefault(state.information_state_string(p), []).append((state, reach))
+                for a in state.legal_actions():
+                    c = state.clone(); c.apply_action(a)
+                    collect(c, reach)
+            else:
+                for a, pr in policy.action_probabilities(state).items():
+                    c = state.clone(); c.apply_action(a)
+                    collect(c, reach * pr)
+
+        collect(game.new_initial_state(), 1.0)
+        choice, memo = {}, {}
+
+        def value(state):
+            key = state.history_str()
+            if key in memo:
+                return memo[key]
+            if state.is_terminal():
+                v = float(state.returns()[br])
+            else:
+                p = state.current_player()
+                if p == br:
+                    c = state.clone(); c.apply_action(best_action(state.information_state_string(p)))
+                    v = value(c)
+                else:
+                    v = 0.0
+                    for a, pr in policy.action_probabilities(state).items():
+                        c = state.clone(); c.apply_action(a)
+                        v += pr * value(c)
+            memo[key] = v
+            return v
+
+        def best_action(istr):
+            if istr not in choice:
+                members = infosets[istr]
+                best, best_q = None, None
+                for a in members[0][0].legal_actions():
+                    q = 0.0
+                    for st, reach in members:
+                        c = st.clone(); c.apply_action(a)
+                        q += reach * value(c)
+                    if best is None or q > best_q:
+                        best, best_q = a, q
+                choice[istr] = best
+            return choice[istr]
+
+        return value(game.new_initial_state())
+
+    def on_policy_value(policy, state=None):
+        state = game.new_initial_state() if state is None else state
+        if state.is_terminal():
+            return float(state.returns()[0])
+        v = 0.0
+        for a, pr in policy.action_probabilities(state).items():
+            c = state.clone(); c.apply_action(a)
+            v += pr * on_policy_value(policy, c)
+        return v
+
+    def table(policy):
+        """{information-state string: probabilities in legal-action (hand) order} over every decision node of the tree"""
+        out = {}
+
+        def walk(state):
+            if state.is_terminal():
+                return
+            p = state.current_player()
+            pr = policy.action_probabilities(state)
+            out.setdefault(state.information_state_string(p), [float(pr[a]) for a in state.legal_actions()])
+            for a in state.legal_actions():
+                c = state.clone(); c.apply_action(a)
+                walk(c)
+        walk(game.new_initial_state())
+        return out
+
+    cases = {}
+    cases["uniform"] = ns.vanilla.RandomPolicy(game)
+    tr = ns.vanilla.CFRTrainer(game)
+    for _ in range(50):
+        for i in range(game.num_players()):
+            tr._cfr_recursive(game.new_initial_state(), i, 1.0, 1.0)
+    cases["cfr50"] = tr.get_openspiel_policy()
+    np.random.seed(0)
+    mc = ns.mc.MCCFRTrainer(game)
+    for _ in range(200):
+        mc.iteration()
+    cases["mccfr200"] = mc.tabular_policy()
+    out = {}
+    for name, pol in cases.items():
+        b0, b1 = best_response_value(pol, 0), best_response_value(pol, 1)
+        v0 = on_policy_value(pol)
+        out[name] = {"policy": table(pol), "br": [b0, b1], "value_p0": v0, "exploitability": 0.5 * (b0 + b1)}
+        print("exploitability", name, out[name]["exploitability"], "br", b0, b1, "value", v0, "infosets", len(out[name]["policy"]))
+    with open(os.path.join(OUT, "exploitability.json"), "w") as f:
+        json.dump(out, f, separators=(",", ":"))
+
+
+ALL = dict(exploitability=gen_exploitability, vanilla_experiment=gen_vanilla_experiment, experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

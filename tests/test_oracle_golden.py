@@ -131,6 +131,31 @@ def test_uniform_value_and_exploitability_invariants(oracle, golden):
     assert 0 <= e30 < e
 
 
+def _fixture_policy(entry, strings):
+    """tests/golden/exploitability.json: {information-state string: probabilities in hand order} -> [n_infosets][4] in the tree's infoset ids"""
+    assert set(entry["policy"]) == set(strings)
+    P = np.zeros((len(strings), 4))
+    for i, s in enumerate(strings):
+        P[i, :len(entry["policy"][s])] = entry["policy"][s]
+    return P
+
+
+@pytest.mark.parametrize("name", ["uniform", "cfr50", "mccfr200"])
+def test_exploitability_agrees_with_the_independent_best_response(oracle, golden, name):
+    """Cross-check (not a pin: the reference publishes no exploitability): oracle/gen_golden.py:gen_exploitability computes best
+    responses over the REFERENCE's own state and policy objects (clone / apply_action / information_state_string / returns,
+    policy.action_probabilities), following the procedural definition OpenSpiel's exploitability uses (vanilla_cfr.py:112-118), for
+    the uniform policy, the reference CFRTrainer's average policy after 50 iterations and the reference MCCFRTrainer's after 200.
+    The oracle's og_exploitability on the same policy tables gives the same best-response values, policy value and exploitability."""
+    e = golden.json("exploitability.json")[name]
+    t = oracle.Tree(seed=42)
+    P = _fixture_policy(e, t.infoset_strings)
+    expl, br = t.exploitability(P)
+    assert abs(br[0] - e["br"][0]) < 1e-12 and abs(br[1] - e["br"][1]) < 1e-12
+    assert abs(expl - e["exploitability"]) < 1e-12 and abs(t.policy_value(P) - e["value_p0"]) < 1e-12
+    assert expl >= 0 and abs(e["exploitability"] - 0.5 * (e["br"][0] + e["br"][1])) < 1e-15
+
+
 def test_batched_mccfr_shape_and_split_invariance(oracle):
     t = oracle.Tree(seed=42)
     R = np.zeros((t.n_infosets, 4))
