@@ -330,6 +330,7 @@ def main():
     ap.add_argument("--exchange-form", choices=["auto", "light", "fenced"], default="auto",
                     help="peer-memory exchange protocol form: light (sc0 sc1 accesses + s_waitcnt) only if it validates on this topology, else fenced")
     ap.add_argument("--inject-proof-failure", action="store_true", help="testing: treat the first sharded proof as failed, to exercise the fallback from the peer exchange to torch.distributed")
+    ap.add_argument("--graph", action="store_true", help="N = 1 mccfr: replay the iteration loop as captured HIP graphs of up to 64 iterations (scopa_mccfr_graph_mode; A/B against the eager loop)")
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: all ranks use device 0, the process group is gloo (RCCL refuses two ranks on one device)")
@@ -389,6 +390,8 @@ def main():
                                                       exchange=exchange_choice, exchange_form=args.exchange_form)
     if forced_note:
         ctx.exchange_note = forced_note
+    if args.graph:
+        ctx.mccfr_graph_mode(True)
     batch_total = args.batch * world
     # --force-dist with one rank still takes the exchange step (always_exchange), so the N>1 code path can be timed on one GPU
     drv = ShardedMCCFR(ctx, rank, world, all_reduce, fused_exchange=(use_dist and ctx.exchange == "p2p"), always_exchange=use_dist)
@@ -569,6 +572,7 @@ def main():
                        "parallelism": f"dp{world}" + ((" + 1 all-reduce of 29520 B per iteration (" + {"p2p": "one-shot peer-memory exchange over xGMI, rank-ordered sum", "rccl": "RCCL via torch.distributed"}.get(ctx.exchange, ctx.exchange) + ")") if use_dist else ""),
                        "exchange": ctx.exchange if use_dist else None, "exchange_form": ctx.exchange_form if use_dist else None,
                        "exchange_note": ctx.exchange_note if use_dist else None,
+                       "iteration_loop": "captured HIP graphs of <= 64 iterations" if args.graph else "eager launches (in-library loop)",
                        "replicas_bit_identical": replicas_identical, "sharded_10_iterations_match_one_gpu": sharded_check,
                        "shared_gpu_rehearsal": bool(args.share_gpu),
                        "rng": "Philox4x32-10, key = seed, counter = (block of the node's (level, branch index), global traversal id, iteration, traverser); 31-bit draws"},

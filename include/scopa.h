@@ -162,6 +162,14 @@ int32_t scopa_mccfr_delta_set(scopa_ctx *ctx, const double *h_delta);
 /* ... then regret += delta[:, :4]; strategy += count * sigma; delta <- 0; iteration counter += 1 */
 int32_t scopa_mccfr_apply(scopa_ctx *ctx);
 int32_t scopa_mccfr_iteration_counter(scopa_ctx *ctx, uint32_t *iteration);
+/* Graph mode of scopa_mccfr_iterate: on = chunks of up to 64 iterations are replayed as ONE captured HIP graph of (traverse, apply)
+ * launches each (captured once per (batch, chunk length) and deal), the iteration number read from a device word that the apply
+ * launch advances -- the same iteration ids, hence the same draws and results, as the eager loop.  Off by default (measured:
+ * DESIGN.md section 4). */
+int32_t scopa_mccfr_graph_mode(scopa_ctx *ctx, int32_t on);
+/* Test hook: treat the device as offering only `bytes` of LDS per workgroup (0 = its real limit again), so that the launch
+ * geometries only deals with very many infosets reach -- narrow traversal workgroups -- run on any deal.  Results do not change. */
+int32_t scopa_debug_lds_limit(scopa_ctx *ctx, int32_t bytes);
 
 /* ---- SDCFR: level-synchronous external-sampling traversal (DeepCFR._external_sampling_cfr, deep_cfr.py:284-365) ---------
  * B traversals of one traverser advance ply by ply; the advantage MLP runs in PyTorch between the two calls of a ply.

@@ -25,7 +25,7 @@ SYMBOLS = [
     "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
     "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_mode", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
-    "scopa_mccfr_iteration_counter", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
+    "scopa_mccfr_iteration_counter", "scopa_mccfr_graph_mode", "scopa_debug_lds_limit", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
@@ -120,6 +120,8 @@ def lib():
         "scopa_mccfr_delta_set": (i32, [vp, vp]),
         "scopa_mccfr_apply": (i32, [vp]),
         "scopa_mccfr_iteration_counter": (i32, [vp, C.POINTER(u32)]),
+        "scopa_mccfr_graph_mode": (i32, [vp, i32]),
+        "scopa_debug_lds_limit": (i32, [vp, i32]),
         "scopa_exploitability": (i32, [vp, vp, vp, vp]),
         "scopa_sdcfr_frontier_width": (i32, [i32, i32]),
         "scopa_sdcfr_features": (i32, [vp, i32, i64, vp, vp, vp]),
@@ -361,6 +363,13 @@ class Context:
 
     def mccfr_apply(self):
         self._ck(self._L.scopa_mccfr_apply(self._h), "scopa_mccfr_apply")
+
+    def mccfr_graph_mode(self, on):
+        """replay scopa_mccfr_iterate's (traverse, apply) launches as captured HIP graphs of up to 64 iterations (same results)"""
+        self._ck(self._L.scopa_mccfr_graph_mode(self._h, 1 if on else 0), "scopa_mccfr_graph_mode")
+
+    def debug_lds_limit(self, nbytes):
+        self._ck(self._L.scopa_debug_lds_limit(self._h, int(nbytes)), "scopa_debug_lds_limit")
 
     def mccfr_iteration(self):
         v = C.c_uint32()

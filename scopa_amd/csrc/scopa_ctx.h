@@ -80,6 +80,12 @@ struct scopa_ctx {
 
     scopa_p2p *p2p = nullptr;  // peer-memory exchange of the N > 1 path
 
+    // graph mode of scopa_mccfr_iterate (scopa_mccfr.hip): captured (traverse, apply) x k chains by (batch, k); the iteration number
+    // the captured launches use lives in d_meta[2]
+    struct GraphEntry { uint32_t batch, k; void *exec; };
+    std::vector<GraphEntry> mccfr_graphs;
+    bool mccfr_graph_mode = false;
+
     int lds_limit = 160 * 1024;
     int n_cus = 256;
     uint32_t lds_attr_done = 0;  // kernels whose dynamic-LDS cap was raised on THIS context's device (scopa::ensure_lds_attr)
@@ -147,5 +153,6 @@ inline int32_t ensure_lds_attr(scopa_ctx *ctx, uint32_t kernel_bit, const void *
 // (start, stop) events to attach to a sampled launch of the dominant kernel when profiling is on
 bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop);
 void p2p_release(scopa_ctx *ctx);
+void mccfr_graphs_clear(scopa_ctx *ctx);   // scopa_mccfr.hip: on a new deal, a new seed, context destruction
 
 }  // namespace scopa

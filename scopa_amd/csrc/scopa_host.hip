@@ -127,12 +127,26 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     scopa::p2p_release(ctx);
+    scopa::mccfr_graphs_clear(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
                     ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_visit, ctx->d_sigcdf, ctx->d_groups, ctx->d_clock, ctx->d_sched, ctx->d_lane_tab, ctx->d_sdnode};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
+    return SCOPA_OK;
+}
+
+int32_t scopa_debug_lds_limit(scopa_ctx *ctx, int32_t bytes) {
+    // test hook: pretend the device offers less LDS per workgroup, so that launch geometries that only very large deals reach
+    // (narrow workgroups of the traversal kernel) can be exercised on the seed-42 deal; 0 restores the device's own limit
+    if (!ctx || bytes < 0) return SCOPA_EINVAL;
+    hipDeviceProp_t prop;
+    SC_HIP(ctx, hipGetDeviceProperties(&prop, ctx->device));
+    SC_REQUIRE(ctx, bytes == 0 || (bytes >= 64 * 1024 && (size_t)bytes <= prop.sharedMemPerBlock), SCOPA_EINVAL, "scopa_debug_lds_limit: 0 or 64 KB .. the device's limit");
+    ctx->lds_limit = bytes ? bytes : (int)prop.sharedMemPerBlock;
+    ctx->lds_attr_done = 0;                 // the kernels' dynamic-LDS caps are re-derived from the new limit
+    scopa::mccfr_graphs_clear(ctx);         // captured launches carry the old geometry
     return SCOPA_OK;
 }
 

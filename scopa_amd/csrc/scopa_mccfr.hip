@@ -537,9 +537,11 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_groups,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
                  unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock,
-                 const uint4 *__restrict__ g_lane_tab) {
+                 const uint4 *__restrict__ g_lane_tab, const uint32_t *__restrict__ g_iter) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
+    if (g_iter) iteration = *g_iter;   // graph-captured iteration loops (scopa_mccfr_graph_mode): the iteration number lives in a device word that
+                                       // the apply kernel advances, so that one captured graph serves every replay; draws stay keyed by it
     __shared__ double s_one[1];
     __shared__ uint32_t s_next[1];   // next pair of this workgroup not taken yet
     __shared__ uint32_t s_slice[1];  // wavefronts that have left the pair loop
@@ -598,6 +600,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         if (tid == 0) s_inf[kDecision - 1] = last_inf;
         if (tid < kTerminal / 4) reinterpret_cast<uint32_t *>(s_pay)[tid] = wp;
     }
+    for (int i = tid + nthr; i < kLaneVecs * 64; i += nthr) s_lane_tab[i] = g_lane_tab[i];   // workgroups narrower than 576 threads (deals with > ~1430 infosets): the rest of the table
     for (int i = tid + nthr; i < kDecision / 2; i += nthr) reinterpret_cast<uint32_t *>(s_inf)[i] = gi[i];
     for (int i = tid + nthr; i < kTerminal / 4; i += nthr) reinterpret_cast<uint32_t *>(s_pay)[i] = gp[i];
     __syncthreads();
@@ -857,7 +860,8 @@ constexpr int kApplyLanes = 8, kApplyThreads = 64;
 // loads per lane.  The launch must find d_sigcdf current (it holds the sigma the traversal sampled with).
 __global__ void __launch_bounds__(kApplyThreads)
 k_mccfr_apply_groups(const uint64_t *__restrict__ g_key, double *__restrict__ g_regret, double *__restrict__ g_strat,
-                     double *__restrict__ g_groups, int n_infosets, double *__restrict__ g_sigcdf) {
+                     double *__restrict__ g_groups, int n_infosets, double *__restrict__ g_sigcdf, uint32_t *__restrict__ g_iter) {
+    if (g_iter && blockIdx.x == 0 && threadIdx.x == 0) *g_iter += 1u;   // (graph mode) the next traversal launch reads it behind the kernel boundary
     const int lane = threadIdx.x & 63, k = lane & (kApplyLanes - 1);
     const int r = (int)(blockIdx.x * blockDim.x + threadIdx.x) / kApplyLanes;
     const bool valid = r < n_infosets;
@@ -1022,18 +1026,21 @@ static int32_t ensure_lane_table(scopa_ctx *ctx) {
 
 // One traversal launch of `nb` traversal pairs [b0, b0 + nb) of iteration `iteration` against the rows in d_sigcdf; the launch
 // adds its deltas into the context's group tables (all-zero whenever no launch's result is pending).
-static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
-    // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~870 infosets), fewer for deals
+struct TraverseGeom { int threads; size_t lds; uint32_t grid; };
+
+// everything a traversal launch needs that is not a launch: the kernel's LDS cap, the lane table, current sigma | threshold rows
+static int32_t prepare_traverse(scopa_ctx *ctx, uint32_t nb, TraverseGeom *g) {
+    // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~1430 infosets), fewer for deals
     // with more infosets (the tables alone fit up to 1653, the maximum)
     int waves = 16;
-    while (waves > 1 && traverse_lds_bytes(ctx->n_infosets, waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
-    const int threads = waves * 64;
-    const size_t lds = traverse_lds_bytes(ctx->n_infosets, waves);
-    SC_REQUIRE(ctx, lds + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
+    while (waves > 2 && traverse_lds_bytes(ctx->n_infosets, waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
+    g->threads = waves * 64;
+    g->lds = traverse_lds_bytes(ctx->n_infosets, waves);
+    SC_REQUIRE(ctx, g->lds + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
     SC_LDS_ATTR(ctx, scopa::kLdsTraverse, k_mccfr_traverse, ctx->lds_limit - kStaticLds);
     const uint32_t n_passes = (nb + waves - 1) / waves;  // one traversal pair per wavefront pass
-    const uint32_t grid = n_passes < (uint32_t)ctx->n_cus ? n_passes : (uint32_t)ctx->n_cus;
-    SC_REQUIRE(ctx, grid <= 1024u, SCOPA_ELIMIT, "mccfr traverse: more than 1024 compute units");
+    g->grid = n_passes < (uint32_t)ctx->n_cus ? n_passes : (uint32_t)ctx->n_cus;
+    SC_REQUIRE(ctx, g->grid <= 1024u, SCOPA_ELIMIT, "mccfr traverse: more than 1024 compute units");
     static_assert(kClockStride >= 4 * 512, "clock sample stride");
     if (int32_t rc = ensure_lane_table(ctx)) return rc;
     if (!ctx->sigcdf_valid) {  // tables were changed by another entry point since the last apply
@@ -1042,6 +1049,17 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
         SC_HIP(ctx, hipGetLastError());
         ctx->sigcdf_valid = true;
     }
+    return SCOPA_OK;
+}
+
+// One traversal launch of `nb` traversal pairs [b0, b0 + nb) of iteration `iteration` against the rows in d_sigcdf; the launch
+// adds its deltas into the context's group tables (all-zero whenever no launch's result is pending).
+static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, uint32_t nb) {
+    TraverseGeom g;
+    if (int32_t rc = prepare_traverse(ctx, nb, &g)) return rc;
+    const int threads = g.threads;
+    const size_t lds = g.lds;
+    const uint32_t grid = g.grid;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     const bool sampled = prof_events(ctx, &ev0, &ev1);
     unsigned long long *clock = sampled && ctx->d_clock && grid <= 512u ? ctx->d_clock + (size_t)((ctx->prof_launches - 1) % kClockSamples) * kClockStride : nullptr;
@@ -1049,12 +1067,47 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     if (sampled)
         hipExtLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ev0, ev1, 0, ctx->d_infoset, ctx->d_payoff,
                               ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab);
+                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)nullptr);
     else
         hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                            ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab);
+                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)nullptr);
     SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+// ---- graph mode: K iterations (traverse + apply each) captured ONCE into a HIP graph and replayed ------------------------------------
+// The iteration number cannot be a kernel argument then: it lives in a device word (d_meta[2]) that the apply kernel advances and the
+// traversal kernel reads, so results stay keyed by the same iteration ids as the eager loop's.
+void scopa::mccfr_graphs_clear(scopa_ctx *ctx) {
+    for (auto &e : ctx->mccfr_graphs) (void)hipGraphExecDestroy((hipGraphExec_t)e.exec);
+    ctx->mccfr_graphs.clear();
+}
+
+static int32_t graph_for(scopa_ctx *ctx, uint32_t batch, uint32_t k, hipGraphExec_t *out) {
+    for (auto &e : ctx->mccfr_graphs)
+        if (e.batch == batch && e.k == k) { *out = (hipGraphExec_t)e.exec; return SCOPA_OK; }
+    TraverseGeom g;
+    if (int32_t rc = prepare_traverse(ctx, batch, &g)) return rc;
+    uint32_t *d_iter = reinterpret_cast<uint32_t *>(ctx->d_meta + 2);
+    hipGraph_t graph = nullptr;
+    SC_HIP(ctx, hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeThreadLocal));
+    for (uint32_t i = 0; i < k; i++) {
+        hipLaunchKernelGGL(k_mccfr_traverse, dim3(g.grid), dim3(g.threads), g.lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
+                           ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
+                           0u, 0u, batch, ctx->d_counters + 8, ctx->d_visit, (unsigned long long *)nullptr, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)d_iter);
+        hipLaunchKernelGGL(k_mccfr_apply_groups, dim3((ctx->n_infosets * kApplyLanes + kApplyThreads - 1) / kApplyThreads), dim3(kApplyThreads), 0, ctx->stream, ctx->d_key,
+                           ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf, d_iter);
+    }
+    const hipError_t e_end = hipStreamEndCapture(ctx->stream, &graph);
+    if (e_end != hipSuccess || !graph) return scopa::fail(ctx, SCOPA_EHIP, "mccfr graph: stream capture", e_end);
+    hipGraphExec_t exec = nullptr;
+    const hipError_t e_inst = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    if (e_inst != hipSuccess) return scopa::fail(ctx, SCOPA_EHIP, "mccfr graph: instantiate", e_inst);
+    if (ctx->mccfr_graphs.size() >= 16) { (void)hipGraphExecDestroy((hipGraphExec_t)ctx->mccfr_graphs.front().exec); ctx->mccfr_graphs.erase(ctx->mccfr_graphs.begin()); }
+    ctx->mccfr_graphs.push_back({batch, k, (void *)exec});
+    *out = exec;
     return SCOPA_OK;
 }
 
@@ -1083,6 +1136,7 @@ extern "C" {
 
 int32_t scopa_mccfr_seed(scopa_ctx *ctx, uint64_t seed) {
     if (!ctx) return SCOPA_EINVAL;
+    if (seed != ctx->seed) scopa::mccfr_graphs_clear(ctx);   // captured launches carry the seed as an argument
     ctx->seed = seed;
     return SCOPA_OK;
 }
@@ -1170,15 +1224,39 @@ int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_iterate: no deal set");
     SC_REQUIRE(ctx, batch > 0 && batch <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_iterate: bad batch");
     SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (ctx->mccfr_graph_mode && !ctx->prof_on && n_iters > 1) {
+        // graph mode: chunks of <= 64 iterations, each one replay of a captured (traverse, apply) x k chain; launches that carry
+        // profiling events cannot be captured, so a profiled run takes the eager loop
+        TraverseGeom g;
+        if (int32_t rc = prepare_traverse(ctx, batch, &g)) return rc;
+        SC_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_meta + 2), (int)ctx->iteration, 1, ctx->stream));
+        for (uint32_t left = n_iters; left > 0;) {
+            const uint32_t k = left >= 64u ? 64u : left;
+            hipGraphExec_t exec = nullptr;
+            if (int32_t rc = graph_for(ctx, batch, k, &exec)) return rc;
+            SC_HIP(ctx, hipGraphLaunch(exec, ctx->stream));
+            ctx->iteration += k;
+            left -= k;
+        }
+        ctx->sigcdf_valid = true;
+        return SCOPA_OK;
+    }
     for (uint32_t it = 0; it < n_iters; it++) {
         const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch);
         if (rc != SCOPA_OK) return rc;
         hipLaunchKernelGGL(k_mccfr_apply_groups, dim3((ctx->n_infosets * kApplyLanes + kApplyThreads - 1) / kApplyThreads), dim3(kApplyThreads), 0, ctx->stream, ctx->d_key,
-                           ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf);
+                           ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf, (uint32_t *)nullptr);
         SC_HIP(ctx, hipGetLastError());
         ctx->sigcdf_valid = true;
         ctx->iteration++;
     }
+    return SCOPA_OK;
+}
+
+int32_t scopa_mccfr_graph_mode(scopa_ctx *ctx, int32_t on) {
+    if (!ctx) return SCOPA_EINVAL;
+    ctx->mccfr_graph_mode = on != 0;
+    if (!on) scopa::mccfr_graphs_clear(ctx);
     return SCOPA_OK;
 }
 

@@ -299,6 +299,72 @@ def test_mccfr_config2_whole_iteration_on_one_gpu(ctx, sl, oracle):
     assert ctx.mccfr_iteration() == 2
 
 
+def test_mccfr_graph_mode_replays_the_same_iterations(ctx, sl, oracle):
+    """scopa_mccfr_graph_mode: 150 iterations as captured HIP graphs (64 + 64 + 22: two replays of one graph and a shorter one), the
+    iteration number read from a device word the apply launch advances -- the same iteration ids as the eager loop, so the same
+    draws: exact visit counters, the same first-visit order, tables equal to the eager run's up to the order of the float64
+    atomics; then eager iterations continue from where the graphs stopped."""
+    perm = sl.deal_py_seed(42)
+    runs = []
+    for graph in (False, True):
+        ctx.set_deal(perm)
+        ctx.mccfr_seed(77)
+        ctx.mccfr_graph_mode(graph)
+        c0 = ctx.counters()
+        ctx.mccfr_iterate(512, 150)
+        assert ctx.mccfr_iteration() == 150
+        ctx.mccfr_graph_mode(False)
+        ctx.mccfr_iterate(512, 3)                # eager launches take over at iteration 150
+        assert ctx.mccfr_iteration() == 153
+        R, S, _ = ctx.tables_get()
+        c1 = ctx.counters()
+        runs.append((R, S, ctx.visited_get(), (c1[0] - c0[0], c1[1] - c0[1])))
+    (R0, S0, v0, n0), (R1, S1, v1, n1) = runs
+    assert n0 == n1 == (463 * 512 * 153, 240 * 512 * 153)
+    assert np.array_equal(v0 > 0, v1 > 0)
+    np.testing.assert_allclose(R1, R0, rtol=1e-9, atol=1e-9 * np.abs(R0).max())
+    np.testing.assert_allclose(S1, S0, rtol=1e-9, atol=1e-9 * np.abs(S0).max())
+    # and against the oracle from scratch for a short run (graph mode only)
+    ctx.set_deal(perm)
+    ctx.mccfr_seed(5)
+    ctx.mccfr_graph_mode(True)
+    ctx.mccfr_iterate(256, 5)
+    ctx.mccfr_graph_mode(False)
+    t = oracle.Tree(seed=42)
+    Ro, So, _ = t.tables()
+    t.mccfr_batched(Ro, So, 5, 0, 5, 256)
+    R, S, _ = ctx.tables_get()
+    np.testing.assert_allclose(R, Ro, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(Ro).max()))
+    np.testing.assert_allclose(S, So, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(So).max()))
+
+
+def test_mccfr_narrow_workgroups_give_the_same_deltas(ctx, sl, oracle):
+    """Deals with very many infosets leave room for fewer than 16 wavefronts per traversal workgroup (8 or fewer above ~1430
+    infosets: narrower than the 576 threads that stage the lane table in one step).  The test hook scopa_debug_lds_limit makes the
+    seed-42 deal run with 8, 4 and 2 wavefronts per workgroup: visit counts exact, deltas as the 16-wavefront launch's and the
+    oracle's."""
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    R, S, L = t.tables()
+    t.cfr_exact(R, S, L, 3)
+    ctx.tables_set(regret=R)
+    ctx.mccfr_seed(0x5C09A)
+    dR, dS, dv, tv = t.mccfr_batched_delta(R, 0x5C09A, 4, 100, 3000)
+    try:
+        for limit in (0, 100 * 1024, 88 * 1024, 82 * 1024):       # 16, 8, 4, 2 wavefronts per workgroup at 738 infosets
+            ctx.debug_lds_limit(limit)
+            c0 = ctx.counters()
+            ctx.mccfr_delta_set(np.zeros((t.n_infosets, 5)))
+            ctx.mccfr_traverse(4, 100, 3000)
+            d = ctx.mccfr_delta_get()
+            c1 = ctx.counters()
+            assert (c1[0] - c0[0], c1[1] - c0[1]) == (dv, tv) == (463 * 3000, 240 * 3000), limit
+            assert np.array_equal(d[:, 4], np.rint(dS.sum(1))), limit
+            np.testing.assert_allclose(d[:, :4], dR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(dR).max()))
+    finally:
+        ctx.debug_lds_limit(0)
+
+
 def test_two_contexts_are_independent(sl, oracle):
     """include/scopa.h: distinct contexts are independent.  Every entry point whose kernel needs more than the default 64 KB of
     dynamic LDS (the cap is raised per context = per device, not once per process) runs on a first AND on a second context."""
