@@ -35,6 +35,16 @@ ALG_BYTES_PER_VISIT = 111.6    # 32 B state + 32 B regret row + 0
 HBM_PEAK_GBPS = 8000.0         # MI355X_MICROARCH.md: 8.0 TB/s spec
 CLOCK_HZ = 2.4e9               # MI355X_MICROARCH.md: max clock
 N_CUS, SIMDS_PER_CU = 256, 4
+# The traversal kernel's LDS work counted from its DESIGN, not from its binary ("floor"): per traversal pair
+#   6 ply rounds over 2,6,10,25,40,80 unique nodes (7 wave-instructions: ply 5 needs two) x {parent record by cross-lane read, infoset id,
+#   threshold row (16 B), draw word, record store}                                                                    = 35
+#   the pair's 58 Philox blocks stored as 4 draw arrays                                                                =  4
+#   leaf stage: 240 leaves (4 wave-instructions) x {ply-5 record, payoff byte, payoff store}                           = 12
+#   update step: 52 traverser nodes (1 wave-instruction) x {5 ancestor records, 5 ancestor sigmas, own sigma row (2 x 16 B), leaf
+#   payoffs, 4 regret adds (ds_add_f64), visit count add}                                                               = 18
+# and the LDS-array cycles those cost when conflict-free (MI355X_MICROARCH.md LDS table: 2 per 4/8-byte access, 4 per 16-byte one).
+LDS_FLOOR_INSTR_PER_PAIR = 69
+LDS_FLOOR_CYCLES_PER_PAIR = 164
 REF_PY_VISITS_PER_S = 9300.0   # reference Python MCCFR, 1 Xeon core, survey container
 PRE_PHASE_S = 0.4
 REGIONS = 31
@@ -525,6 +535,15 @@ def main():
         valu_cyc = sq.get("valu_busy_cycles_per_pair", 2411.0)    # SQ_ACTIVE_INST_VALU x 4 (quad-cycles) / pairs
         lds_cyc = sq.get("lds_array_cycles_per_pair", 510.3)      # SQ_LDS_IDX_ACTIVE / pairs
         tr = load_profile_json("hbm_traffic.json") or {}
+        # the counter files were taken on ONE version of the kernel: say so when the source has moved on since
+        try:
+            with open(os.path.join(ROOT, "scopa_amd", "csrc", "scopa_mccfr.hip"), "rb") as fh:
+                src_sha = hashlib.sha256(fh.read()).hexdigest()
+        except OSError:
+            src_sha = None
+        profile_stale = {name: (src_sha is None or prof.get("source_sha256") != src_sha) for name, prof in (("traverse_sq.json", sq), ("hbm_traffic.json", tr))}
+        # the counters measured AT this run's batch, where the file has them (B = 4096): the units' busy fractions of this very launch shape
+        at_batch = sq.get("b%d" % args.batch) or {}
         traffic = tr.get("bytes_per_launch") if tr.get("batch", 4096) == args.batch else None
         bounds = {}
         if launches:
@@ -540,6 +559,18 @@ def main():
             }
             for b in bounds.values():
                 b["frac"] = (b["achieved"] / b["peak"]) if b["achieved"] else None
+            # two readings of the same ceilings.  frac (above): the per-pair cost of the kernel's steady state (counters at B = 65536,
+            # launch-time work amortised) x this launch's pairs / its time = what share of the launch the pair loop's work explains.
+            # frac_busy: the counters of a launch of THIS batch (prologue, epilogue, idle wavefronts included) = how busy the unit was.
+            if at_batch:
+                bounds["valu-issue"]["frac_busy"] = at_batch["valu_busy_cycles_per_pair"] * pairs_per_launch / kern_s / (N_CUS * SIMDS_PER_CU * CLOCK_HZ)
+                bounds["lds"]["frac_busy"] = at_batch["lds_array_cycles_per_pair"] * pairs_per_launch / kern_s / (N_CUS * CLOCK_HZ)
+            # distance from an algorithm-level floor (not from the binary's own instruction stream)
+            bounds["lds"]["floor"] = {"wave_instructions_per_pair": LDS_FLOOR_INSTR_PER_PAIR, "array_cycles_per_pair": LDS_FLOOR_CYCLES_PER_PAIR,
+                                      "measured_wave_instructions_per_pair": sq.get("lds_instr_per_pair"), "measured_array_cycles_per_pair": lds_cyc,
+                                      "frac_at_floor": LDS_FLOOR_CYCLES_PER_PAIR * pairs_per_launch / kern_s / (N_CUS * CLOCK_HZ),
+                                      "how": "LDS accesses the design needs per traversal pair, conflict-free (bench.py LDS_FLOOR_*; DESIGN.md section 5): "
+                                             "frac_at_floor = the LDS ceiling fraction this launch time would mean if the kernel issued only those"}
         top = max((k for k in bounds if bounds[k]["frac"] is not None), key=lambda k: bounds[k]["frac"], default=None)
         roofline = {
             "bound": top, "achieved": bounds[top]["achieved"] if top else None, "peak": bounds[top]["peak"] if top else None,
@@ -556,6 +587,9 @@ def main():
                                 "note": "SURVEY 8(d)'s algorithmic price, 111.6 B/visit x 463 x batch visits per launch, divided by kernel time.  NOT a bound "
                                         "for this kernel: those bytes are served from LDS, so the ratio exceeds 1; the HBM traffic actually measured is `traffic`"},
             "traffic_source": {k: tr.get(k) for k in ("source", "commit", "batch")} if tr else None,
+            "profile_stale": profile_stale,
+            "profile_stale_note": "true = scopa_mccfr.hip has changed since the named counter file was taken (sha256 of the source recorded by "
+                                  "tests/tools/fold_profiles.py): the per-pair figures then describe an older kernel",
             "timing_note": "kernel_avg_us: HIP start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL) of every "
                            "prof-stride-th launch on the kernel's stream -- the kernel's own begin/end timestamps, what rocprofv3 "
                            "reports as its duration; kernel_avg_us_device_clock: first workgroup start -> last workgroup end on the "

@@ -11,9 +11,11 @@ import collections, csv, glob, json, os, statistics as st, subprocess, sys
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "gpurun_out", "prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r02"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 P = os.path.join(R, "profiles")
 commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_mccfr.hip"], capture_output=True, text=True).stdout.strip()
+import hashlib
+source_sha256 = hashlib.sha256(open(os.path.join(R, "scopa_amd", "csrc", "scopa_mccfr.hip"), "rb").read()).hexdigest()   # bench.py recomputes it: roofline.profile_stale
 
 
 def counters(d):
@@ -39,7 +41,7 @@ for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
     res[ctr] = {r["kernel"]: r for r in rows}
 f, w = res["FETCH_SIZE"]["k_mccfr_traverse"]["mean_KB"], res["WRITE_SIZE"]["k_mccfr_traverse"]["mean_KB"]
 af, aw = res["FETCH_SIZE"].get("k_mccfr_apply_groups", {}).get("mean_KB"), res["WRITE_SIZE"].get("k_mccfr_apply_groups", {}).get("mean_KB")
-json.dump({"kernel": "k_mccfr_traverse", "batch": 4096, "commit": commit,
+json.dump({"kernel": "k_mccfr_traverse", "batch": 4096, "commit": commit, "source_sha256": source_sha256,
            "workload": "bench.py default (B=4096 per traverser, 738 infosets)",
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d dispatches each (profiles/%s_pmc_*.csv; tests/tools/profile_round.sh)"
                      % (res["FETCH_SIZE"]["k_mccfr_traverse"]["dispatches"], tag),
@@ -70,10 +72,55 @@ for batch in (4096, 65536):
                "per_launch_mean": m, "derived": d}, open(f"{P}/{tag}_pmc_sq_traverse_b{batch}.json", "w"), indent=1)
 # what bench.py prices the ceilings with: the per-pair figures of the batch that keeps every wavefront in its loop (launch-time work amortised)
 big = sq_all[65536]
-json.dump({"kernel": "k_mccfr_traverse", "commit": commit,
+json.dump({"kernel": "k_mccfr_traverse", "commit": commit, "source_sha256": source_sha256,
            "source": f"SQ counter passes at B=65536 (profiles/{tag}_pmc_sq_traverse_b65536.json); B=4096 figures beside them",
            "valu_instr_per_pair": big["valu_instr_per_pair"], "valu_busy_cycles_per_pair": big["valu_busy_cycles_per_pair"],
            "lds_array_cycles_per_pair": big["lds_array_cycles_per_pair"],
-           "b4096": {k: sq_all[4096][k] for k in ("valu_instr_per_pair", "valu_busy_cycles_per_pair", "lds_array_cycles_per_pair")}},
+           "lds_instr_per_pair": big["lds_instr_per_pair"],
+           "b4096": {k: sq_all[4096][k] for k in ("valu_instr_per_pair", "valu_busy_cycles_per_pair", "lds_array_cycles_per_pair", "lds_instr_per_pair")}},
           open(f"{P}/traverse_sq.json", "w"), indent=1)
 print(open(f"{P}/traverse_sq.json").read())
+
+
+# 4. SDCFR traversal kernel (tests/tools/profile_sdcfr.sh, run per batch; its outputs moved to gpurun_out/prof_sdcfr_b<batch>)
+sd_sha = hashlib.sha256(open(os.path.join(R, "scopa_amd", "csrc", "scopa_sdcfr.hip"), "rb").read()).hexdigest()
+sd_commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_sdcfr.hip"], capture_output=True, text=True).stdout.strip()
+for batch in (4096, 32768):
+    d = os.path.join(os.path.dirname(src), f"prof_sdcfr_b{batch}")
+    if not os.path.isdir(d):
+        continue
+    m, kern_us = {}, {}
+    for part in ("a", "b", "c"):
+        rows = list(csv.DictReader(open(f"{d}/{part}/sdcfr_counters.csv")))
+        acc = collections.defaultdict(list)
+        for r in rows:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+        for c, v in acc.items():
+            m[c] = st.mean(v)
+        kern_us[part] = json.loads(open(f"{d}/{part}.json").read().strip().splitlines()[-1])["traversal_only"]["kernel_avg_us"]
+    n_disp = len(rows) // max(len(acc), 1)
+    waves_working = batch // 4 if batch // 4 < 2048 else 2048            # tasks of 4 traversals; 8 wavefronts x 256 compute units at most
+    plain = json.loads(open(f"{d}/stats.json").read().strip().splitlines()[-1])
+    t_us = plain["traversal_only"]["kernel_avg_us"]                      # under --kernel-trace --stats only (counter passes run slower: lower clocks)
+    cyc = 4.0 * m["SQ_WAVE_CYCLES"] / waves_working
+    derived = {
+        "kernel_avg_us_under_kernel_trace": t_us, "kernel_avg_us_in_counter_passes": kern_us,
+        "mfma_busy_cycles_per_simd": m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, "mfma_flop_per_launch": 512.0 * m["SQ_INSTS_VALU_MFMA_MOPS_F32"],
+        "cycles_per_working_wave": cyc, "mfma_pipe_busy_share_of_a_working_wave_s_lifetime": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / cyc,   # a SIMD's matrix pipe against the lifetime of the wavefront(s) it hosts
+        "wave_time_issuing": m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], "wave_time_waiting_to_issue": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
+        "wave_time_waiting_on_counters_or_barriers": m["SQ_WAIT_ANY"] / m["SQ_WAVE_CYCLES"],
+        "valu_instr_per_traversal": m["SQ_INSTS_VALU"] / batch, "mfma_instr_per_traversal": m["SQ_INSTS_MFMA"] / batch,
+        "lds_instr_per_traversal": m["SQ_INSTS_LDS"] / batch, "lds_array_cycles_per_cu": m["SQ_LDS_IDX_ACTIVE"] / 256.0,
+        "lds_bank_conflict_share_of_lds_active": m["SQ_LDS_BANK_CONFLICT"] / m["SQ_LDS_IDX_ACTIVE"],
+        "vmem_reads_per_working_wave": m["SQ_INSTS_VMEM_RD"] / waves_working, "vmem_writes_per_working_wave": m["SQ_INSTS_VMEM_WR"] / waves_working,
+        "working_waves": waves_working,
+    }
+    json.dump({"kernel": "k_sdcfr_traverse", "commit": sd_commit, "source_sha256": sd_sha,
+               "workload": f"bench.py --workload sdcfr --batch {batch} ({batch} traversals per launch, launches of both traversers averaged)",
+               "dispatches": n_disp,
+               "source": "rocprofv3 --kernel-trace --pmc SQ_*, three passes of 8 counters (tests/tools/profile_sdcfr.sh); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in "
+                         "quad-cycles, SQ_LDS_IDX_ACTIVE and SQ_VALU_MFMA_BUSY_CYCLES in cycles (MI355X_MICROARCH.md)",
+               "per_launch_mean": m, "derived": derived}, open(f"{P}/{tag}_pmc_sq_sdcfr_traverse_b{batch}.json", "w"), indent=1)
+    open(f"{P}/{tag}_sdcfr_kernel_stats_b{batch}.csv", "w").write(open(glob.glob(f"{d}/stats/*kernel_stats.csv")[0]).read())
+    open(f"{P}/{tag}_bench_sdcfr_b{batch}_under_rocprof_stats.json", "w").write(json.dumps(plain) + "\n")
+    print(batch, json.dumps(derived, indent=1))
