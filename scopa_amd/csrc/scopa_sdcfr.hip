@@ -333,12 +333,14 @@ static_assert(kImgFloats == SCOPA_SDCFR_IMAGE_FLOATS, "include/scopa.h states th
 
 template <int T, int W>
 struct alignas(16) SdTeam {     // scratch of one TEAM (W wavefronts walking one task = T traversals); a frontier node is addressed by its POSITION f = t * width + j
-    float pol_trav[T][41][4];   // policy (legal actions, hand order) of every traverser node: plies m = 0..3 at offsets 0,1,5,17
-    uint32_t hr[T][41];         // the same nodes' hand nibbles | DFS post-order rank << 16 (the backward pass needs nothing else of them)
-    float val[W > 1 ? 2 : 1][T * 24];   // values of the frontier flowing back up, by position.  A team's wavefronts work on a ply's positions side by
-                                // side: two buffers.  A solo wavefront replaces them IN PLACE: node f reads its children f nl + k >= f, the 64 lanes read
-                                // before any of them writes (LDS executes a wavefront's operations in order), and a second round (positions >= 64) reads
-                                // positions >= 64 nl, which the first round did not write
+    float pol_trav[T][64];      // policy (legal actions, hand order) of every traverser node, packed: a node of traverser ply m = 0..3 has 4 - m legal
+                                // actions, so the 1, 4, 12, 24 nodes of a traversal take 4 + 12 + 24 + 24 = 64 floats, ply m from offset 0, 4, 16, 40
+    uint16_t hand_trav[T][41];  // the same nodes' hand nibbles (all the backward pass needs of a state), plies m = 0..3 at offsets 0, 1, 5, 17
+    uint16_t pad0[T == 4 ? 4 : 6];
+    float val[W > 1 ? 2 : 1][W > 1 ? T * 24 : 4];   // values of the frontier flowing back up, by position.  A team's wavefronts work on a ply's positions
+                                // side by side: two buffers here.  A SOLO wavefront keeps them in its `pos` area (dead once the forward pass is over) and
+                                // replaces them IN PLACE: node f reads its children f nl + k >= f, the 64 lanes read before any of them writes (LDS executes
+                                // a wavefront's operations in order), and a second round (positions >= 64) reads positions >= 64 nl, which the first did not write
     uint16_t idx[2][T * 24];    // tree index of the frontier nodes of the current / the next ply
     uint32_t bar;               // arrivals at the team's barriers so far (monotonic)
     int32_t task;               // the task the team walks next
@@ -348,9 +350,18 @@ struct alignas(16) SdPos { float pos[16][16]; };   // per wavefront: relu(adv) *
 static_assert(sizeof(SdTeam<4, 1>) % 16 == 0 && sizeof(SdTeam<2, 1>) % 16 == 0 && sizeof(SdTeam<4, 2>) % 16 == 0 && sizeof(SdTeam<2, 2>) % 16 == 0, "SdTeam alignment");
 constexpr int kSdNodeSlots = (kDecision + 1) & ~1;   // the node table in LDS, padded to 16 bytes
 static_assert(kTerminal % 16 == 0, "the payoff table in LDS keeps the team scratch behind it 16-byte aligned and is copied four bytes at a time");
-// wavefronts per workgroup: solo wavefronts (W = 1) need a scratch each and eight fit beside the two nets; teams share theirs, so
-// twelve wavefronts (three per SIMD, 168 registers each) fit as six teams of two or four teams of three
-__host__ __device__ constexpr int sd_waves(int W) { return W == 1 ? 8 : 12; }
+// wavefronts per workgroup: twelve (three per SIMD, 168 registers each) -- as solo wavefronts (W = 1; 2.8 KB of scratch each beside the two
+// nets: policies packed, values in the dead `pos` area; with eight wavefronts the matrix pipes idled a quarter of the time), as six teams of
+// two or four teams of three
+__host__ __device__ constexpr int sd_waves(int W) { return 12; }
+// DFS post-order rank of traverser node j of traverser ply m within its traversal = its memory row (the reference appends in that order):
+// (41, 10, 3, 1)[m] - 1 + the digits of j (radices 4, 3, 2 from the top) times (10, 3, 1), written out per m with constant divisors -- as a
+// loop over a table it cost a scalar memory load per digit (each draining the LDS queue with it: one lgkm counter) and a division by a
+// run-time radix
+__device__ __forceinline__ int sd_rank(int m, int j) {
+    const int jh = m == 3 ? j >> 1 : j, j1 = m >= 2 ? jh / 3 : jh, j2 = jh - 3 * j1;
+    return m == 0 ? 40 : m == 1 ? 9 + 10 * j : m == 2 ? 2 + 3 * j2 + 10 * j1 : (j & 1) + 3 * j2 + 10 * j1;
+}
 
 // A wavefront's LDS operations execute in order, so lane A's store is seen by lane B's later load without any wait; this only
 // keeps the compiler from moving LDS accesses across the point (the wait for a load's data is the compiler's own s_waitcnt).
@@ -475,6 +486,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
     __syncthreads();
     SdTeam<T, W> &ws = s_team[team];
     float (*wpos)[16] = s_pos[wave].pos;
+    float *vals = W > 1 ? &ws.val[0][0] : &wpos[0][0];   // the frontier's values on the way back up (a solo wavefront: in its pos area, free by then)
     uint32_t phase = 0;                        // arrivals the team's barrier counter shows once everybody has reached this wavefront's latest barrier
     const int nj = lane & 15, q = lane >> 4;   // this lane's column (node of the tile) and K / row group
 
@@ -515,7 +527,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
             if (!trav_ply && nl == 1) continue;
             const int n_nodes = T * width;
             const int m = (d - traverser) >> 1;                             // traverser-ply index when trav_ply
-            const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
+            const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, poff = m == 0 ? 0 : m == 1 ? 4 : m == 2 ? 16 : 40;
             const uint2 *nodes_d = s_node + (d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 21 : d == 4 ? 69 : d == 5 ? 213 : d == 6 ? 501 : 1077);   // level_offset(d) as
                                                                                   // selects: the table lookup is a scalar memory load per ply
             const float *Wn = s_w + p * kImgFloats;
@@ -671,20 +683,12 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                     // recurse on ALL legal actions, hand order (:326-336): lane (q, node) takes action q
                     const float pk = q < nl ? wpos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;
                     if (live) {
-                        ws.pol_trav[t][moff + j][q] = pk;
+                        if (q < nl) ws.pol_trav[t][poff + j * nl + q] = pk;
                         if (q < nl) ws.idx[cb ^ 1][f * nl + q] = (uint16_t)(node * nl + q);
                         // the node's memory row (:339-346): where, and everything of it that does not wait for the values -- features
                         // and mask -- now, four lanes to a row; the regrets follow in the backward pass.
-                        // Ring position: the reference appends in DFS post-order; rank of this traverser node within its traversal
-                        // = (41, 10, 3, 1)[m] - 1 + the digits of j (radices 4, 3, 2 from the top) times (10, 3, 1): written out per m with
-                        // constant divisors -- as a loop over a table it cost a scalar memory load per digit (each draining the LDS queue with
-                        // it: one lgkm counter) and a division by a run-time radix
-                        int rank;
-                        {
-                            const int jh = m == 3 ? j >> 1 : j, j1 = m >= 2 ? jh / 3 : jh, j2 = jh - 3 * j1;
-                            rank = m == 0 ? 40 : m == 1 ? 9 + 10 * j : m == 2 ? 2 + 3 * j2 + 10 * j1 : (j & 1) + 3 * j2 + 10 * j1;
-                        }
-                        if (q == 0) ws.hr[t][moff + j] = hand | ((uint32_t)rank << 16);
+                        const int rank = sd_rank(m, j);
+                        if (q == 0) ws.hand_trav[t][moff + j] = (uint16_t)hand;
                         if (t < n_live) {
                             uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)rank;
                             row = row >= capacity ? row - capacity : row;
@@ -702,8 +706,13 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                 } else {
                     // opponent: sample ONE action (:347-365); the four lanes of a node draw the same number
                     float pk[4];
+                    {
+                        float pr[4];                                        // all four reads before any use: one LDS round trip (unused hand nibbles are 0: a valid slot)
 #pragma unroll
-                    for (int k = 0; k < 4; k++) pk[k] = k < nl ? wpos[nj][(hand >> (4 * k)) & 15u] / den : 0.0f;
+                        for (int k = 0; k < 4; k++) pr[k] = wpos[nj][(hand >> (4 * k)) & 15u];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) pk[k] = k < nl ? pr[k] / den : 0.0f;
+                    }
                     float sum = pk[0];
 #pragma unroll
                     for (int k = 1; k < 4; k++) if (k < nl) sum += pk[k];  // action_probs.sum(), float32, left to right
@@ -723,9 +732,11 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                         double last = cdf[0];
 #pragma unroll
                         for (int k = 1; k < 4; k++) last = k < nl ? cdf[k] : last;
-                        a = 0;
-#pragma unroll
-                        for (int k = 0; k < 3; k++) if (k < nl - 1 && cdf[k] / last <= u) a = k + 1;   // (cdf[nl - 1] / last = 1 > u: never)
+                        // a = #{k < nl - 1 : cdf[k] / last <= u}  (cdf[nl - 1] / last = 1 > u: never); nl is wave-uniform, so the float64
+                        // divisions a ply does not need are branched over, not computed and masked (nl = 2 at the widest plies: one)
+                        a = cdf[0] / last <= u ? 1 : 0;
+                        if (nl > 2) a = cdf[1] / last <= u ? 2 : a;
+                        if (nl > 3) a = cdf[2] / last <= u ? 3 : a;
                     }
                     if (live && q == 0) ws.idx[cb ^ 1][f] = (uint16_t)(node * nl + a);
                 }
@@ -739,39 +750,42 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
         // ---- leaves, then backward ---------------------------------------------------------------------------------------
         for (int f = lane + 64 * wr; f < T * width; f += 64 * W) {
             const int p0 = s_payoff[ws.idx[cb][f]];
-            ws.val[0][f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
+            vals[f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
         }
         team_barrier<W>(&ws.bar, phase, lane, g_err);
-        int cur = 0;
+        int cur = 0;                                                        // (teams) which half of the value buffer holds the children's values
 #pragma unroll 1
         for (int d = kPlies - 1; d >= 0; d--) {
             const int p = d & 1, nl = 4 - (d >> 1);
             if (p != traverser) continue;                                  // opponent ply: the sampled child's value is returned unchanged (:363-365), same position
             width /= nl;
             const int m = (d - traverser) >> 1;
-            const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
+            const int moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, poff = m == 0 ? 0 : m == 1 ? 4 : m == 2 ? 16 : 40;
+            const float *vin = vals + (W > 1 ? cur * T * 24 : 0);
+            float *vout = vals + (W > 1 ? (cur ^ 1) * T * 24 : 0);
             for (int f = lane + 64 * wr; f < T * width; f += 64 * W) {
                 int t = 0;
 #pragma unroll
                 for (int k = 1; k < T; k++) t += f >= k * width;
                 const int j = f - t * width;
-                const uint32_t hr = ws.hr[t][moff + j], hand = hr & 0xFFFFu, rank = hr >> 16;
-                const float4 pol = *reinterpret_cast<const float4 *>(&ws.pol_trav[t][moff + j][0]);
-                const float pl[4] = {pol.x, pol.y, pol.z, pol.w};
+                const uint32_t hand = ws.hand_trav[t][moff + j], rank = (uint32_t)sd_rank(m, j);
+                float pl[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) pl[k] = ws.pol_trav[t][poff + j * nl + (k < nl ? k : 0)];
                 float value = 0.0f, cfv[16];
 #pragma unroll
                 for (int cc = 0; cc < 16; cc++) cfv[cc] = 0.0f;           // counterfactual_values = zeros(16) (:324)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     if (k < nl) {
-                        const float av = ws.val[cur][f * nl + k];
+                        const float av = vin[f * nl + k];
                         value += pl[k] * av;                                 // value += policy[action] * action_value, float32 (:335)
                         const int c = (int)((hand >> (4 * k)) & 15u);
 #pragma unroll
                         for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
                     }
                 }
-                ws.val[cur ^ (W > 1)][f] = value;
+                vout[f] = value;
                 if (t < n_live) {
                     float mx = 0.0f, reg[16];
 #pragma unroll
@@ -791,7 +805,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
             cur ^= (W > 1);
             team_barrier<W>(&ws.bar, phase, lane, g_err);
         }
-        if (wr == 0 && lane < n_live) root_values[tb0 + lane] = ws.val[cur][lane];
+        if (wr == 0 && lane < n_live) root_values[tb0 + lane] = vals[(W > 1 ? cur * T * 24 : 0) + lane];
         SD_STAMP(6);
         // the team's next task: its first wavefront takes it (everybody has passed the barrier above, so the scratch is free)
         if (W == 1) {
