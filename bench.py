@@ -278,6 +278,13 @@ def run_sdcfr(args, emit=True):
         for b in bounds.values():
             b["frac"] = b["achieved"] / b["peak"]
         top = max(bounds, key=lambda k: bounds[k]["frac"])
+        tr = load_profile_json(f"sdcfr_hbm_traffic_b{batch}.json") or {}     # FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch, if taken
+        traffic = tr.get("bytes_per_launch")
+        try:
+            with open(os.path.join(ROOT, "scopa_amd", "csrc", "scopa_sdcfr.hip"), "rb") as fh:
+                traffic_stale = tr.get("source_sha256") != hashlib.sha256(fh.read()).hexdigest() if tr else None
+        except OSError:
+            traffic_stale = None
         nets = np.stack([np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in a.net.state_dict().values()]) for a in d.advantage_nets])
         out = {"metric": "MiniScopa infoset-traversals/sec", "value": visits / elapsed, "unit": "infoset-traversals/s", "n_gpus": world,
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
@@ -290,7 +297,8 @@ def run_sdcfr(args, emit=True):
                           "replicas_bit_identical": replicas_identical, "shared_gpu_rehearsal": bool(args.share_gpu)},
                "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms)},
                "roofline": {"bound": top, "achieved": bounds[top]["achieved"], "peak": bounds[top]["peak"], "unit": bounds[top]["unit"], "frac": bounds[top]["frac"],
-                            "traffic": None, "kernel": "k_sdcfr_traverse", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,
+                            "traffic": traffic, "traffic_GBps": (traffic / kern_s / 1e9) if traffic else None, "profile_stale": traffic_stale,
+                            "kernel": "k_sdcfr_traverse", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,
                             "note": "kernel time from events recorded on the kernel's stream around each launch; both nets (2 x 54 KB as MFMA operand images), the "
                                     "node table and the per-team frontier live in LDS, activations stay in registers (an accumulator tile is the next layer's B operand), "
                                     "HBM sees the 41 x 264 B memory rows per traversal; SQ counter passes: profiles/r03_pmc_sq_sdcfr_traverse.json"},

@@ -19,7 +19,11 @@
 // Random draws are Philox4x32-10 blocks keyed by the node: block (ntl, j >> 1) of the (global traversal id, iteration, traverser)
 // stream serves the four nodes (j even | odd) x (opponent node | traverser node below it), one 32-bit word each.  All 58 blocks of a
 // pair are computed in ONE dense pre-pass (draw_pair) and kept as 31-bit integers that are compared with integer thresholds
-// ceil(cdf * 2^31) -- so results do not depend on launch geometry, pass size or GPU count.  Plies 6-7 have one legal action: they
+// ceil(cdf * 2^31) -- so WHICH traversals are sampled does not depend on launch geometry, pass size or GPU count (the sums of their
+// increments do, at rounding level: float64 atomics add in arrival order -- LDS within a workgroup, memory-side into a group table -- so two
+// runs agree to ~1e-15 relative per iteration, not bit for bit, and since the rounded regrets feed the next iteration's integer thresholds a
+// one-ulp difference can eventually flip a draw: batched MCCFR is reproducible to rounding per run and per grid; the reference-order
+// kernels, k_mccfr_replay and k_cfr_exact*, are bit-exact).  Plies 6-7 have one legal action: they
 // only resolve the 60 leaf payoffs per task and the visit counts.  The update step then gives one lane per traverser node (26 per
 // task): reach and sampling probability rebuilt from the <= 5 ancestor records (the reference's products in the reference's order),
 // v as the reference's fma chain over <= 4 leaf payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Every stage

@@ -202,7 +202,7 @@ def test_fused_traversal_matches_ply_by_ply_path(dcfr, trav):
     sampled actions, identical features/masks/row order, float32 values within 1e-5."""
     import torch
     d, _ = dcfr
-    B = 300
+    B = 303                       # 75 whole tasks of four traversals and one of three
     v_ref = d._traverse_batch(trav, B, fused=False)
     mem = d.advantage_nets[trav].buffer
     fa, ra, ma = (t.clone() for t in mem.rows(torch.arange(B * 41, device="cuda:0")))
