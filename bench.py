@@ -281,8 +281,8 @@ def run_sdcfr(args, emit=True):
         tr = load_profile_json(f"sdcfr_hbm_traffic_b{batch}.json") or {}     # FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch, if taken
         traffic = tr.get("bytes_per_launch")
         try:
-            with open(os.path.join(ROOT, "scopa_amd", "csrc", "scopa_sdcfr.hip"), "rb") as fh:
-                traffic_stale = tr.get("source_sha256") != hashlib.sha256(fh.read()).hexdigest() if tr else None
+            from scopa_amd.build import source_fingerprint
+            traffic_stale = (tr.get("source_sha256") != source_fingerprint("scopa_sdcfr.hip")) if tr else None
         except OSError:
             traffic_stale = None
         nets = np.stack([np.concatenate([v.detach().cpu().numpy().reshape(-1) for v in a.net.state_dict().values()]) for a in d.advantage_nets])
@@ -545,8 +545,8 @@ def main():
         tr = load_profile_json("hbm_traffic.json") or {}
         # the counter files were taken on ONE version of the kernel: say so when the source has moved on since
         try:
-            with open(os.path.join(ROOT, "scopa_amd", "csrc", "scopa_mccfr.hip"), "rb") as fh:
-                src_sha = hashlib.sha256(fh.read()).hexdigest()
+            from scopa_amd.build import source_fingerprint
+            src_sha = source_fingerprint("scopa_mccfr.hip")       # comments and whitespace do not count
         except OSError:
             src_sha = None
         profile_stale = {name: (src_sha is None or prof.get("source_sha256") != src_sha) for name, prof in (("traverse_sq.json", sq), ("hbm_traffic.json", tr))}
@@ -596,7 +596,7 @@ def main():
                                         "for this kernel: those bytes are served from LDS, so the ratio exceeds 1; the HBM traffic actually measured is `traffic`"},
             "traffic_source": {k: tr.get(k) for k in ("source", "commit", "batch")} if tr else None,
             "profile_stale": profile_stale,
-            "profile_stale_note": "true = scopa_mccfr.hip has changed since the named counter file was taken (sha256 of the source recorded by "
+            "profile_stale_note": "true = scopa_mccfr.hip has changed (comments and whitespace aside) since the named counter file was taken (sha256 recorded by "
                                   "tests/tools/fold_profiles.py): the per-pair figures then describe an older kernel",
             "timing_note": "kernel_avg_us: HIP start/stop events attached to the dispatch itself (hipExtLaunchKernelGGL) of every "
                            "prof-stride-th launch on the kernel's stream -- the kernel's own begin/end timestamps, what rocprofv3 "

@@ -40,3 +40,15 @@ def build_lib(force=False, verbose=False):
 
 if __name__ == "__main__":
     print(build_lib(force=True, verbose=True))
+
+
+def source_fingerprint(name):
+    """sha256 of a kernel source under csrc/ with comments and whitespace removed: what the profile summaries under profiles/ record
+    (tests/tools/fold_profiles.py) and bench.py recomputes for `roofline.profile_stale` -- an edited comment is not a new kernel."""
+    import hashlib
+    import re
+    with open(os.path.join(CSRC, name)) as fh:
+        text = fh.read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", "", text)
+    return hashlib.sha256("".join(text.split()).encode()).hexdigest()

@@ -15,7 +15,9 @@ tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
 P = os.path.join(R, "profiles")
 commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_mccfr.hip"], capture_output=True, text=True).stdout.strip()
 import hashlib
-source_sha256 = hashlib.sha256(open(os.path.join(R, "scopa_amd", "csrc", "scopa_mccfr.hip"), "rb").read()).hexdigest()   # bench.py recomputes it: roofline.profile_stale
+sys.path.insert(0, R)
+from scopa_amd.build import source_fingerprint
+source_sha256 = source_fingerprint("scopa_mccfr.hip")   # comments and whitespace stripped; bench.py recomputes it: roofline.profile_stale
 
 
 def counters(d):
@@ -83,7 +85,7 @@ print(open(f"{P}/traverse_sq.json").read())
 
 
 # 4. SDCFR traversal kernel (tests/tools/profile_sdcfr.sh, run per batch; its outputs moved to gpurun_out/prof_sdcfr_b<batch>)
-sd_sha = hashlib.sha256(open(os.path.join(R, "scopa_amd", "csrc", "scopa_sdcfr.hip"), "rb").read()).hexdigest()
+sd_sha = source_fingerprint("scopa_sdcfr.hip")
 sd_commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_sdcfr.hip"], capture_output=True, text=True).stdout.strip()
 for batch in (4096, 32768):
     d = os.path.join(os.path.dirname(src), f"prof_sdcfr_b{batch}")
