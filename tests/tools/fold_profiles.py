@@ -101,7 +101,7 @@ for batch in (4096, 32768):
             m[c] = st.mean(v)
         kern_us[part] = json.loads(open(f"{d}/{part}.json").read().strip().splitlines()[-1])["traversal_only"]["kernel_avg_us"]
     n_disp = len(rows) // max(len(acc), 1)
-    waves_working = batch // 4 if batch // 4 < 2048 else 2048            # tasks of 4 traversals; 8 wavefronts x 256 compute units at most
+    waves_working = min(batch // 4, 12 * 256)                            # tasks of 4 traversals; 12 wavefronts x 256 compute units at most
     plain = json.loads(open(f"{d}/stats.json").read().strip().splitlines()[-1])
     t_us = plain["traversal_only"]["kernel_avg_us"]                      # under --kernel-trace --stats only (counter passes run slower: lower clocks)
     cyc = 4.0 * m["SQ_WAVE_CYCLES"] / waves_working
