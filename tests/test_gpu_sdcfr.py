@@ -482,3 +482,31 @@ def test_memory_ring_wraps_like_a_deque(ctx, oracle, golden, fused):
     a._rng.seed(42); a._rng.shuffle(list(range(16)))
     assert np.array_equal(rows_dev[0].cpu().numpy(), mem.logical_to_physical(torch.tensor(idx, device="cuda:0")).cpu().numpy())
     assert a.train(batch_size=128, epochs=1) >= 0.0
+
+
+@pytest.mark.parametrize("seed", [7, 123])
+def test_traversal_on_other_deals_vs_oracle(ctx, golden, oracle, seed):
+    """The traversal kernels are deal-parametric (MiniScopaEnv(seed=k), mini_scopa_game.py:120-132; the reference's solvers only ever see
+    seed 42): on two other deals -- other hands, other capture patterns, another node table in the fused kernel's LDS -- both paths
+    give the oracle's rows for the same ids, and a second solver on the SAME context type sees its own deal."""
+    import torch
+    from scopa_amd.envs.openspiel_mini_scopa import MiniScopaGame
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    g = golden.npz("sdcfr.npz")
+    torch.manual_seed(0)
+    d = DeepCFR(MiniScopaGame(seed=seed), num_players=2, device="cuda:0", batch=64)
+    for p in range(2):
+        d.advantage_nets[p].net.load_state_dict({str(k): torch.from_numpy(g[f"net{p}__{k}"]).to("cuda:0") for k in g[f"net{p}_names"]})
+    nets, t = _nets_flat(d), oracle.Tree(seed=seed)
+    B = 64
+    for trav in (0, 1):
+        of, orr, om, ov, vis = t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=0, b0=0, nb=B)
+        assert vis == (105, 82)[trav] * B
+        for fused in (True, False):
+            mem = d.advantage_nets[trav].buffer
+            base = len(mem)
+            vals = d._traverse_batch(trav, B, fused=fused)
+            f, r, m = mem.rows(torch.arange(base, base + 41 * B, device="cuda:0"))
+            assert np.array_equal(f.cpu().numpy(), of) and np.array_equal(m.cpu().numpy(), om), (seed, trav, fused)
+            np.testing.assert_allclose(r.cpu().numpy(), orr, atol=ATOL, rtol=0)
+            np.testing.assert_allclose(vals.cpu().numpy(), ov, atol=ATOL, rtol=0)
