@@ -208,7 +208,9 @@ def run_sdcfr(args, emit=True):
     sys.stdout.flush()
     os.dup2(_so, 1)
     ctx = d._engine.ctx
-    if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):       # kernel experiments: task shape of k_sdcfr_traverse
+    if os.environ.get("SCOPA_SDCFR_MODE"):                                        # kernel experiments: 1 = a forward pass per visit in the timed region too
+        ctx.sdcfr_mode(int(os.environ["SCOPA_SDCFR_MODE"]))
+    if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):       # kernel experiments: task shape of the traversal kernels
         ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))
     epochs = args.sdcfr_epochs
 
@@ -261,6 +263,22 @@ def run_sdcfr(args, emit=True):
     assert visits == (105 + 82) * batch * args.steps * world
     kern_ms = [a.elapsed_time(b) for a, b in d.kernel_events]
     d.kernel_events = None
+    # beside the timed region: the same traversal with a forward pass per VISIT (k_sdcfr_traverse, scopa_sdcfr_mode 1), for its MFMA
+    # roofline -- the default path evaluates every decision node once per launch and is bound by the memory rows instead
+    pv_ms = []
+    if os.environ.get("SCOPA_SDCFR_MODE") != "1":
+        ctx.sdcfr_mode(1)
+        for a in d.advantage_nets:
+            a.buffer.total = 0
+        d.kernel_events = []
+        for _ in range(6):
+            for p in range(2):
+                d._traverse_batch(p, batch, sync=False)
+        d._stream.synchronize()
+        pv_ms = [a.elapsed_time(b) for a, b in d.kernel_events][4:]
+        d.kernel_events = None
+        ctx.sdcfr_mode(0)
+    per_visit_default = os.environ.get("SCOPA_SDCFR_MODE") == "1"
     out = None
     if rank == 0:
         kern_s = 1e-3 * sum(kern_ms) / max(len(kern_ms), 1)              # one launch = one player's batch
@@ -268,17 +286,26 @@ def run_sdcfr(args, emit=True):
         flop_visit = 2.0 * (34 * 128 + 128 * 64 + 64 * 16)               # one MLP forward (27 136 FLOP) ...
         fwd_launch = (81 + 58) / 2.0 * batch                             # ... per visit that needs one: the 24 single-action opponent nodes of plies 6/7 are forced, the kernel skips them
         alg_b = 412.0
-        bounds = {"mfma-f32": {"achieved": flop_visit * fwd_launch / kern_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
-                               "how": "27 136 FLOP (one 34-128-64-16 forward) x forward passes per launch (81 / 58 of the 105 / 82 visits of a traversal) / kernel time "
-                                      "against the f32 matrix peak at 2.4 GHz (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD; the kernel pads tiles of 16 nodes: it issues "
-                                      "4.5 % more FLOP than counted here).  The shader clock holds ~2.15 GHz while this kernel runs (in-kernel s_memtime / s_memrealtime, "
-                                      "profiles/r03_sdcfr_stamps.txt), i.e. 0.89 of this peak is the most the clock allows"},
+        rows_b = 41 * 264.0 * batch                                      # the memory rows a launch must write (41 rows x (34 + 16 + 16) float32 per traversal)
+        pv_s = 1e-3 * sum(pv_ms) / max(len(pv_ms), 1) if pv_ms else (kern_s if per_visit_default else None)
+        bounds = {"hbm-memory-rows": {"achieved": rows_b / kern_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                                      "how": "41 x 264 B of memory rows per traversal x traversals per launch / traversal time (policy launch + walk launch): what the "
+                                             "launch must write whatever the algorithm; nets, policy table, node table and frontier are LDS-resident"},
                   "hbm-algorithmic": {"achieved": alg_b * v_launch / kern_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                      "how": "SURVEY 8(d): 412 B per visit (state, features, mask, advantages, memory rows) x visits per launch / kernel time"}}
+                                      "how": "SURVEY 8(d): 412 B per visit (state, features, mask, advantages, memory rows) x visits per launch / traversal time"}}
+        if per_visit_default:
+            bounds.pop("hbm-memory-rows")
+        if pv_s:
+            bounds["mfma-f32"] = {"achieved": flop_visit * fwd_launch / pv_s / 1e12, "peak": 157.3, "unit": "TFLOP/s",
+                                  "how": "the forward-per-visit form (k_sdcfr_traverse, scopa_sdcfr_mode 1; measured beside the timed region unless it IS the timed path): 27 136 FLOP "
+                                         "(one 34-128-64-16 forward) x forward passes per launch (81 / 58 of the 105 / 82 visits of a traversal) / kernel time against the f32 matrix "
+                                         "peak at 2.4 GHz (v_mfma_f32_16x16x4_f32, 64 FLOP/clk/SIMD; tiles of 16 nodes: 4.5 % more FLOP issued than counted).  The shader clock holds "
+                                         "~2.15 GHz while it runs (profiles/r03_sdcfr_stamps.txt): 0.89 of this peak is the most the clock allows.  The default path does not pay "
+                                         "this: it evaluates the deal's 1 653 decision nodes once per launch (k_sdcfr_policy) instead of once per visit"}
         for b in bounds.values():
             b["frac"] = b["achieved"] / b["peak"]
-        top = max(bounds, key=lambda k: bounds[k]["frac"])
-        tr = load_profile_json(f"sdcfr_hbm_traffic_b{batch}.json") or {}     # FETCH_SIZE / WRITE_SIZE passes of this kernel at this batch, if taken
+        top = "mfma-f32" if per_visit_default else "hbm-memory-rows"
+        tr = load_profile_json(f"sdcfr_hbm_traffic_b{batch}.json") or {}     # FETCH_SIZE / WRITE_SIZE passes of the traversal launches at this batch, if taken
         traffic = tr.get("bytes_per_launch")
         try:
             from scopa_amd.build import source_fingerprint
@@ -295,13 +322,18 @@ def run_sdcfr(args, emit=True):
                           "parallelism": f"dp{world}" + (" + 1 gradient all-reduce of 55104 B per optimiser step (RCCL)" if world > 1 else ""),
                           "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)",
                           "replicas_bit_identical": replicas_identical, "shared_gpu_rehearsal": bool(args.share_gpu)},
-               "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms)},
+               "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms),
+                                  "form": "forward pass per visit (k_sdcfr_traverse)" if per_visit_default else "policy table per launch + walks (k_sdcfr_policy + k_sdcfr_walk)",
+                                  "forward_per_visit_kernel_avg_us": 1e6 * pv_s if pv_s else None,
+                                  "forward_per_visit_visits_per_s_per_gpu": (v_launch / pv_s) if pv_s else None},
                "roofline": {"bound": top, "achieved": bounds[top]["achieved"], "peak": bounds[top]["peak"], "unit": bounds[top]["unit"], "frac": bounds[top]["frac"],
                             "traffic": traffic, "traffic_GBps": (traffic / kern_s / 1e9) if traffic else None, "profile_stale": traffic_stale,
-                            "kernel": "k_sdcfr_traverse", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,
-                            "note": "kernel time from events recorded on the kernel's stream around each launch; both nets (2 x 54 KB as MFMA operand images), the "
-                                    "node table and the per-team frontier live in LDS, activations stay in registers (an accumulator tile is the next layer's B operand), "
-                                    "HBM sees the 41 x 264 B memory rows per traversal; SQ counter passes: profiles/r03_pmc_sq_sdcfr_traverse.json"},
+                            "kernel": "k_sdcfr_traverse" if per_visit_default else "k_sdcfr_walk (+ k_sdcfr_policy)", "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms), "bounds": bounds,
+                            "note": "time from events recorded on the kernels' stream around each player's traversal (both launches of the default form).  Default form: the "
+                                    "advantage nets are frozen during a launch and a node's features depend on the tree node alone, so the deal's 1 653 decision nodes are "
+                                    "evaluated once (MFMA tiles, k_sdcfr_policy) and the traversals walk the 26 KB policy table in LDS; HBM sees the 41 x 264 B memory rows per "
+                                    "traversal, which is what bounds it.  Forward-per-visit form (bounds.mfma-f32): both nets as MFMA operand images in LDS, activations in "
+                                    "registers; SQ counter passes: profiles/r03_pmc_sq_sdcfr_traverse_b*.json"},
                "decision_visits": visits, "world": roster}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sdcfr(nets)

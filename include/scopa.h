@@ -211,8 +211,15 @@ int32_t scopa_sdcfr_pack_weights(scopa_ctx *ctx, int32_t player, const float *d_
 int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_image, float *d_mem_feat,
                                    float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
                                    float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0);
-/* experiments: traversals per task of the fused kernel (0 = the library's choice, 2 or 4) and wavefronts that share a task's
- * tiles (0 = the library's choice, 1..3).  Results do not depend on either. */
+/* How scopa_sdcfr_traverse_fused evaluates the advantage nets.  0 (default): ONCE per decision node of the deal and launch -- the nets
+ * are frozen while a launch runs and a node's features depend on the tree node alone, so its 1 653 policies are computed by one
+ * small launch on the matrix cores and the traversals walk that table (two launches; the memory rows bound it).  1: a forward pass
+ * per visit inside the traversal kernel (one launch; the form for batches that would not share a deal; also what d_uniforms takes).
+ * Same rows, same values, same sampled actions either way. */
+int32_t scopa_sdcfr_mode(scopa_ctx *ctx, int32_t forward_per_visit);
+/* experiments: traversals per task of the traversal kernels (0 = the library's choice; 2, 4 or 8 for the walk kernel, 2 or 4 for
+ * the forward-per-visit kernel) and wavefronts that share a task's tiles in the latter (0 = the library's choice, 1..3).  Results
+ * do not depend on either. */
 int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task);
 /* features / masks of arbitrary device-resident states for the player to move (DeepCFR.get_policy, :497-504) */
 int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask);

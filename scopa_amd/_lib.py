@@ -26,7 +26,7 @@ SYMBOLS = [
     "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_mode", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_mccfr_graph_mode", "scopa_debug_lds_limit", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
-    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_features_from_states",
+    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_sdcfr_mode", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
     "scopa_multi_cfr_exact_iterate_lanes", "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
@@ -133,6 +133,7 @@ def lib():
         "scopa_sdcfr_image_floats": (i32, []),
         "scopa_sdcfr_pack_weights": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "scopa_sdcfr_tuning": (i32, [vp, i32, i32]),
+        "scopa_sdcfr_mode": (i32, [vp, i32]),
         "scopa_features_from_states": (i32, [vp, vp, i64, vp, vp]),
         "scopa_eval_init_states": (i32, [vp, vp, i64]),
         "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
@@ -409,6 +410,10 @@ class Context:
         """torch tensors of one advantage net (W[out][in], float32) -> `player`'s half of the fused kernel's weight image."""
         self._ck(self._L.scopa_sdcfr_pack_weights(self._h, player, *(C.c_void_p(x) for x in (w1_ptr, b1_ptr, w2_ptr, b2_ptr, w3_ptr, b3_ptr, image_ptr))),
                  "scopa_sdcfr_pack_weights")
+
+    def sdcfr_mode(self, forward_per_visit):
+        """0 = policy table per launch + walks (default), 1 = a forward pass per visit inside the traversal kernel; same results"""
+        self._ck(self._L.scopa_sdcfr_mode(self._h, 1 if forward_per_visit else 0), "scopa_sdcfr_mode")
 
     def sdcfr_tuning(self, traversals_per_task=0, wavefronts_per_task=0):
         """experiments: task shape of the fused traversal kernel (0 = the library's choice); results do not depend on it"""

@@ -59,6 +59,8 @@ struct scopa_ctx {
     uint64_t sdcfr_visits = 0;  // decision-node visits of SDCFR traversals (one per frontier slot featurised)
     void *d_sdnode = nullptr;   // [kDecision] uint2: feature bits | mover's hand nibbles of every decision node (scopa_sdcfr.hip: k_sdcfr_nodeinfo), built at first use per deal
     bool sdnode_valid = false;  // false after scopa_set_deal
+    void *d_sdpol = nullptr;    // [kDecision] float4: regret-matching policy of every decision node under the nets of the launch at hand (k_sdcfr_policy)
+    int sdcfr_mode = 0;         // 0 = policy table per launch + walks (one deal: every node evaluated once), 1 = a forward pass per visit (k_sdcfr_traverse)
     int sdcfr_tile_t = 0, sdcfr_team_w = 0;   // k_sdcfr_traverse: traversals per task (2, 4) and wavefronts per task (1..3); 0 = the library's choice (scopa_sdcfr_tuning)
     uint32_t iteration = 0;
 
@@ -138,7 +140,7 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, so the "already raised" flag lives in the
 // context (one context = one device), not in a process-wide static: a second context on another device raises it again.
-enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsCfrSched = 512u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u, kLdsSdcfr2 = 1024u, kLdsSdcfr3 = 2048u, kLdsSdcfr4 = 4096u, kLdsSdcfr5 = 8192u, kLdsSdcfr6 = 16384u, kLdsSdcfr7 = 32768u };
+enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsCfrSched = 512u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u, kLdsSdcfr2 = 1024u, kLdsSdcfr3 = 2048u, kLdsSdcfr4 = 4096u, kLdsSdcfr5 = 8192u, kLdsSdcfr6 = 16384u, kLdsSdcfr7 = 32768u, kLdsSdPolicy = 65536u, kLdsSdWalk2 = 131072u, kLdsSdWalk4 = 262144u, kLdsSdWalk8 = 524288u };
 inline int32_t ensure_lds_attr(scopa_ctx *ctx, uint32_t kernel_bit, const void *fn, int bytes) {
     if (ctx->lds_attr_done & kernel_bit) return SCOPA_OK;
     SC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

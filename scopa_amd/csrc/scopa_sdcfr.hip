@@ -828,6 +828,324 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
     }
 }
 
+// =====================================================================================================================
+// The same traversal for the reference's own workload -- ONE deal per solver -- without a forward pass per VISIT.
+// The advantage nets are frozen while a launch runs and a node's features are a function of the tree node alone, so the policy at a
+// decision node is the same for every traversal that reaches it.  The deal's 1 653 decision nodes are therefore evaluated ONCE per
+// launch (k_sdcfr_policy: 105 tiles of 16 nodes on the matrix cores, the tile arithmetic of k_sdcfr_traverse instruction for
+// instruction, so the same bits) and the traversals become walks over a 26 KB policy table held in LDS (k_sdcfr_walk): sample, expand,
+// write memory rows, carry values back up.  At 4 096 traversals a launch's 331 776 forward passes (81 per traversal) become 1 653; what
+// is left is bound by the memory rows it must write (41 x 264 B per traversal) and by the sampling arithmetic.  This is the frozen-table
+// idea of the batched MCCFR path (sigma | threshold rows per iteration) applied to Deep CFR.  k_sdcfr_traverse stays: it is the form
+// for batches whose traversals do NOT share a deal (nothing to share then), it pins the tile arithmetic to the reference fixture through
+// the replayed-draws tests, and the two paths are tested against each other row for row.
+namespace {
+// one 16-node tile through the 34-128-64-16 MLP: xbits = the lane's node's feature bits, result = outputs 4 q + r of node lane % 16.
+// The MFMA sequence is k_sdcfr_traverse's (same K order, same accumulator chains): results are bit-identical.
+__device__ __forceinline__ void sd_mlp_tile(const float *Wn, int lane, uint32_t xbits, float (&adv)[4]) {
+    const int q = lane >> 4;
+    const float4 *w1 = reinterpret_cast<const float4 *>(Wn + kImgW1) + lane, *c1 = reinterpret_cast<const float4 *>(Wn + kImgC1) + q;
+    const float4 *w2 = reinterpret_cast<const float4 *>(Wn + kImgW2) + lane, *b2 = reinterpret_cast<const float4 *>(Wn + kImgB2) + q;
+    const float4 *w3 = reinterpret_cast<const float4 *>(Wn + kImgW3) + lane, *b3 = reinterpret_cast<const float4 *>(Wn + kImgB3) + q;
+    v4f h1[8];
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++) h1[mt] = to_v4f(c1[mt * 4]);
+    const uint32_t xs = xbits >> q;
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        float4 w[8];
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) w[mt] = w1[(mt * 2 + g) * 64];
+        const float x0 = (float)((xs >> (16 * g)) & 1u), x1 = (float)((xs >> (16 * g + 4)) & 1u);
+        const float x2 = (float)((xs >> (16 * g + 8)) & 1u), x3 = (float)((xs >> (16 * g + 12)) & 1u);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].x, x0, h1[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].y, x1, h1[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].z, x2, h1[mt]);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].w, x3, h1[mt]);
+    }
+    v4f h2[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) h2[nt] = to_v4f(b2[nt * 4]);
+#pragma unroll
+    for (int mt = 0; mt < 8; mt++) {
+        float4 w[4];
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) w[nt] = w2[(nt * 8 + mt) * 64];
+        const float a0 = relu(h1[mt][0]), a1 = relu(h1[mt][1]), a2 = relu(h1[mt][2]), a3 = relu(h1[mt][3]);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].x, a0, h2[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].y, a1, h2[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].z, a2, h2[nt]);
+#pragma unroll
+        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].w, a3, h2[nt]);
+    }
+    float4 w3r[4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++) w3r[nt] = w3[nt * 64];
+    v4f o0 = to_v4f(b3[0]), o1 = {0.0f, 0.0f, 0.0f, 0.0f};
+    float g[4][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; nt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) g[nt][r] = relu(h2[nt][r]);
+    o0 = mfma16(w3r[0].x, g[0][0], o0); o1 = mfma16(w3r[1].x, g[1][0], o1);
+    o0 = mfma16(w3r[0].y, g[0][1], o0); o1 = mfma16(w3r[1].y, g[1][1], o1);
+    o0 = mfma16(w3r[0].z, g[0][2], o0); o1 = mfma16(w3r[1].z, g[1][2], o1);
+    o0 = mfma16(w3r[0].w, g[0][3], o0); o1 = mfma16(w3r[1].w, g[1][3], o1);
+    o0 = mfma16(w3r[2].x, g[2][0], o0); o1 = mfma16(w3r[3].x, g[3][0], o1);
+    o0 = mfma16(w3r[2].y, g[2][1], o0); o1 = mfma16(w3r[3].y, g[3][1], o1);
+    o0 = mfma16(w3r[2].z, g[2][2], o0); o1 = mfma16(w3r[3].z, g[3][2], o1);
+    o0 = mfma16(w3r[2].w, g[2][3], o0); o1 = mfma16(w3r[3].w, g[3][3], o1);
+#pragma unroll
+    for (int r = 0; r < 4; r++) adv[r] = o0[r] + o1[r];
+}
+__host__ __device__ constexpr int sd_level_off(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 21 : d == 4 ? 69 : d == 5 ? 213 : d == 6 ? 501 : 1077; }   // level_offset as selects (no table load)
+constexpr int kPolicyTiles = 1 + 1 + 1 + 3 + 9 + 18 + 36 + 36;   // 16-node tiles per ply: widths 1, 4, 16, 48, 144, 288, 576, 576
+constexpr int kPolicyWaves = 8;
+}  // namespace
+
+// regret-matching policy (legal actions in hand order, zeros beyond) of EVERY decision node of the deal under the current nets
+__global__ void __launch_bounds__(kPolicyWaves * 64)
+k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_image, float4 *__restrict__ g_pol) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    float *s_w = reinterpret_cast<float *>(smem);                           // [2][kImgFloats]
+    SdPos *s_pos = reinterpret_cast<SdPos *>(s_w + 2 * kImgFloats);         // [wavefronts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < 2 * kImgFloats / 4; i += blockDim.x)
+        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image)[i];
+    __syncthreads();
+    int tile = (int)blockIdx.x * kPolicyWaves + wave;
+    if (tile >= kPolicyTiles) return;
+    int d = 0;
+#pragma unroll
+    for (int k = 0; k < 7; k++) {                                           // which ply the tile belongs to
+        const int tiles_k = (level_width(k) + 15) / 16;
+        if (d == k && tile >= tiles_k) { tile -= tiles_k; d = k + 1; }
+    }
+    const int wd = d == 0 ? 1 : d == 1 ? 4 : d == 2 ? 16 : d == 3 ? 48 : d == 4 ? 144 : d == 5 ? 288 : 576, nl = 4 - (d >> 1);
+    const int nj = lane & 15, q = lane >> 4, j = tile * 16 + nj;
+    const bool live = j < wd;
+    const uint2 inf = g_ninfo[sd_level_off(d) + (live ? j : wd - 1)];
+    const uint32_t xbits = inf.x, hand = inf.y;
+    float adv[4];
+    sd_mlp_tile(s_w + (d & 1) * kImgFloats, lane, xbits, adv);
+    float (*wpos)[16] = s_pos[wave].pos;
+    float z = 0.0f;
+    {
+        float4 pv;
+        float *pp = &pv.x;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { pp[r] = (((xbits >> (4 * q + r)) & 1u) && adv[r] > 0.0f) ? adv[r] : 0.0f; z += pp[r]; }
+        *reinterpret_cast<float4 *>(&wpos[nj][4 * q]) = pv;
+        z = sum_row_groups(z);
+    }
+    const float den = z > 1e-8f ? z : 1e-8f;
+    sd_order();
+    const float pk = q < nl ? wpos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;   // lane (q, node): action q of the node, hand order
+    if (live) reinterpret_cast<float *>(g_pol + sd_level_off(d) + j)[q] = pk;
+}
+
+namespace {
+template <int T>
+struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a frontier node addressed by its position f = t * width + j
+    float val[T * 24];            // values of the frontier on the way back up, replaced in place (see SdTeam::val)
+    uint16_t idx[2][T * 24];      // tree index of the frontier nodes of the current / the next ply
+    uint16_t trav_node[T][41];    // tree index (within its ply) of every traverser node, plies m = 0..3 at offsets 0, 1, 5, 17
+    uint32_t xb[T][41];           // feature bits of every traverser node BY MEMORY-ROW RANK: features and masks of the task's rows are written from
+                                  // here in one sweep of consecutive addresses (a lane per row piece, rows in memory order) instead of a lane per row
+    alignas(16) float stage[32][16];   // regrets of 32 traverser nodes on their way to memory: written a lane per row, stored four lanes per row (whole 64-byte rows
+    uint32_t stage_row[32];       // per store instruction, 16 of them, instead of 64 rows x 16 bytes), with the rows' ring positions
+};
+constexpr int kWalkWaves = 16;
+}  // namespace
+
+template <int T>
+__global__ void __launch_bounds__(kWalkWaves * 64)
+k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float4 *__restrict__ g_pol, int traverser, int batch,
+             float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask, uint32_t capacity, uint32_t write_base,
+             float *__restrict__ root_values, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    __shared__ int s_next[1];
+    float4 *s_pol = reinterpret_cast<float4 *>(smem);                        // [kDecision] policy of every decision node
+    uint2 *s_node = reinterpret_cast<uint2 *>(s_pol + kDecision + 1);        // [kSdNodeSlots] feature bits | hand nibbles   (kDecision + 1: keeps 16-byte alignment)
+    int8_t *s_payoff = reinterpret_cast<int8_t *>(s_node + kSdNodeSlots);    // [kTerminal]
+    SdWalk<T> *s_wave = reinterpret_cast<SdWalk<T> *>(s_payoff + kTerminal); // [wavefronts]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (tid == 0) s_next[0] = kWalkWaves;
+    for (int i = tid; i < kDecision; i += blockDim.x) { s_pol[i] = g_pol[i]; s_node[i] = g_ninfo[i]; }
+    for (int i = tid; i < kTerminal / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_payoff)[i] = reinterpret_cast<const uint32_t *>(g_payoff)[i];
+    __syncthreads();
+    SdWalk<T> &ws = s_wave[wave];
+    const int n_tasks = (batch + T - 1) / T;
+    const int per_wg = (n_tasks + (int)gridDim.x - 1) / (int)gridDim.x;
+    const int first = (int)blockIdx.x * per_wg, count = first < n_tasks ? (n_tasks - first < per_wg ? n_tasks - first : per_wg) : 0;
+    for (int c = wave; c < count;) {
+        const int tb0 = (first + c) * T;
+        const int n_live = batch - tb0 < T ? batch - tb0 : T;               // traversals t >= n_live are walked like the others but write nothing
+        uint32_t row0 = write_base + 41u * (uint32_t)tb0;                   // ring row of the task's first memory row (see k_sdcfr_traverse)
+        row0 = row0 >= capacity ? row0 - capacity : row0;
+        if (lane < T) ws.idx[0][lane] = 0;
+        sd_order();
+        int width = 1, cb = 0;
+        // ---- forward --------------------------------------------------------------------------------------------------------------
+#pragma unroll 1
+        for (int d = 0; d < kPlies; d++) {
+            const int p = d & 1, nl = 4 - (d >> 1);
+            const bool trav_ply = p == traverser;
+            if (!trav_ply && nl == 1) continue;                             // forced child, same position, same index within the next ply
+            const int n_nodes = T * width, m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_level_off(d);
+#pragma unroll 1
+            for (int f = lane; f < n_nodes; f += 64) {
+                const uint32_t node = ws.idx[cb][f];
+                const uint2 inf = s_node[off_d + (int)node];
+                const float4 pol = s_pol[off_d + (int)node];
+                const uint32_t xbits = inf.x;
+                int t = 0;
+#pragma unroll
+                for (int k = 1; k < T; k++) t += f >= k * width;
+                const int j = f - t * width;
+                if (trav_ply) {
+                    // recurse on ALL legal actions, hand order (:326-336)
+#pragma unroll
+                    for (int k = 0; k < 4; k++) if (k < nl) ws.idx[cb ^ 1][f * nl + k] = (uint16_t)(node * nl + k);
+                    ws.trav_node[t][moff + j] = (uint16_t)node;
+                    ws.xb[t][sd_rank(m, j)] = xbits;                       // its memory row's features and mask follow in the sweep below
+                } else {
+                    // opponent: sample ONE action (:347-365), k_sdcfr_expand's arithmetic and Philox keying
+                    const float pk[4] = {pol.x, pol.y, pol.z, pol.w};
+                    float sum = pk[0];
+#pragma unroll
+                    for (int k = 1; k < 4; k++) if (k < nl) sum += pk[k];  // action_probs.sum(), float32, left to right
+                    const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)(tb0 + t), iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
+                    const double u = u53(x.x0, x.x1);
+                    int a;
+                    if (sum == 0.0f) { a = (int)(u * (double)nl); a = a < nl - 1 ? a : nl - 1; }   // np.random.choice(legal_actions): uniform
+                    else {                                                                          // p = action_probs / sum: float32 p, float64 cdf
+                        double cs = 0.0, cdf[4];
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const double pq = (double)(pk[k] / sum); cs = k ? cs + pq : pq; cdf[k] = cs; }
+                        double last = cdf[0];
+#pragma unroll
+                        for (int k = 1; k < 4; k++) last = k < nl ? cdf[k] : last;
+                        a = cdf[0] / last <= u ? 1 : 0;                    // #{k < nl - 1 : cdf[k] / last <= u}; nl is wave-uniform
+                        if (nl > 2) a = cdf[1] / last <= u ? 2 : a;
+                        if (nl > 3) a = cdf[2] / last <= u ? 3 : a;
+                    }
+                    ws.idx[cb ^ 1][f] = (uint16_t)(node * nl + a);
+                }
+            }
+            cb ^= 1;
+            if (trav_ply) width *= nl;
+            sd_order();
+        }
+        // ---- the task's memory rows (:339-346), features and masks: 41 n_live rows, consecutive in the ring (up to its wrap) ------------------
+        {
+            const uint32_t *xbv = &ws.xb[0][0];
+            for (int e = lane; e < n_live * 41 * 17; e += 64) {             // features: 17 eight-byte pieces per 136-byte row
+                const int rr = e / 17, i = e - rr * 17;
+                const uint32_t xbits = xbv[rr];
+                uint32_t row = row0 + (uint32_t)rr;
+                row = row >= capacity ? row - capacity : row;
+                reinterpret_cast<float2 *>(mem_feat + (size_t)row * 34)[i] =
+                    i < 16 ? make_float2((float)((xbits >> (2 * i)) & 1u), (float)((xbits >> (2 * i + 1)) & 1u)) : make_float2(1.0f, 0.0f);   // [32] = float(player == current_player), [33] unused
+            }
+            for (int e = lane; e < n_live * 41 * 4; e += 64) {              // masks: 4 sixteen-byte pieces per 64-byte row
+                const int rr = e >> 2, i = e & 3;
+                const uint32_t hb = xbv[rr] >> (4 * i);
+                uint32_t row = row0 + (uint32_t)rr;
+                row = row >= capacity ? row - capacity : row;
+                reinterpret_cast<float4 *>(mem_mask + (size_t)row * 16)[i] = make_float4((float)(hb & 1u), (float)((hb >> 1) & 1u), (float)((hb >> 2) & 1u), (float)((hb >> 3) & 1u));
+            }
+        }
+        // ---- leaves, then backward -------------------------------------------------------------------------------------------------
+        for (int f = lane; f < T * width; f += 64) {
+            const int p0 = s_payoff[ws.idx[cb][f]];
+            ws.val[f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
+        }
+        sd_order();
+#pragma unroll 1
+        for (int d = kPlies - 1; d >= 0; d--) {
+            const int p = d & 1, nl = 4 - (d >> 1);
+            if (p != traverser) continue;                                  // opponent ply: the sampled child's value is returned unchanged (:363-365), same position
+            width /= nl;
+            const int m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_level_off(d);
+#pragma unroll 1
+            for (int f0 = 0; f0 < T * width; f0 += 64) {
+            const int f = f0 + lane;
+            uint32_t rrow = 0xFFFFFFFFu;                                    // this lane's regret row of the round: ring position (none: beyond the frontier / a dead traversal)
+            float4 rq[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            if (f < T * width) {
+                int t = 0;
+#pragma unroll
+                for (int k = 1; k < T; k++) t += f >= k * width;
+                const int j = f - t * width;
+                const int node = ws.trav_node[t][moff + j];
+                const uint32_t hand = s_node[off_d + node].y;
+                const float4 pol = s_pol[off_d + node];
+                const float pl[4] = {pol.x, pol.y, pol.z, pol.w};
+                float value = 0.0f, cfv[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) cfv[cc] = 0.0f;           // counterfactual_values = zeros(16) (:324)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < nl) {
+                        const float av = ws.val[f * nl + k];
+                        value += pl[k] * av;                                 // value += policy[action] * action_value, float32 (:335)
+                        const int c = (int)((hand >> (4 * k)) & 15u);
+#pragma unroll
+                        for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();                            // (every lane of the round has read its children before any writes)
+                ws.val[f] = value;
+                float mx = 0.0f, reg[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) { reg[cc] = cfv[cc] - value; const float a = fabsf(reg[cc]); mx = a > mx ? a : mx; }   // illegal slots = -value
+                const float den = mx + 1e-8f;
+                if (mx > 0.0f) {
+#pragma unroll
+                    for (int cc = 0; cc < 16; cc++) reg[cc] = reg[cc] / den;        // add_experience (:73-74)
+                }
+                uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)sd_rank(m, j);
+                row = row >= capacity ? row - capacity : row;
+                rrow = t < n_live ? row : 0xFFFFFFFFu;
+#pragma unroll
+                for (int i = 0; i < 4; i++) rq[i] = make_float4(reg[4 * i], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]);
+            }
+            // the round's regret rows through the stage, 32 at a time: lane L puts its row down, then four lanes store each row
+#pragma unroll
+            for (int half = 0; half < 2; half++) {
+                if ((lane >> 5) == half) {
+                    ws.stage_row[lane & 31] = rrow;
+#pragma unroll
+                    for (int i = 0; i < 4; i++) reinterpret_cast<float4 *>(&ws.stage[lane & 31][0])[i] = rq[i];
+                }
+                sd_order();
+#pragma unroll
+                for (int it = 0; it < 2; it++) {
+                    const int e = it * 64 + lane, rl = e >> 2, i = e & 3;
+                    const uint32_t row = ws.stage_row[rl];
+                    if (row != 0xFFFFFFFFu) reinterpret_cast<float4 *>(mem_regret + (size_t)row * 16)[i] = reinterpret_cast<const float4 *>(&ws.stage[rl][0])[i];
+                }
+                sd_order();
+            }
+            }
+            sd_order();
+        }
+        if (lane < n_live) root_values[tb0 + lane] = ws.val[lane];
+        sd_order();
+        int got = 0;
+        if (lane == 0) got = atomicAdd(s_next, 1);
+        c = __builtin_amdgcn_readfirstlane(got);
+    }
+}
+
 #ifdef SCOPA_WALK_STAMPS
 extern "C" int scopa_debug_sdcfr_stamps(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
@@ -851,8 +1169,14 @@ int32_t scopa_sdcfr_pack_weights(scopa_ctx *ctx, int32_t player, const float *d_
     return SCOPA_OK;
 }
 
+int32_t scopa_sdcfr_mode(scopa_ctx *ctx, int32_t forward_per_visit) {
+    if (!ctx || forward_per_visit < 0 || forward_per_visit > 1) return SCOPA_EINVAL;
+    ctx->sdcfr_mode = forward_per_visit;
+    return SCOPA_OK;
+}
+
 int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task) {
-    if (!ctx || (traversals_per_task != 0 && traversals_per_task != 2 && traversals_per_task != 4) || wavefronts_per_task < 0 || wavefronts_per_task > 3)
+    if (!ctx || (traversals_per_task != 0 && traversals_per_task != 2 && traversals_per_task != 4 && traversals_per_task != 8) || wavefronts_per_task < 0 || wavefronts_per_task > 3)
         return SCOPA_EINVAL;
     ctx->sdcfr_tile_t = traversals_per_task;
     ctx->sdcfr_team_w = wavefronts_per_task;
@@ -879,9 +1203,43 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         SC_HIP(ctx, hipGetLastError());
         ctx->sdnode_valid = true;
     }
+    if (!d_uniforms && ctx->sdcfr_mode == 0) {
+        // the default: every decision node of the deal evaluated once (k_sdcfr_policy), then the traversals as walks over that table
+        if (!ctx->d_sdpol) SC_HIP(ctx, hipMalloc(&ctx->d_sdpol, sizeof(float4) * kDecision));
+        const size_t lds_p = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kPolicyWaves * sizeof(SdPos);
+        SC_REQUIRE(ctx, lds_p + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (policy kernel)");
+        SC_LDS_ATTR(ctx, scopa::kLdsSdPolicy, k_sdcfr_policy, ctx->lds_limit - 64);
+        hipLaunchKernelGGL(k_sdcfr_policy, dim3((kPolicyTiles + kPolicyWaves - 1) / kPolicyWaves), dim3(kPolicyWaves * 64), lds_p, ctx->stream,
+                           (const uint2 *)ctx->d_sdnode, d_image, (float4 *)ctx->d_sdpol);
+        SC_HIP(ctx, hipGetLastError());
+        // traversals per wavefront: 8 would use the 64 lanes best (frontiers 8 .. 192 wide), but the walk is a chain of LDS round trips and
+        // float64 sampling arithmetic per ply, and more, smaller tasks hide it better: measured 40.7 / 120.9 us (policy + walk) at 4096 /
+        // 32768 traversals with 2 per wavefront, 51.8 / 126.5 with 8
+        int Tw = ctx->sdcfr_tile_t;
+        if (Tw != 2 && Tw != 4 && Tw != 8) Tw = 2;
+        const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < ctx->n_cus ? tasks_w : ctx->n_cus;
+        const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : sizeof(SdWalk<2>);
+        const size_t lds_w = (size_t)(kDecision + 1) * sizeof(float4) + (size_t)kSdNodeSlots * sizeof(uint2) + (size_t)kTerminal + (size_t)kWalkWaves * wave_w;
+        SC_REQUIRE(ctx, lds_w + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (walk kernel)");
+#define SD_WALK(TT, BIT)                                                                                                                          \
+    do {                                                                                                                                          \
+        SC_LDS_ATTR(ctx, BIT, k_sdcfr_walk<TT>, ctx->lds_limit - 64);                                                                             \
+        hipLaunchKernelGGL(k_sdcfr_walk<TT>, dim3(grid_w), dim3(kWalkWaves * 64), lds_w, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, \
+                           (const float4 *)ctx->d_sdpol, (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity,     \
+                           (uint32_t)write_base, d_root_values, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);                  \
+    } while (0)
+        if (Tw == 8) SD_WALK(8, scopa::kLdsSdWalk8);
+        else if (Tw == 4) SD_WALK(4, scopa::kLdsSdWalk4);
+        else SD_WALK(2, scopa::kLdsSdWalk2);
+#undef SD_WALK
+        SC_HIP(ctx, hipGetLastError());
+        ctx->sdcfr_visits += (uint64_t)batch * (traverser == 0 ? 105 : 82);
+        return SCOPA_OK;
+    }
+    // a forward pass per visit (scopa_sdcfr_mode 1, and the replayed draws of the tests).
     // T traversals per task: 4 fills the 16-node tiles best (21 tiles for traverser 0's 324 evaluated nodes; 2: 26 tiles for twice
     // the tasks).  W wavefronts per task: 1 = solo wavefronts, eight per compute unit; 2 / 3 = teams, twelve wavefronts per compute unit.
-    const int T = (ctx->sdcfr_tile_t && !d_uniforms) ? ctx->sdcfr_tile_t : 4;   // (replayed draws: the default shape only)
+    const int T = (ctx->sdcfr_tile_t == 2 && !d_uniforms) ? 2 : 4;                // (replayed draws: the default shape only)
     const int W = (ctx->sdcfr_team_w && !d_uniforms) ? ctx->sdcfr_team_w : 1;   // measured: solo wavefronts 110 / 620 us at 4096 / 32768 traversals, teams of two 121 / 788, of three 117 / 753
     const int n_waves = sd_waves(W), n_teams = n_waves / W;
     const size_t team_bytes = T == 4 ? (W == 1 ? sizeof(SdTeam<4, 1>) : sizeof(SdTeam<4, 2>)) : (W == 1 ? sizeof(SdTeam<2, 1>) : sizeof(SdTeam<2, 2>));

@@ -196,12 +196,15 @@ def test_graphed_training_step_matches_eager(ctx, golden):
         np.testing.assert_allclose(v.cpu().numpy(), g[f"net0_after__{k}"], atol=ATOL, rtol=0)
 
 
+@pytest.mark.parametrize("per_visit", [0, 1])
 @pytest.mark.parametrize("trav", [0, 1])
-def test_fused_traversal_matches_ply_by_ply_path(dcfr, trav):
-    """k_sdcfr_traverse (one launch, MLP in LDS) vs the ply-by-ply path (PyTorch MLP): same Philox draws -> the same
+def test_fused_traversal_matches_ply_by_ply_path(dcfr, trav, per_visit):
+    """The one-call traversal in both its forms -- policy table per launch + walks (k_sdcfr_policy, k_sdcfr_walk; the default) and a
+    forward pass per visit (k_sdcfr_traverse) -- vs the ply-by-ply path (PyTorch MLP): same Philox draws -> the same
     sampled actions, identical features/masks/row order, float32 values within 1e-5."""
     import torch
     d, _ = dcfr
+    d._engine.ctx.sdcfr_mode(per_visit)
     B = 303                       # 75 whole tasks of four traversals and one of three
     v_ref = d._traverse_batch(trav, B, fused=False)
     mem = d.advantage_nets[trav].buffer
@@ -286,12 +289,13 @@ def test_traversal_batch_with_device_draws_vs_oracle(dcfr, oracle, trav):
     t = oracle.Tree(seed=42)
     feat, reg, mask, ovals, visits = t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=3, b0=0, nb=B)
     assert visits == (105, 82)[trav] * B
-    for fused in (True, False):
+    for fused, per_visit in ((True, 0), (True, 1), (False, 0)):
+        d._engine.ctx.sdcfr_mode(per_visit)
         mem = d.advantage_nets[trav].buffer
         base = len(mem)
         vals = d._traverse_batch(trav, B, fused=fused)
         f, r, m = mem.rows(torch.arange(base, base + 41 * B, device="cuda:0"))
-        assert np.array_equal(f.cpu().numpy(), feat) and np.array_equal(m.cpu().numpy(), mask), fused
+        assert np.array_equal(f.cpu().numpy(), feat) and np.array_equal(m.cpu().numpy(), mask), (fused, per_visit)
         np.testing.assert_allclose(r.cpu().numpy(), reg, atol=ATOL, rtol=0)
         np.testing.assert_allclose(vals.cpu().numpy(), ovals, atol=ATOL, rtol=0)
 
@@ -399,8 +403,9 @@ def _solver_with_reference_nets(golden, **kw):
     return d, g
 
 
+@pytest.mark.parametrize("per_visit", [0, 1])
 @pytest.mark.parametrize("trav", [0, 1])
-def test_traversal_at_the_stated_batch_vs_oracle(ctx, golden, oracle, trav):
+def test_traversal_at_the_stated_batch_vs_oracle(ctx, golden, oracle, trav, per_visit):
     """BASELINE configs[3]'s size (B = 4096 traversals per player per iteration) in ONE launch with the product's own
     draws: exact visit count, every row well-formed, and the 41 rows + root value of traversals 0, 1, 2047 and 4095 (first task,
     a middle one, the last lane of the last task) equal to the oracle's restatement of _external_sampling_cfr for those ids."""
@@ -408,6 +413,7 @@ def test_traversal_at_the_stated_batch_vs_oracle(ctx, golden, oracle, trav):
     B = 4096
     d, g = _solver_with_reference_nets(golden, batch=B)      # batch=B sizes the ring: 8 x 41 x B rows (one launch appends 167 936 rows, more than the
     d._iteration = 7                                         # reference's 100 000: a ring that small would only ever hold the tail of one launch)
+    d._engine.ctx.sdcfr_mode(per_visit)
     mem = d.advantage_nets[trav].buffer
     assert mem.capacity == 8 * 41 * B
     v0 = d._engine.ctx.sdcfr_visits()
@@ -429,7 +435,7 @@ def test_traversal_at_the_stated_batch_vs_oracle(ctx, golden, oracle, trav):
         assert abs(float(vals[tb]) - float(ov[0])) < ATOL
 
 
-@pytest.mark.parametrize("fused", [True, False])
+@pytest.mark.parametrize("fused", ["table", "per-visit", False])
 def test_memory_ring_wraps_like_a_deque(ctx, oracle, golden, fused):
     """The advantage memory is a FIFO (deque(maxlen=...), deep_cfr.py:52): two launches of B traversals into a ring of 41 B + 100 rows --
     the second one STRADDLES the end of the ring -- must leave every row at its deque position: the kernel's rows (traversal, DFS
@@ -447,6 +453,8 @@ def test_memory_ring_wraps_like_a_deque(ctx, oracle, golden, fused):
         d.advantage_nets[p].net.load_state_dict({str(k): torch.from_numpy(g[f"net{p}__{k}"]).to("cuda:0") for k in g[f"net{p}_names"]})
     nets, t = _nets_flat(d), oracle.Tree(seed=42)
     trav = 0
+    d._engine.ctx.sdcfr_mode(1 if fused == "per-visit" else 0)
+    fused = bool(fused)
     mem = d.advantage_nets[trav].buffer
     model = collections.deque(maxlen=cap)                     # the reference's memory: (launch, row) tags in append order
     want = {}
@@ -502,11 +510,38 @@ def test_traversal_on_other_deals_vs_oracle(ctx, golden, oracle, seed):
     for trav in (0, 1):
         of, orr, om, ov, vis = t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=0, b0=0, nb=B)
         assert vis == (105, 82)[trav] * B
-        for fused in (True, False):
+        for fused, per_visit in ((True, 0), (True, 1), (False, 0)):
+            d._engine.ctx.sdcfr_mode(per_visit)
             mem = d.advantage_nets[trav].buffer
             base = len(mem)
             vals = d._traverse_batch(trav, B, fused=fused)
             f, r, m = mem.rows(torch.arange(base, base + 41 * B, device="cuda:0"))
-            assert np.array_equal(f.cpu().numpy(), of) and np.array_equal(m.cpu().numpy(), om), (seed, trav, fused)
+            assert np.array_equal(f.cpu().numpy(), of) and np.array_equal(m.cpu().numpy(), om), (seed, trav, fused, per_visit)
             np.testing.assert_allclose(r.cpu().numpy(), orr, atol=ATOL, rtol=0)
             np.testing.assert_allclose(vals.cpu().numpy(), ov, atol=ATOL, rtol=0)
+
+
+def test_walk_and_per_visit_forms_are_bitwise_the_same(dcfr):
+    """k_sdcfr_policy evaluates a node with the tile arithmetic of k_sdcfr_traverse (same MFMA sequence): the two forms of the one-call
+    traversal produce the SAME BITS -- rows, regrets, root values -- at every task shape of the walk kernel (2, 4, 8 traversals per
+    wavefront) and at batches that leave partial tasks."""
+    import torch
+    d, _ = dcfr
+    ctx = d._engine.ctx
+    d._iteration = 2
+    for trav in (0, 1):
+        for B in (1, 5, 67):
+            ref = None
+            for per_visit, T in ((1, 0), (0, 2), (0, 4), (0, 8)):
+                ctx.sdcfr_mode(per_visit)
+                ctx.sdcfr_tuning(T, 0)
+                mem = d.advantage_nets[trav].buffer
+                mem.total = 0
+                vals = d._traverse_batch(trav, B)
+                got = [x.clone() for x in mem.rows(torch.arange(41 * B, device="cuda:0"))] + [vals.clone()]
+                if ref is None:
+                    ref = got
+                else:
+                    assert all(torch.equal(a, b) for a, b in zip(ref, got)), (trav, B, per_visit, T)
+    ctx.sdcfr_mode(0)
+    ctx.sdcfr_tuning(0, 0)

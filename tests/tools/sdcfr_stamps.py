@@ -11,6 +11,7 @@ from scopa_amd.envs import load_game
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 d = DeepCFR(load_game("mini_scopa"), device="cuda:0", batch=B)
+d._engine.ctx.sdcfr_mode(1)   # the stamps live in the forward-per-visit kernel (k_sdcfr_traverse)
 if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):
     d._engine.ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))
 lib = ctypes.CDLL(os.environ["SCOPA_HIP_LIBRARY"])

@@ -11,6 +11,8 @@ N = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 torch.manual_seed(0)
 from scopa_amd.envs import load_game
 solver = DeepCFR(load_game("mini_scopa"), device="cuda:0", batch=B)
+if os.environ.get("SCOPA_SDCFR_MODE"):
+    solver._engine.ctx.sdcfr_mode(int(os.environ["SCOPA_SDCFR_MODE"]))   # 1 = a forward pass per visit (k_sdcfr_traverse), 0 = policy table + walks
 if os.environ.get("SCOPA_SDCFR_T") or os.environ.get("SCOPA_SDCFR_W"):
     solver._engine.ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))   # traversals / wavefronts per task
 for p in (0, 1):
