@@ -910,9 +910,14 @@ constexpr int kPolicyTiles = 1 + 1 + 1 + 3 + 9 + 18 + 36 + 36;   // 16-node tile
 constexpr int kPolicyWaves = 8;
 }  // namespace
 
-// regret-matching policy (legal actions in hand order, zeros beyond) of EVERY decision node of the deal under the current nets
+// regret-matching policy (legal actions in hand order, zeros beyond) of EVERY decision node of the deal under the current nets, and what
+// sampling from it needs.  np.random.choice(legal, p = probs / probs.sum()) (deep_cfr.py:347-365) is index = #{k : cdf_k / cdf_last <= u}
+// with float32 p and a float64 cdf; every u the traversals draw is N * 2^-53 with an integer N < 2^53 (u53 of two Philox words), and
+// x * 2^53 is exact in float64, so  x <= u  <=>  ceil(x * 2^53) <= N: the node's three thresholds are stored as those integers and a
+// visit compares 64-bit integers -- the same answer as the float64 compare, bit for bit, with the float32 / float64 divisions done once per
+// node instead of once per visit.  thr[0] = ~0 marks probs.sum() == 0 (uniform choice: the visit keeps numpy's arithmetic for that case).
 __global__ void __launch_bounds__(kPolicyWaves * 64)
-k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_image, float4 *__restrict__ g_pol) {
+k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_image, float4 *__restrict__ g_pol, unsigned long long *__restrict__ g_thr) {
     extern __shared__ __align__(16) unsigned char smem[];
     float *s_w = reinterpret_cast<float *>(smem);                           // [2][kImgFloats]
     SdPos *s_pos = reinterpret_cast<SdPos *>(s_w + 2 * kImgFloats);         // [wavefronts]
@@ -949,6 +954,31 @@ k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_im
     sd_order();
     const float pk = q < nl ? wpos[nj][(hand >> (4 * q)) & 15u] / den : 0.0f;   // lane (q, node): action q of the node, hand order
     if (live) reinterpret_cast<float *>(g_pol + sd_level_off(d) + j)[q] = pk;
+    // the node's sampling thresholds: its four probabilities meet in lane (0, node) through the tile's pos area (free by now)
+    sd_order();
+    wpos[nj][q] = pk;
+    sd_order();
+    if (q == 0 && live) {
+        const float4 p4 = *reinterpret_cast<const float4 *>(&wpos[nj][0]);
+        const float pv[4] = {p4.x, p4.y, p4.z, p4.w};
+        float sum = pv[0];
+#pragma unroll
+        for (int k = 1; k < 4; k++) if (k < nl) sum += pv[k];              // action_probs.sum(), float32, left to right
+        unsigned long long thr[3] = {1ull << 53, 1ull << 53, 1ull << 53};   // 2^53 > every N: never counted (k >= nl - 1: cdf_k / cdf_last = 1 > u)
+        if (sum == 0.0f) thr[0] = ~0ull;
+        else {
+            double cs = 0.0, cdf[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) { const double pq = (double)(pv[k] / sum); cs = k ? cs + pq : pq; cdf[k] = cs; }   // float32 p, float64 cdf
+            double last = cdf[0];
+#pragma unroll
+            for (int k = 1; k < 4; k++) last = k < nl ? cdf[k] : last;
+#pragma unroll
+            for (int k = 0; k < 3; k++) if (k < nl - 1) thr[k] = (unsigned long long)ceil((cdf[k] / last) * 9007199254740992.0);
+        }
+        unsigned long long *out = g_thr + (size_t)(sd_level_off(d) + j) * 3;
+        out[0] = thr[0]; out[1] = thr[1]; out[2] = thr[2];
+    }
 }
 
 namespace {
@@ -962,23 +992,26 @@ struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a fr
     alignas(16) float stage[32][16];   // regrets of 32 traverser nodes on their way to memory: written a lane per row, stored four lanes per row (whole 64-byte rows
     uint32_t stage_row[32];       // per store instruction, 16 of them, instead of 64 rows x 16 bytes), with the rows' ring positions
 };
-constexpr int kWalkWaves = 16;
+__host__ __device__ constexpr int sd_walk_waves(int T) { return T == 8 ? 12 : 16; }   // wavefronts per workgroup that fit beside the 78 KB of tables
 }  // namespace
 
 template <int T>
-__global__ void __launch_bounds__(kWalkWaves * 64)
-k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float4 *__restrict__ g_pol, int traverser, int batch,
+__global__ void __launch_bounds__(sd_walk_waves(T) * 64)
+k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float4 *__restrict__ g_pol, const unsigned long long *__restrict__ g_thr,
+             int traverser, int batch,
              float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask, uint32_t capacity, uint32_t write_base,
              float *__restrict__ root_values, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_next[1];
     float4 *s_pol = reinterpret_cast<float4 *>(smem);                        // [kDecision] policy of every decision node
     uint2 *s_node = reinterpret_cast<uint2 *>(s_pol + kDecision + 1);        // [kSdNodeSlots] feature bits | hand nibbles   (kDecision + 1: keeps 16-byte alignment)
-    int8_t *s_payoff = reinterpret_cast<int8_t *>(s_node + kSdNodeSlots);    // [kTerminal]
+    unsigned long long *s_thr = reinterpret_cast<unsigned long long *>(s_node + kSdNodeSlots);   // [kSdNodeSlots][3] sampling thresholds (k_sdcfr_policy)
+    int8_t *s_payoff = reinterpret_cast<int8_t *>(s_thr + (size_t)kSdNodeSlots * 3);               // [kTerminal]
     SdWalk<T> *s_wave = reinterpret_cast<SdWalk<T> *>(s_payoff + kTerminal); // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    if (tid == 0) s_next[0] = kWalkWaves;
+    if (tid == 0) s_next[0] = sd_walk_waves(T);
     for (int i = tid; i < kDecision; i += blockDim.x) { s_pol[i] = g_pol[i]; s_node[i] = g_ninfo[i]; }
+    for (int i = tid; i < kDecision * 3; i += blockDim.x) s_thr[i] = g_thr[i];
     for (int i = tid; i < kTerminal / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_payoff)[i] = reinterpret_cast<const uint32_t *>(g_payoff)[i];
     __syncthreads();
     SdWalk<T> &ws = s_wave[wave];
@@ -1004,7 +1037,6 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
             for (int f = lane; f < n_nodes; f += 64) {
                 const uint32_t node = ws.idx[cb][f];
                 const uint2 inf = s_node[off_d + (int)node];
-                const float4 pol = s_pol[off_d + (int)node];
                 const uint32_t xbits = inf.x;
                 int t = 0;
 #pragma unroll
@@ -1017,25 +1049,16 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                     ws.trav_node[t][moff + j] = (uint16_t)node;
                     ws.xb[t][sd_rank(m, j)] = xbits;                       // its memory row's features and mask follow in the sweep below
                 } else {
-                    // opponent: sample ONE action (:347-365), k_sdcfr_expand's arithmetic and Philox keying
-                    const float pk[4] = {pol.x, pol.y, pol.z, pol.w};
-                    float sum = pk[0];
-#pragma unroll
-                    for (int k = 1; k < 4; k++) if (k < nl) sum += pk[k];  // action_probs.sum(), float32, left to right
+                    // opponent: sample ONE action (:347-365): k_sdcfr_expand's Philox keying, its float comparisons as integer ones (k_sdcfr_policy)
+                    const unsigned long long *th = s_thr + (size_t)(off_d + (int)node) * 3;
+                    const unsigned long long t0 = th[0], t1 = th[1], t2 = th[2];
                     const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)(tb0 + t), iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
-                    const double u = u53(x.x0, x.x1);
-                    int a;
-                    if (sum == 0.0f) { a = (int)(u * (double)nl); a = a < nl - 1 ? a : nl - 1; }   // np.random.choice(legal_actions): uniform
-                    else {                                                                          // p = action_probs / sum: float32 p, float64 cdf
-                        double cs = 0.0, cdf[4];
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { const double pq = (double)(pk[k] / sum); cs = k ? cs + pq : pq; cdf[k] = cs; }
-                        double last = cdf[0];
-#pragma unroll
-                        for (int k = 1; k < 4; k++) last = k < nl ? cdf[k] : last;
-                        a = cdf[0] / last <= u ? 1 : 0;                    // #{k < nl - 1 : cdf[k] / last <= u}; nl is wave-uniform
-                        if (nl > 2) a = cdf[1] / last <= u ? 2 : a;
-                        if (nl > 3) a = cdf[2] / last <= u ? 3 : a;
+                    const unsigned long long N = ((unsigned long long)(x.x0 >> 5) << 26) | (unsigned long long)(x.x1 >> 6);   // u = N * 2^-53 (u53)
+                    int a = (int)(t0 <= N) + (int)(t1 <= N) + (int)(t2 <= N);
+                    if (t0 == ~0ull) {                                     // probs.sum() == 0: np.random.choice(legal_actions), uniform, numpy's float64 arithmetic
+                        const double u = u53(x.x0, x.x1);
+                        a = (int)(u * (double)nl);
+                        a = a < nl - 1 ? a : nl - 1;
                     }
                     ws.idx[cb ^ 1][f] = (uint16_t)(node * nl + a);
                 }
@@ -1089,28 +1112,36 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                 const uint32_t hand = s_node[off_d + node].y;
                 const float4 pol = s_pol[off_d + node];
                 const float pl[4] = {pol.x, pol.y, pol.z, pol.w};
-                float value = 0.0f, cfv[16];
-#pragma unroll
-                for (int cc = 0; cc < 16; cc++) cfv[cc] = 0.0f;           // counterfactual_values = zeros(16) (:324)
+                // value = sum policy * action value (float32, hand order, :335); regrets = counterfactual_values - value over all 16 slots, where
+                // counterfactual_values is zero at the illegal slots (:324, :339): a row holds at most nl + 1 DISTINCT numbers -- av_k - value at the
+                // legal cards, 0 - value everywhere else -- so the max-abs normalisation (add_experience :73-74) divides those and not 16 slots
+                float value = 0.0f, av[4];
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
-                    if (k < nl) {
-                        const float av = ws.val[f * nl + k];
-                        value += pl[k] * av;                                 // value += policy[action] * action_value, float32 (:335)
-                        const int c = (int)((hand >> (4 * k)) & 15u);
-#pragma unroll
-                        for (int cc = 0; cc < 16; cc++) if (cc == c) cfv[cc] = av;
-                    }
+                    av[k] = k < nl ? ws.val[f * nl + k] : 0.0f;
+                    if (k < nl) value += pl[k] * av[k];
                 }
                 __builtin_amdgcn_wave_barrier();                            // (every lane of the round has read its children before any writes)
                 ws.val[f] = value;
-                float mx = 0.0f, reg[16];
+                float rv[4], ri = 0.0f - value, mx = fabsf(ri);
 #pragma unroll
-                for (int cc = 0; cc < 16; cc++) { reg[cc] = cfv[cc] - value; const float a = fabsf(reg[cc]); mx = a > mx ? a : mx; }   // illegal slots = -value
-                const float den = mx + 1e-8f;
+                for (int k = 0; k < 4; k++) { rv[k] = av[k] - value; if (k < nl) { const float a = fabsf(rv[k]); mx = a > mx ? a : mx; } }
                 if (mx > 0.0f) {
+                    const float den = mx + 1e-8f;
+                    ri = ri / den;
 #pragma unroll
-                    for (int cc = 0; cc < 16; cc++) reg[cc] = reg[cc] / den;        // add_experience (:73-74)
+                    for (int k = 0; k < 4; k++) if (k < nl) rv[k] = rv[k] / den;
+                }
+                float reg[16];
+#pragma unroll
+                for (int cc = 0; cc < 16; cc++) reg[cc] = ri;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    if (k < nl) {
+                        const int c = (int)((hand >> (4 * k)) & 15u);
+#pragma unroll
+                        for (int cc = 0; cc < 16; cc++) if (cc == c) reg[cc] = rv[k];
+                    }
                 }
                 uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)sd_rank(m, j);
                 row = row >= capacity ? row - capacity : row;
@@ -1205,12 +1236,13 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
     }
     if (!d_uniforms && ctx->sdcfr_mode == 0) {
         // the default: every decision node of the deal evaluated once (k_sdcfr_policy), then the traversals as walks over that table
-        if (!ctx->d_sdpol) SC_HIP(ctx, hipMalloc(&ctx->d_sdpol, sizeof(float4) * kDecision));
+        if (!ctx->d_sdpol) SC_HIP(ctx, hipMalloc(&ctx->d_sdpol, (sizeof(float4) + 3 * sizeof(unsigned long long)) * kDecision));   // policies, then thresholds
+        unsigned long long *d_thr = reinterpret_cast<unsigned long long *>(reinterpret_cast<float4 *>(ctx->d_sdpol) + kDecision);
         const size_t lds_p = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kPolicyWaves * sizeof(SdPos);
         SC_REQUIRE(ctx, lds_p + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (policy kernel)");
         SC_LDS_ATTR(ctx, scopa::kLdsSdPolicy, k_sdcfr_policy, ctx->lds_limit - 64);
         hipLaunchKernelGGL(k_sdcfr_policy, dim3((kPolicyTiles + kPolicyWaves - 1) / kPolicyWaves), dim3(kPolicyWaves * 64), lds_p, ctx->stream,
-                           (const uint2 *)ctx->d_sdnode, d_image, (float4 *)ctx->d_sdpol);
+                           (const uint2 *)ctx->d_sdnode, d_image, (float4 *)ctx->d_sdpol, d_thr);
         SC_HIP(ctx, hipGetLastError());
         // traversals per wavefront: 8 would use the 64 lanes best (frontiers 8 .. 192 wide), but the walk is a chain of LDS round trips and
         // float64 sampling arithmetic per ply, and more, smaller tasks hide it better: measured 40.7 / 120.9 us (policy + walk) at 4096 /
@@ -1219,13 +1251,13 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         if (Tw != 2 && Tw != 4 && Tw != 8) Tw = 2;
         const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < ctx->n_cus ? tasks_w : ctx->n_cus;
         const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : sizeof(SdWalk<2>);
-        const size_t lds_w = (size_t)(kDecision + 1) * sizeof(float4) + (size_t)kSdNodeSlots * sizeof(uint2) + (size_t)kTerminal + (size_t)kWalkWaves * wave_w;
+        const size_t lds_w = (size_t)(kDecision + 1) * sizeof(float4) + (size_t)kSdNodeSlots * (sizeof(uint2) + 3 * sizeof(unsigned long long)) + (size_t)kTerminal + (size_t)sd_walk_waves(Tw) * wave_w;
         SC_REQUIRE(ctx, lds_w + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (walk kernel)");
 #define SD_WALK(TT, BIT)                                                                                                                          \
     do {                                                                                                                                          \
         SC_LDS_ATTR(ctx, BIT, k_sdcfr_walk<TT>, ctx->lds_limit - 64);                                                                             \
-        hipLaunchKernelGGL(k_sdcfr_walk<TT>, dim3(grid_w), dim3(kWalkWaves * 64), lds_w, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, \
-                           (const float4 *)ctx->d_sdpol, (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity,     \
+        hipLaunchKernelGGL(k_sdcfr_walk<TT>, dim3(grid_w), dim3(sd_walk_waves(TT) * 64), lds_w, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, \
+                           (const float4 *)ctx->d_sdpol, (const unsigned long long *)d_thr, (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, \
                            (uint32_t)write_base, d_root_values, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);                  \
     } while (0)
         if (Tw == 8) SD_WALK(8, scopa::kLdsSdWalk8);

@@ -84,29 +84,40 @@ json.dump({"kernel": "k_mccfr_traverse", "commit": commit, "source_sha256": sour
 print(open(f"{P}/traverse_sq.json").read())
 
 
-# 4. SDCFR traversal kernel (tests/tools/profile_sdcfr.sh, run per batch; its outputs moved to gpurun_out/prof_sdcfr_b<batch>)
+# 4. SDCFR traversal kernels (tests/tools/profile_sdcfr.sh, run per batch; its outputs moved to gpurun_out/prof_sdcfr_b<batch>)
 sd_sha = source_fingerprint("scopa_sdcfr.hip")
 sd_commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_sdcfr.hip"], capture_output=True, text=True).stdout.strip()
+
+
+def sd_counters(path, kernel):
+    acc = collections.defaultdict(list)
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Kernel_Name"]:
+            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
+    return {c: st.mean(v) for c, v in acc.items()}, (min(len(v) for v in acc.values()) if acc else 0)
+
+
+def sd_stats(path, kernel):
+    for r in csv.DictReader(open(path)):
+        if kernel in r["Name"]:
+            return float(r["AverageNs"]) / 1e3, int(r["Calls"])
+    return None, 0
+
+
 for batch in (4096, 32768):
     d = os.path.join(os.path.dirname(src), f"prof_sdcfr_b{batch}")
     if not os.path.isdir(d):
         continue
-    m, kern_us = {}, {}
+    # ---- 4a. the forward-per-visit kernel ----
+    m, n_disp = {}, 0
     for part in ("a", "b", "c"):
-        rows = list(csv.DictReader(open(f"{d}/{part}/sdcfr_counters.csv")))
-        acc = collections.defaultdict(list)
-        for r in rows:
-            acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-        for c, v in acc.items():
-            m[c] = st.mean(v)
-        kern_us[part] = json.loads(open(f"{d}/{part}.json").read().strip().splitlines()[-1])["traversal_only"]["kernel_avg_us"]
-    n_disp = len(rows) // max(len(acc), 1)
+        mm, n_disp = sd_counters(f"{d}/visit/{part}/sdcfr_counters.csv", "k_sdcfr_traverse")
+        m.update(mm)
     waves_working = min(batch // 4, 12 * 256)                            # tasks of 4 traversals; 12 wavefronts x 256 compute units at most
-    plain = json.loads(open(f"{d}/stats.json").read().strip().splitlines()[-1])
-    t_us = plain["traversal_only"]["kernel_avg_us"]                      # under --kernel-trace --stats only (counter passes run slower: lower clocks)
+    t_us, calls = sd_stats(glob.glob(f"{d}/visit/stats/*kernel_stats.csv")[0], "k_sdcfr_traverse")
     cyc = 4.0 * m["SQ_WAVE_CYCLES"] / waves_working
     derived = {
-        "kernel_avg_us_under_kernel_trace": t_us, "kernel_avg_us_in_counter_passes": kern_us,
+        "kernel_avg_us_under_kernel_trace": t_us, "calls_under_kernel_trace": calls,
         "mfma_busy_cycles_per_simd": m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0, "mfma_flop_per_launch": 512.0 * m["SQ_INSTS_VALU_MFMA_MOPS_F32"],
         "cycles_per_working_wave": cyc, "mfma_pipe_busy_share_of_a_working_wave_s_lifetime": (m["SQ_VALU_MFMA_BUSY_CYCLES"] / 1024.0) / cyc,   # a SIMD's matrix pipe against the lifetime of the wavefront(s) it hosts
         "wave_time_issuing": m["SQ_ACTIVE_INST_ANY"] / m["SQ_WAVE_CYCLES"], "wave_time_waiting_to_issue": m["SQ_WAIT_INST_ANY"] / m["SQ_WAVE_CYCLES"],
@@ -117,29 +128,51 @@ for batch in (4096, 32768):
         "vmem_reads_per_working_wave": m["SQ_INSTS_VMEM_RD"] / waves_working, "vmem_writes_per_working_wave": m["SQ_INSTS_VMEM_WR"] / waves_working,
         "working_waves": waves_working,
     }
-    json.dump({"kernel": "k_sdcfr_traverse", "commit": sd_commit, "source_sha256": sd_sha,
-               "workload": f"bench.py --workload sdcfr --batch {batch} ({batch} traversals per launch, launches of both traversers averaged)",
+    json.dump({"kernel": "k_sdcfr_traverse (a forward pass per visit, scopa_sdcfr_mode 1)", "commit": sd_commit, "source_sha256": sd_sha,
+               "workload": f"SCOPA_SDCFR_MODE=1 bench.py --workload sdcfr --batch {batch} ({batch} traversals per launch, launches of both traversers averaged)",
                "dispatches": n_disp,
                "source": "rocprofv3 --kernel-trace --pmc SQ_*, three passes of 8 counters (tests/tools/profile_sdcfr.sh); SQ_WAVE_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* are in "
                          "quad-cycles, SQ_LDS_IDX_ACTIVE and SQ_VALU_MFMA_BUSY_CYCLES in cycles (MI355X_MICROARCH.md)",
                "per_launch_mean": m, "derived": derived}, open(f"{P}/{tag}_pmc_sq_sdcfr_traverse_b{batch}.json", "w"), indent=1)
-    # HBM traffic per launch (PMC passes of their own), the guide's gfx950 correction: FETCH_SIZE x 2 for wide coalesced reads (the
-    # kernel's reads are its 16-byte-per-lane prologue copies), WRITE_SIZE as it is (8- / 16-byte memory-row stores: uncalibrated width,
-    # compare with the algorithmic 41 x 264 B per traversal)
-    if os.path.isdir(f"{d}/pmc_FETCH_SIZE"):
-        hb = {}
-        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
-            vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f"{d}/pmc_{ctr}/sdcfr_counters.csv")) if r["Counter_Name"] == ctr]
-            hb[ctr] = st.mean(vals)
-        rows_bytes = 41 * 264 * batch
-        json.dump({"kernel": "k_sdcfr_traverse", "batch": batch, "commit": sd_commit, "source_sha256": sd_sha,
-                   "source": f"rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tests/tools/profile_sdcfr.sh), {len(vals)} dispatches each",
-                   "FETCH_SIZE_KB_raw": hb["FETCH_SIZE"], "WRITE_SIZE_KB": hb["WRITE_SIZE"],
-                   "bytes_per_launch": (2 * hb["FETCH_SIZE"] + hb["WRITE_SIZE"]) * 1e3, "bytes_per_launch_uncorrected": (hb["FETCH_SIZE"] + hb["WRITE_SIZE"]) * 1e3,
-                   "memory_rows_bytes_per_launch": rows_bytes,
-                   "note": "the launch's necessary HBM traffic is its memory rows (41 rows x 264 B per traversal); nets, node table and frontier are LDS-resident, "
-                           "the 122 KB prologue copy per workgroup is served by L2 after its first touch per XCD"},
-                  open(f"{P}/sdcfr_hbm_traffic_b{batch}.json", "w"), indent=1)
-    open(f"{P}/{tag}_sdcfr_kernel_stats_b{batch}.csv", "w").write(open(glob.glob(f"{d}/stats/*kernel_stats.csv")[0]).read())
-    open(f"{P}/{tag}_bench_sdcfr_b{batch}_under_rocprof_stats.json", "w").write(json.dumps(plain) + "\n")
-    print(batch, json.dumps(derived, indent=1))
+    open(f"{P}/{tag}_sdcfr_kernel_stats_forward_per_visit_b{batch}.csv", "w").write(open(glob.glob(f"{d}/visit/stats/*kernel_stats.csv")[0]).read())
+    print(batch, "per visit", json.dumps(derived, indent=1))
+    # ---- 4b. the default form: k_sdcfr_policy + k_sdcfr_walk ----
+    w, n_w = {}, 0
+    for part in ("a", "b"):
+        mm, n_w = sd_counters(f"{d}/table/{part}/sdcfr_counters.csv", "k_sdcfr_walk")
+        w.update(mm)
+    pol = {}
+    for part in ("a", "b"):
+        pol.update(sd_counters(f"{d}/table/{part}/sdcfr_counters.csv", "k_sdcfr_policy")[0])
+    stats_csv = glob.glob(f"{d}/table/stats/*kernel_stats.csv")[0]
+    walk_us, walk_calls = sd_stats(stats_csv, "k_sdcfr_walk")
+    pol_us, _ = sd_stats(stats_csv, "k_sdcfr_policy")
+    hb = {}
+    for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+        for k in ("k_sdcfr_walk", "k_sdcfr_policy"):
+            hb[(ctr, k)] = sd_counters(f"{d}/table/pmc_{ctr}/sdcfr_counters.csv", k)[0].get(ctr, 0.0)
+    rows_bytes = 41 * 264 * batch
+    line = json.loads(open(f"{d}/table/stats.json").read().strip().splitlines()[-1])
+    wd = {"walk_avg_us_under_kernel_trace": walk_us, "policy_avg_us_under_kernel_trace": pol_us, "calls": walk_calls,
+          "walk_valu_instr_per_traversal": w["SQ_INSTS_VALU"] / batch, "walk_lds_instr_per_traversal": w["SQ_INSTS_LDS"] / batch,
+          "walk_wave_time_issuing": w["SQ_ACTIVE_INST_ANY"] / w["SQ_WAVE_CYCLES"], "walk_wave_time_waiting_to_issue": w["SQ_WAIT_INST_ANY"] / w["SQ_WAVE_CYCLES"],
+          "walk_wave_time_waiting_on_counters_or_barriers": w["SQ_WAIT_ANY"] / w["SQ_WAVE_CYCLES"],
+          "walk_valu_busy_share_of_simd_time": 4.0 * w["SQ_ACTIVE_INST_VALU"] / 1024.0 / (walk_us * 1e-6 * 2.4e9) if walk_us else None,
+          "walk_lds_array_busy_share": w["SQ_LDS_IDX_ACTIVE"] / 256.0 / (walk_us * 1e-6 * 2.4e9) if walk_us else None,
+          "policy_mfma_flop_per_launch": 512.0 * pol.get("SQ_INSTS_VALU_MFMA_MOPS_F32", 0.0)}
+    json.dump({"kernels": "k_sdcfr_policy + k_sdcfr_walk (the default form of scopa_sdcfr_traverse_fused)", "commit": sd_commit, "source_sha256": sd_sha,
+               "workload": f"bench.py --workload sdcfr --batch {batch}", "dispatches": n_w,
+               "per_launch_mean_walk": w, "per_launch_mean_policy": pol, "derived": wd}, open(f"{P}/{tag}_pmc_sq_sdcfr_walk_b{batch}.json", "w"), indent=1)
+    fw, ww = hb[("FETCH_SIZE", "k_sdcfr_walk")], hb[("WRITE_SIZE", "k_sdcfr_walk")]
+    fp, wp = hb[("FETCH_SIZE", "k_sdcfr_policy")], hb[("WRITE_SIZE", "k_sdcfr_policy")]
+    json.dump({"kernels": "k_sdcfr_policy + k_sdcfr_walk", "batch": batch, "commit": sd_commit, "source_sha256": sd_sha,
+               "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tests/tools/profile_sdcfr.sh)",
+               "walk_FETCH_SIZE_KB_raw": fw, "walk_WRITE_SIZE_KB": ww, "policy_FETCH_SIZE_KB_raw": fp, "policy_WRITE_SIZE_KB": wp,
+               "bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1e3, "bytes_per_launch_uncorrected": (fw + fp + ww + wp) * 1e3,
+               "memory_rows_bytes_per_launch": rows_bytes,
+               "note": "per player's traversal call (both launches).  The necessary HBM traffic is the memory rows (41 rows x 264 B per traversal); policy table, node table and "
+                       "frontier are LDS-resident; FETCH_SIZE doubled per the guide's gfx950 correction for wide coalesced reads"},
+              open(f"{P}/sdcfr_hbm_traffic_b{batch}.json", "w"), indent=1)
+    open(f"{P}/{tag}_sdcfr_kernel_stats_b{batch}.csv", "w").write(open(stats_csv).read())
+    open(f"{P}/{tag}_bench_sdcfr_b{batch}_under_rocprof_stats.json", "w").write(json.dumps(line) + "\n")
+    print(batch, "table", json.dumps(wd, indent=1), json.dumps({"bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1e3, "rows": rows_bytes}))
