@@ -908,6 +908,8 @@ __device__ __forceinline__ void sd_mlp_tile(const float *Wn, int lane, uint32_t 
 __host__ __device__ constexpr int sd_level_off(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 21 : d == 4 ? 69 : d == 5 ? 213 : d == 6 ? 501 : 1077; }   // level_offset as selects (no table load)
 constexpr int kPolicyTiles = 1 + 1 + 1 + 3 + 9 + 18 + 36 + 36;   // 16-node tiles per ply: widths 1, 4, 16, 48, 144, 288, 576, 576
 constexpr int kPolicyWaves = 8;
+constexpr int kPolicyBlocks0 = (47 + kPolicyWaves - 1) / kPolicyWaves, kPolicyBlocks1 = (58 + kPolicyWaves - 1) / kPolicyWaves;
+static_assert(kPolicyTiles == 47 + 58, "tiles by player");
 }  // namespace
 
 // regret-matching policy (legal actions in hand order, zeros beyond) of EVERY decision node of the deal under the current nets, and what
@@ -919,19 +921,21 @@ constexpr int kPolicyWaves = 8;
 __global__ void __launch_bounds__(kPolicyWaves * 64)
 k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_image, float4 *__restrict__ g_pol, unsigned long long *__restrict__ g_thr) {
     extern __shared__ __align__(16) unsigned char smem[];
-    float *s_w = reinterpret_cast<float *>(smem);                           // [2][kImgFloats]
-    SdPos *s_pos = reinterpret_cast<SdPos *>(s_w + 2 * kImgFloats);         // [wavefronts]
+    float *s_w = reinterpret_cast<float *>(smem);                           // [kImgFloats]: ONE net -- a workgroup's tiles belong to one player's plies
+    SdPos *s_pos = reinterpret_cast<SdPos *>(s_w + kImgFloats);             // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < 2 * kImgFloats / 4; i += blockDim.x)
-        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image)[i];
+    // workgroups 0 .. kPolicyBlocks0 - 1 take the 47 tiles of player 0's plies (0, 2, 4, 6: 1 + 1 + 9 + 36), the rest the 58 of player 1's (1, 3, 5, 7: 1 + 3 + 18 + 36)
+    const int p = (int)blockIdx.x >= kPolicyBlocks0 ? 1 : 0;
+    for (int i = tid; i < kImgFloats / 4; i += blockDim.x)
+        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image + p * kImgFloats)[i];
     __syncthreads();
-    int tile = (int)blockIdx.x * kPolicyWaves + wave;
-    if (tile >= kPolicyTiles) return;
-    int d = 0;
+    int tile = ((int)blockIdx.x - (p ? kPolicyBlocks0 : 0)) * kPolicyWaves + wave;
+    if (tile >= (p ? 58 : 47)) return;
+    int d = p;
 #pragma unroll
-    for (int k = 0; k < 7; k++) {                                           // which ply the tile belongs to
-        const int tiles_k = (level_width(k) + 15) / 16;
-        if (d == k && tile >= tiles_k) { tile -= tiles_k; d = k + 1; }
+    for (int k = 0; k < 3; k++) {                                           // which of the player's plies the tile belongs to
+        const int tiles_k = (level_width(2 * k + p) + 15) / 16;
+        if (d == 2 * k + p && tile >= tiles_k) { tile -= tiles_k; d += 2; }
     }
     const int wd = d == 0 ? 1 : d == 1 ? 4 : d == 2 ? 16 : d == 3 ? 48 : d == 4 ? 144 : d == 5 ? 288 : 576, nl = 4 - (d >> 1);
     const int nj = lane & 15, q = lane >> 4, j = tile * 16 + nj;
@@ -939,7 +943,7 @@ k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_im
     const uint2 inf = g_ninfo[sd_level_off(d) + (live ? j : wd - 1)];
     const uint32_t xbits = inf.x, hand = inf.y;
     float adv[4];
-    sd_mlp_tile(s_w + (d & 1) * kImgFloats, lane, xbits, adv);
+    sd_mlp_tile(s_w, lane, xbits, adv);
     float (*wpos)[16] = s_pos[wave].pos;
     float z = 0.0f;
     {
@@ -1238,10 +1242,10 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         // the default: every decision node of the deal evaluated once (k_sdcfr_policy), then the traversals as walks over that table
         if (!ctx->d_sdpol) SC_HIP(ctx, hipMalloc(&ctx->d_sdpol, (sizeof(float4) + 3 * sizeof(unsigned long long)) * kDecision));   // policies, then thresholds
         unsigned long long *d_thr = reinterpret_cast<unsigned long long *>(reinterpret_cast<float4 *>(ctx->d_sdpol) + kDecision);
-        const size_t lds_p = (size_t)2 * kImgFloats * sizeof(float) + (size_t)kPolicyWaves * sizeof(SdPos);
+        const size_t lds_p = (size_t)kImgFloats * sizeof(float) + (size_t)kPolicyWaves * sizeof(SdPos);
         SC_REQUIRE(ctx, lds_p + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (policy kernel)");
         SC_LDS_ATTR(ctx, scopa::kLdsSdPolicy, k_sdcfr_policy, ctx->lds_limit - 64);
-        hipLaunchKernelGGL(k_sdcfr_policy, dim3((kPolicyTiles + kPolicyWaves - 1) / kPolicyWaves), dim3(kPolicyWaves * 64), lds_p, ctx->stream,
+        hipLaunchKernelGGL(k_sdcfr_policy, dim3(kPolicyBlocks0 + kPolicyBlocks1), dim3(kPolicyWaves * 64), lds_p, ctx->stream,
                            (const uint2 *)ctx->d_sdnode, d_image, (float4 *)ctx->d_sdpol, d_thr);
         SC_HIP(ctx, hipGetLastError());
         // traversals per wavefront: 8 would use the 64 lanes best (frontiers 8 .. 192 wide), but the walk is a chain of LDS round trips and
