@@ -1,4 +1,8 @@
-// scopa_sdcfr.hip -- external-sampling traversal for Single Deep CFR, level-synchronous over the 8 plies.
+// scopa_sdcfr.hip -- external-sampling traversal for Single Deep CFR, level-synchronous over the 8 plies.  Three forms, same rows:
+//   (1) ply by ply around a PyTorch forward (k_sdcfr_features / _expand / _terminal / _backward, first part of this file);
+//   (2) one launch with a forward pass per visit on the matrix cores (k_sdcfr_traverse);
+//   (3) the default: every decision node of the deal evaluated once per launch (k_sdcfr_policy), the traversals as walks over that
+//       policy table (k_sdcfr_walk) -- the nets are frozen during a launch and a node's features depend on the tree node alone.
 //
 // Reference behaviour: DeepCFR._external_sampling_cfr / ._state_to_features / ._get_legal_actions_mask
 // (src/algorithms/deep_cfr/deep_cfr.py:213-365), AdvantageNetwork.add_experience (:70-75),
