@@ -217,7 +217,7 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
  * per visit inside the traversal kernel (one launch; the form for batches that would not share a deal; also what d_uniforms takes).
  * Same rows, same values, same sampled actions either way. */
 int32_t scopa_sdcfr_mode(scopa_ctx *ctx, int32_t forward_per_visit);
-/* experiments: traversals per task of the traversal kernels (0 = the library's choice; 2, 4 or 8 for the walk kernel, 2 or 4 for
+/* experiments: traversals per task of the traversal kernels (0 = the library's choice; 1, 2, 4 or 8 for the walk kernel, 2 or 4 for
  * the forward-per-visit kernel) and wavefronts that share a task's tiles in the latter (0 = the library's choice, 1..3).  Results
  * do not depend on either. */
 int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task);

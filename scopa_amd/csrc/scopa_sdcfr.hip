@@ -1215,7 +1215,7 @@ int32_t scopa_sdcfr_mode(scopa_ctx *ctx, int32_t forward_per_visit) {
 }
 
 int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task) {
-    if (!ctx || (traversals_per_task != 0 && traversals_per_task != 2 && traversals_per_task != 4 && traversals_per_task != 8) || wavefronts_per_task < 0 || wavefronts_per_task > 3)
+    if (!ctx || (traversals_per_task != 0 && traversals_per_task != 1 && traversals_per_task != 2 && traversals_per_task != 4 && traversals_per_task != 8) || wavefronts_per_task < 0 || wavefronts_per_task > 3)
         return SCOPA_EINVAL;
     ctx->sdcfr_tile_t = traversals_per_task;
     ctx->sdcfr_team_w = wavefronts_per_task;
@@ -1256,9 +1256,9 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         // float64 sampling arithmetic per ply, and more, smaller tasks hide it better: measured 40.7 / 120.9 us (policy + walk) at 4096 /
         // 32768 traversals with 2 per wavefront, 51.8 / 126.5 with 8
         int Tw = ctx->sdcfr_tile_t;
-        if (Tw != 2 && Tw != 4 && Tw != 8) Tw = 2;
+        if (Tw != 1 && Tw != 2 && Tw != 4 && Tw != 8) Tw = 2;
         const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < ctx->n_cus ? tasks_w : ctx->n_cus;
-        const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : sizeof(SdWalk<2>);
+        const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : Tw == 2 ? sizeof(SdWalk<2>) : sizeof(SdWalk<1>);
         const size_t lds_w = (size_t)(kDecision + 1) * sizeof(float4) + (size_t)kSdNodeSlots * (sizeof(uint2) + 3 * sizeof(unsigned long long)) + (size_t)kTerminal + (size_t)sd_walk_waves(Tw) * wave_w;
         SC_REQUIRE(ctx, lds_w + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (walk kernel)");
 #define SD_WALK(TT, BIT)                                                                                                                          \
@@ -1270,7 +1270,8 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
     } while (0)
         if (Tw == 8) SD_WALK(8, scopa::kLdsSdWalk8);
         else if (Tw == 4) SD_WALK(4, scopa::kLdsSdWalk4);
-        else SD_WALK(2, scopa::kLdsSdWalk2);
+        else if (Tw == 2) SD_WALK(2, scopa::kLdsSdWalk2);
+        else SD_WALK(1, scopa::kLdsSdWalk1);
 #undef SD_WALK
         SC_HIP(ctx, hipGetLastError());
         ctx->sdcfr_visits += (uint64_t)batch * (traverser == 0 ? 105 : 82);

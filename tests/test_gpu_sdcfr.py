@@ -523,7 +523,7 @@ def test_traversal_on_other_deals_vs_oracle(ctx, golden, oracle, seed):
 
 def test_walk_and_per_visit_forms_are_bitwise_the_same(dcfr):
     """k_sdcfr_policy evaluates a node with the tile arithmetic of k_sdcfr_traverse (same MFMA sequence): the two forms of the one-call
-    traversal produce the SAME BITS -- rows, regrets, root values -- at every task shape of the walk kernel (2, 4, 8 traversals per
+    traversal produce the SAME BITS -- rows, regrets, root values -- at every task shape of the walk kernel (1, 2, 4, 8 traversals per
     wavefront) and at batches that leave partial tasks."""
     import torch
     d, _ = dcfr
@@ -532,7 +532,7 @@ def test_walk_and_per_visit_forms_are_bitwise_the_same(dcfr):
     for trav in (0, 1):
         for B in (1, 5, 67):
             ref = None
-            for per_visit, T in ((1, 0), (0, 2), (0, 4), (0, 8)):
+            for per_visit, T in ((1, 0), (0, 1), (0, 2), (0, 4), (0, 8)):
                 ctx.sdcfr_mode(per_visit)
                 ctx.sdcfr_tuning(T, 0)
                 mem = d.advantage_nets[trav].buffer
