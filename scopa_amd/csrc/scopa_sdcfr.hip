@@ -990,6 +990,18 @@ k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_im
 }
 
 namespace {
+// What a walk keeps in LDS is per TRAVERSER: policies and node words of the traverser's plies only (the walk recurses there and needs the policy on the way
+// back), sampling thresholds of the opponent's three sampled plies only, nl - 1 of them per node -- 22-24 KB instead of the 80 KB of every node's
+// everything, so that TWO workgroups of sixteen wavefronts fit a compute unit (the walk is a chain of LDS round trips: eight wavefronts per SIMD hide what four did not)
+constexpr int kWalkTravNodes = 916;        // traverser 1's plies 1, 3, 5, 7: 4 + 48 + 288 + 576  (traverser 0's plies 0, 2, 4, 6: 1 + 16 + 144 + 576 = 737)
+constexpr int kWalkThr = 396;              // traverser 0's opponent plies 1, 3, 5: 4 x 3 + 48 x 2 + 288 x 1  (traverser 1's plies 0, 2, 4: 1 x 3 + 16 x 2 + 144 x 1 = 179)
+__host__ __device__ constexpr int sd_trav_off(int traverser, int m) {   // the traverser's ply m = 0..3 within its compact tables
+    return traverser == 0 ? (m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 17 : 161) : (m == 0 ? 0 : m == 1 ? 4 : m == 2 ? 52 : 340);
+}
+__host__ __device__ constexpr int sd_thr_off(int traverser, int k) {    // the opponent's sampled ply k = 0..2 (nl = 4, 3, 2: three, two, one thresholds per node)
+    return traverser == 0 ? (k == 0 ? 0 : k == 1 ? 12 : 108) : (k == 0 ? 0 : k == 1 ? 3 : 35);
+}
+static_assert(sd_trav_off(0, 3) + 576 == 737 && sd_trav_off(1, 3) + 576 == kWalkTravNodes && sd_thr_off(0, 2) + 288 == kWalkThr && sd_thr_off(1, 2) + 144 == 179, "compact tables");
 template <int T>
 struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a frontier node addressed by its position f = t * width + j
     float val[T * 24];            // values of the frontier on the way back up, replaced in place (see SdTeam::val)
@@ -997,29 +1009,49 @@ struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a fr
     uint16_t trav_node[T][41];    // tree index (within its ply) of every traverser node, plies m = 0..3 at offsets 0, 1, 5, 17
     uint32_t xb[T][41];           // feature bits of every traverser node BY MEMORY-ROW RANK: features and masks of the task's rows are written from
                                   // here in one sweep of consecutive addresses (a lane per row piece, rows in memory order) instead of a lane per row
-    alignas(16) float stage[32][16];   // regrets of 32 traverser nodes on their way to memory: written a lane per row, stored four lanes per row (whole 64-byte rows
-    uint32_t stage_row[32];       // per store instruction, 16 of them, instead of 64 rows x 16 bytes), with the rows' ring positions
+    union alignas(16) {
+        struct {
+            float stage[32][16];      // regrets of 32 traverser nodes on their way to memory: written a lane per row, stored four lanes per row (whole 64-byte rows
+            uint32_t stage_row[32];   // per store instruction, 16 of them, instead of 64 rows x 16 bytes), with the rows' ring positions
+        };
+        unsigned long long draw[T * 40];   // forward pass only: the task's opponent draws N (u = N * 2^-53), all of them taken before the walk in full 64-lane rounds
+    };
 };
-__host__ __device__ constexpr int sd_walk_waves(int T) { return T == 8 ? 12 : 16; }   // wavefronts per workgroup that fit beside the 78 KB of tables
+struct __attribute__((aligned(8))) SdF4A8 { float x, y, z, w; };   // sixteen bytes of a 136-byte feature row: rows alternate between 16- and 8-byte alignment
+__host__ __device__ constexpr int sd_walk_waves(int T) { return 16; }   // wavefronts per workgroup; two workgroups per compute unit at T <= 2 (26 KB of tables + 16 x 3 KB each)
 }  // namespace
 
+#ifdef SCOPA_WALK_ROWMASK   // development builds only: every memory row lands in a ring of SCOPA_WALK_ROWMASK + 1 rows (L2-resident) -- the same instruction stream without its HBM traffic
+#define SD_WALK_ROWMASK(row) (row) &= (uint32_t)(SCOPA_WALK_ROWMASK)
+#else
+#define SD_WALK_ROWMASK(row) (void)0
+#endif
 template <int T>
-__global__ void __launch_bounds__(sd_walk_waves(T) * 64)
+__global__ void __launch_bounds__(sd_walk_waves(T) * 64, 8)   // (second figure, HIP: wavefronts per SIMD to stay eligible for -- at most 64 registers)
 k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float4 *__restrict__ g_pol, const unsigned long long *__restrict__ g_thr,
              int traverser, int batch,
              float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask, uint32_t capacity, uint32_t write_base,
              float *__restrict__ root_values, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_next[1];
-    float4 *s_pol = reinterpret_cast<float4 *>(smem);                        // [kDecision] policy of every decision node
-    uint2 *s_node = reinterpret_cast<uint2 *>(s_pol + kDecision + 1);        // [kSdNodeSlots] feature bits | hand nibbles   (kDecision + 1: keeps 16-byte alignment)
-    unsigned long long *s_thr = reinterpret_cast<unsigned long long *>(s_node + kSdNodeSlots);   // [kSdNodeSlots][3] sampling thresholds (k_sdcfr_policy)
-    int8_t *s_payoff = reinterpret_cast<int8_t *>(s_thr + (size_t)kSdNodeSlots * 3);               // [kTerminal]
+    float4 *s_pol = reinterpret_cast<float4 *>(smem);                        // [kWalkTravNodes] policy of the traverser's nodes
+    uint2 *s_node = reinterpret_cast<uint2 *>(s_pol + kWalkTravNodes);       // [kWalkTravNodes] feature bits | hand nibbles of the traverser's nodes
+    unsigned long long *s_thr = reinterpret_cast<unsigned long long *>(s_node + kWalkTravNodes);   // [kWalkThr] sampling thresholds of the opponent's sampled plies (k_sdcfr_policy)
+    int8_t *s_payoff = reinterpret_cast<int8_t *>(s_thr + kWalkThr);         // [kTerminal]
     SdWalk<T> *s_wave = reinterpret_cast<SdWalk<T> *>(s_payoff + kTerminal); // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     if (tid == 0) s_next[0] = sd_walk_waves(T);
-    for (int i = tid; i < kDecision; i += blockDim.x) { s_pol[i] = g_pol[i]; s_node[i] = g_ninfo[i]; }
-    for (int i = tid; i < kDecision * 3; i += blockDim.x) s_thr[i] = g_thr[i];
+    for (int i = tid; i < sd_trav_off(traverser, 3) + 576; i += blockDim.x) {
+        const int m = (int)(i >= sd_trav_off(traverser, 1)) + (int)(i >= sd_trav_off(traverser, 2)) + (int)(i >= sd_trav_off(traverser, 3));
+        const int g = sd_level_off(2 * m + traverser) + i - sd_trav_off(traverser, m);
+        s_pol[i] = g_pol[g];
+        s_node[i] = g_ninfo[g];
+    }
+    for (int i = tid; i < sd_thr_off(traverser, 2) + (traverser == 0 ? 288 : 144); i += blockDim.x) {
+        const int k = (int)(i >= sd_thr_off(traverser, 1)) + (int)(i >= sd_thr_off(traverser, 2)), per = 3 - k, e = i - sd_thr_off(traverser, k);
+        const int node = per == 3 ? e / 3 : per == 2 ? e >> 1 : e, which = e - node * per;
+        s_thr[i] = g_thr[(size_t)(sd_level_off(2 * k + 1 - traverser) + node) * 3 + which];
+    }
     for (int i = tid; i < kTerminal / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_payoff)[i] = reinterpret_cast<const uint32_t *>(g_payoff)[i];
     __syncthreads();
     SdWalk<T> &ws = s_wave[wave];
@@ -1032,25 +1064,42 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
         uint32_t row0 = write_base + 41u * (uint32_t)tb0;                   // ring row of the task's first memory row (see k_sdcfr_traverse)
         row0 = row0 >= capacity ? row0 - capacity : row0;
         if (lane < T) ws.idx[0][lane] = 0;
+        // ---- the task's draws: a draw is keyed by (position within the traversal's frontier + 1024 ply, traversal id, iteration, stream) and by nothing the walk
+        // decides, so all of them -- the three sampled opponent plies, 4 + 12 + 24 positions per traversal for traverser 0, 1 + 4 + 12 for traverser 1 -- are
+        // taken here with every lane busy instead of in three rounds of 2..48 lanes; slot = T * (positions of the earlier sampled plies) + f
+        {
+            const int w0 = traverser == 0 ? 4 : 1, w1 = traverser == 0 ? 12 : 4, w2 = traverser == 0 ? 24 : 12, d0 = 1 - traverser;
+#pragma unroll 1
+            for (int sl = lane; sl < T * (w0 + w1 + w2); sl += 64) {
+                const int k = (int)(sl >= T * w0) + (int)(sl >= T * (w0 + w1));
+                const int wd = k == 0 ? w0 : k == 1 ? w1 : w2, f = sl - (k == 0 ? 0 : k == 1 ? T * w0 : T * (w0 + w1)), d = d0 + 2 * k;
+                int t = 0;
+#pragma unroll
+                for (int k2 = 1; k2 < T; k2++) t += f >= k2 * wd;
+                const int j = f - t * wd;
+                const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)(tb0 + t), iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
+                ws.draw[sl] = ((unsigned long long)(x.x0 >> 5) << 26) | (unsigned long long)(x.x1 >> 6);   // u = N * 2^-53 (u53)
+            }
+        }
         sd_order();
-        int width = 1, cb = 0;
+        int width = 1, cb = 0, dbase = 0;
         // ---- forward --------------------------------------------------------------------------------------------------------------
 #pragma unroll 1
         for (int d = 0; d < kPlies; d++) {
             const int p = d & 1, nl = 4 - (d >> 1);
             const bool trav_ply = p == traverser;
             if (!trav_ply && nl == 1) continue;                             // forced child, same position, same index within the next ply
-            const int n_nodes = T * width, m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_level_off(d);
+            const int n_nodes = T * width, m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
+            const int toff = sd_trav_off(traverser, m & 3), per = nl - 1, thr_off = sd_thr_off(traverser, (d >> 1) < 2 ? (d >> 1) : 2);
 #pragma unroll 1
             for (int f = lane; f < n_nodes; f += 64) {
                 const uint32_t node = ws.idx[cb][f];
-                const uint2 inf = s_node[off_d + (int)node];
-                const uint32_t xbits = inf.x;
-                int t = 0;
-#pragma unroll
-                for (int k = 1; k < T; k++) t += f >= k * width;
-                const int j = f - t * width;
                 if (trav_ply) {
+                    const uint32_t xbits = s_node[toff + (int)node].x;
+                    int t = 0;
+#pragma unroll
+                    for (int k = 1; k < T; k++) t += f >= k * width;
+                    const int j = f - t * width;
                     // recurse on ALL legal actions, hand order (:326-336)
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (k < nl) ws.idx[cb ^ 1][f * nl + k] = (uint16_t)(node * nl + k);
@@ -1058,13 +1107,12 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                     ws.xb[t][sd_rank(m, j)] = xbits;                       // its memory row's features and mask follow in the sweep below
                 } else {
                     // opponent: sample ONE action (:347-365): k_sdcfr_expand's Philox keying, its float comparisons as integer ones (k_sdcfr_policy)
-                    const unsigned long long *th = s_thr + (size_t)(off_d + (int)node) * 3;
-                    const unsigned long long t0 = th[0], t1 = th[1], t2 = th[2];
-                    const philox_out x = philox4x32_10((uint32_t)j + 1024u * (uint32_t)d, b0 + (uint32_t)(tb0 + t), iteration, 4u + (uint32_t)traverser, seed_lo, seed_hi);
-                    const unsigned long long N = ((unsigned long long)(x.x0 >> 5) << 26) | (unsigned long long)(x.x1 >> 6);   // u = N * 2^-53 (u53)
+                    const unsigned long long *th = s_thr + thr_off + (int)node * per;
+                    const unsigned long long t0 = th[0], t1 = per > 1 ? th[1] : 1ull << 53, t2 = per > 2 ? th[2] : 1ull << 53;   // 2^53 > every N: never counted
+                    const unsigned long long N = ws.draw[dbase + f];
                     int a = (int)(t0 <= N) + (int)(t1 <= N) + (int)(t2 <= N);
                     if (t0 == ~0ull) {                                     // probs.sum() == 0: np.random.choice(legal_actions), uniform, numpy's float64 arithmetic
-                        const double u = u53(x.x0, x.x1);
+                        const double u = (double)N * 0x1p-53;              // (exact: u53 of the two Philox words)
                         a = (int)(u * (double)nl);
                         a = a < nl - 1 ? a : nl - 1;
                     }
@@ -1072,25 +1120,28 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                 }
             }
             cb ^= 1;
-            if (trav_ply) width *= nl;
+            if (trav_ply) width *= nl; else dbase += n_nodes;
             sd_order();
         }
         // ---- the task's memory rows (:339-346), features and masks: 41 n_live rows, consecutive in the ring (up to its wrap) ------------------
         {
             const uint32_t *xbv = &ws.xb[0][0];
-            for (int e = lane; e < n_live * 41 * 17; e += 64) {             // features: 17 eight-byte pieces per 136-byte row
-                const int rr = e / 17, i = e - rr * 17;
-                const uint32_t xbits = xbv[rr];
+            for (int e = lane; e < n_live * 41 * 9; e += 64) {              // features: eight 16-byte pieces and one of 8 bytes per 136-byte row
+                const int rr = e / 9, i = e - rr * 9;
+                const uint32_t hb = xbv[rr] >> (4 * i);
                 uint32_t row = row0 + (uint32_t)rr;
                 row = row >= capacity ? row - capacity : row;
-                reinterpret_cast<float2 *>(mem_feat + (size_t)row * 34)[i] =
-                    i < 16 ? make_float2((float)((xbits >> (2 * i)) & 1u), (float)((xbits >> (2 * i + 1)) & 1u)) : make_float2(1.0f, 0.0f);   // [32] = float(player == current_player), [33] unused
+                SD_WALK_ROWMASK(row);
+                float *dst = mem_feat + (size_t)row * 34 + 4 * i;
+                if (i < 8) *reinterpret_cast<SdF4A8 *>(dst) = SdF4A8{(float)(hb & 1u), (float)((hb >> 1) & 1u), (float)((hb >> 2) & 1u), (float)((hb >> 3) & 1u)};
+                else *reinterpret_cast<float2 *>(dst) = make_float2(1.0f, 0.0f);   // [32] = float(player == current_player), [33] unused
             }
             for (int e = lane; e < n_live * 41 * 4; e += 64) {              // masks: 4 sixteen-byte pieces per 64-byte row
                 const int rr = e >> 2, i = e & 3;
                 const uint32_t hb = xbv[rr] >> (4 * i);
                 uint32_t row = row0 + (uint32_t)rr;
                 row = row >= capacity ? row - capacity : row;
+                SD_WALK_ROWMASK(row);
                 reinterpret_cast<float4 *>(mem_mask + (size_t)row * 16)[i] = make_float4((float)(hb & 1u), (float)((hb >> 1) & 1u), (float)((hb >> 2) & 1u), (float)((hb >> 3) & 1u));
             }
         }
@@ -1105,12 +1156,12 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
             const int p = d & 1, nl = 4 - (d >> 1);
             if (p != traverser) continue;                                  // opponent ply: the sampled child's value is returned unchanged (:363-365), same position
             width /= nl;
-            const int m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_level_off(d);
+            const int m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_trav_off(traverser, m);
 #pragma unroll 1
             for (int f0 = 0; f0 < T * width; f0 += 64) {
             const int f = f0 + lane;
-            uint32_t rrow = 0xFFFFFFFFu;                                    // this lane's regret row of the round: ring position (none: beyond the frontier / a dead traversal)
-            float4 rq[4] = {make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f), make_float4(0.f, 0.f, 0.f, 0.f)};
+            uint32_t rrow = 0xFFFFFFFFu, hand_l = 0;                        // this lane's regret row of the round: ring position (none: beyond the frontier / a dead traversal)
+            float rv_l[4] = {0.f, 0.f, 0.f, 0.f}, ri_l = 0.f;
             if (f < T * width) {
                 int t = 0;
 #pragma unroll
@@ -1140,30 +1191,29 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (k < nl) rv[k] = rv[k] / den;
                 }
-                float reg[16];
-#pragma unroll
-                for (int cc = 0; cc < 16; cc++) reg[cc] = ri;
-#pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    if (k < nl) {
-                        const int c = (int)((hand >> (4 * k)) & 15u);
-#pragma unroll
-                        for (int cc = 0; cc < 16; cc++) if (cc == c) reg[cc] = rv[k];
-                    }
-                }
                 uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)sd_rank(m, j);
                 row = row >= capacity ? row - capacity : row;
+                SD_WALK_ROWMASK(row);
                 rrow = t < n_live ? row : 0xFFFFFFFFu;
+                hand_l = hand; ri_l = ri;
 #pragma unroll
-                for (int i = 0; i < 4; i++) rq[i] = make_float4(reg[4 * i], reg[4 * i + 1], reg[4 * i + 2], reg[4 * i + 3]);
+                for (int k = 0; k < 4; k++) rv_l[k] = rv[k];
             }
-            // the round's regret rows through the stage, 32 at a time: lane L puts its row down, then four lanes store each row
+            // the round's regret rows through the stage, 32 at a time: lane L puts its row down -- sixteen times the illegal slots' value, then the legal cards'
+            // values over it (a wavefront's LDS writes land in program order) -- then four lanes store each row
+            const int n_round = T * width - f0;                             // frontier positions of this round (wavefront-uniform)
 #pragma unroll
             for (int half = 0; half < 2; half++) {
+                if (half * 32 >= n_round) break;
                 if ((lane >> 5) == half) {
                     ws.stage_row[lane & 31] = rrow;
+                    if (rrow != 0xFFFFFFFFu) {
+                        float *srow = &ws.stage[lane & 31][0];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) reinterpret_cast<float4 *>(&ws.stage[lane & 31][0])[i] = rq[i];
+                        for (int i = 0; i < 4; i++) reinterpret_cast<float4 *>(srow)[i] = make_float4(ri_l, ri_l, ri_l, ri_l);
+#pragma unroll
+                        for (int k = 0; k < 4; k++) if (k < nl) srow[(hand_l >> (4 * k)) & 15u] = rv_l[k];
+                    }
                 }
                 sd_order();
 #pragma unroll
@@ -1257,9 +1307,9 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         // 32768 traversals with 2 per wavefront, 51.8 / 126.5 with 8
         int Tw = ctx->sdcfr_tile_t;
         if (Tw != 1 && Tw != 2 && Tw != 4 && Tw != 8) Tw = 2;
-        const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < ctx->n_cus ? tasks_w : ctx->n_cus;
+        const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < 2 * ctx->n_cus ? tasks_w : 2 * ctx->n_cus;   // two workgroups per compute unit
         const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : Tw == 2 ? sizeof(SdWalk<2>) : sizeof(SdWalk<1>);
-        const size_t lds_w = (size_t)(kDecision + 1) * sizeof(float4) + (size_t)kSdNodeSlots * (sizeof(uint2) + 3 * sizeof(unsigned long long)) + (size_t)kTerminal + (size_t)sd_walk_waves(Tw) * wave_w;
+        const size_t lds_w = (size_t)kWalkTravNodes * (sizeof(float4) + sizeof(uint2)) + (size_t)kWalkThr * sizeof(unsigned long long) + (size_t)kTerminal + (size_t)sd_walk_waves(Tw) * wave_w;
         SC_REQUIRE(ctx, lds_w + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (walk kernel)");
 #define SD_WALK(TT, BIT)                                                                                                                          \
     do {                                                                                                                                          \
