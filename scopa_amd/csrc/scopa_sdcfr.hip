@@ -844,76 +844,11 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
 // for batches whose traversals do NOT share a deal (nothing to share then), it pins the tile arithmetic to the reference fixture through
 // the replayed-draws tests, and the two paths are tested against each other row for row.
 namespace {
-// one 16-node tile through the 34-128-64-16 MLP: xbits = the lane's node's feature bits, result = outputs 4 q + r of node lane % 16.
-// The MFMA sequence is k_sdcfr_traverse's (same K order, same accumulator chains): results are bit-identical.
-__device__ __forceinline__ void sd_mlp_tile(const float *Wn, int lane, uint32_t xbits, float (&adv)[4]) {
-    const int q = lane >> 4;
-    const float4 *w1 = reinterpret_cast<const float4 *>(Wn + kImgW1) + lane, *c1 = reinterpret_cast<const float4 *>(Wn + kImgC1) + q;
-    const float4 *w2 = reinterpret_cast<const float4 *>(Wn + kImgW2) + lane, *b2 = reinterpret_cast<const float4 *>(Wn + kImgB2) + q;
-    const float4 *w3 = reinterpret_cast<const float4 *>(Wn + kImgW3) + lane, *b3 = reinterpret_cast<const float4 *>(Wn + kImgB3) + q;
-    v4f h1[8];
-#pragma unroll
-    for (int mt = 0; mt < 8; mt++) h1[mt] = to_v4f(c1[mt * 4]);
-    const uint32_t xs = xbits >> q;
-#pragma unroll
-    for (int g = 0; g < 2; g++) {
-        float4 w[8];
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) w[mt] = w1[(mt * 2 + g) * 64];
-        const float x0 = (float)((xs >> (16 * g)) & 1u), x1 = (float)((xs >> (16 * g + 4)) & 1u);
-        const float x2 = (float)((xs >> (16 * g + 8)) & 1u), x3 = (float)((xs >> (16 * g + 12)) & 1u);
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].x, x0, h1[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].y, x1, h1[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].z, x2, h1[mt]);
-#pragma unroll
-        for (int mt = 0; mt < 8; mt++) h1[mt] = mfma16(w[mt].w, x3, h1[mt]);
-    }
-    v4f h2[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) h2[nt] = to_v4f(b2[nt * 4]);
-#pragma unroll
-    for (int mt = 0; mt < 8; mt++) {
-        float4 w[4];
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) w[nt] = w2[(nt * 8 + mt) * 64];
-        const float a0 = relu(h1[mt][0]), a1 = relu(h1[mt][1]), a2 = relu(h1[mt][2]), a3 = relu(h1[mt][3]);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].x, a0, h2[nt]);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].y, a1, h2[nt]);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].z, a2, h2[nt]);
-#pragma unroll
-        for (int nt = 0; nt < 4; nt++) h2[nt] = mfma16(w[nt].w, a3, h2[nt]);
-    }
-    float4 w3r[4];
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++) w3r[nt] = w3[nt * 64];
-    v4f o0 = to_v4f(b3[0]), o1 = {0.0f, 0.0f, 0.0f, 0.0f};
-    float g[4][4];
-#pragma unroll
-    for (int nt = 0; nt < 4; nt++)
-#pragma unroll
-        for (int r = 0; r < 4; r++) g[nt][r] = relu(h2[nt][r]);
-    o0 = mfma16(w3r[0].x, g[0][0], o0); o1 = mfma16(w3r[1].x, g[1][0], o1);
-    o0 = mfma16(w3r[0].y, g[0][1], o0); o1 = mfma16(w3r[1].y, g[1][1], o1);
-    o0 = mfma16(w3r[0].z, g[0][2], o0); o1 = mfma16(w3r[1].z, g[1][2], o1);
-    o0 = mfma16(w3r[0].w, g[0][3], o0); o1 = mfma16(w3r[1].w, g[1][3], o1);
-    o0 = mfma16(w3r[2].x, g[2][0], o0); o1 = mfma16(w3r[3].x, g[3][0], o1);
-    o0 = mfma16(w3r[2].y, g[2][1], o0); o1 = mfma16(w3r[3].y, g[3][1], o1);
-    o0 = mfma16(w3r[2].z, g[2][2], o0); o1 = mfma16(w3r[3].z, g[3][2], o1);
-    o0 = mfma16(w3r[2].w, g[2][3], o0); o1 = mfma16(w3r[3].w, g[3][3], o1);
-#pragma unroll
-    for (int r = 0; r < 4; r++) adv[r] = o0[r] + o1[r];
-}
 __host__ __device__ constexpr int sd_level_off(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 5 : d == 3 ? 21 : d == 4 ? 69 : d == 5 ? 213 : d == 6 ? 501 : 1077; }   // level_offset as selects (no table load)
 constexpr int kPolicyTiles = 1 + 1 + 1 + 3 + 9 + 18 + 36 + 36;   // 16-node tiles per ply: widths 1, 4, 16, 48, 144, 288, 576, 576
-constexpr int kPolicyWaves = 8;
-constexpr int kPolicyBlocks0 = (47 + kPolicyWaves - 1) / kPolicyWaves, kPolicyBlocks1 = (58 + kPolicyWaves - 1) / kPolicyWaves;
-static_assert(kPolicyTiles == 47 + 58, "tiles by player");
+constexpr int kPolicyWaves = 4;                                  // one tile per workgroup, its layers split over four wavefronts
+__host__ __device__ constexpr int sd_tile_off(int d) { return d == 0 ? 0 : d == 1 ? 1 : d == 2 ? 2 : d == 3 ? 3 : d == 4 ? 6 : d == 5 ? 15 : d == 6 ? 33 : 69; }
+static_assert(sd_tile_off(7) + 36 == kPolicyTiles, "tiles by ply");
 }  // namespace
 
 // regret-matching policy (legal actions in hand order, zeros beyond) of EVERY decision node of the deal under the current nets, and what
@@ -924,31 +859,92 @@ static_assert(kPolicyTiles == 47 + 58, "tiles by player");
 // node instead of once per visit.  thr[0] = ~0 marks probs.sum() == 0 (uniform choice: the visit keeps numpy's arithmetic for that case).
 __global__ void __launch_bounds__(kPolicyWaves * 64)
 k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_image, float4 *__restrict__ g_pol, unsigned long long *__restrict__ g_thr) {
-    extern __shared__ __align__(16) unsigned char smem[];
-    float *s_w = reinterpret_cast<float *>(smem);                           // [kImgFloats]: ONE net -- a workgroup's tiles belong to one player's plies
-    SdPos *s_pos = reinterpret_cast<SdPos *>(s_w + kImgFloats);             // [wavefronts]
+    // One 16-node tile per workgroup of four wavefronts.  The launch is a latency chain (105 tiles on 256 compute units), so the tile's MLP is cut
+    // ACROSS wavefronts -- layer 1: two of the eight 16-unit blocks each; layer 2: one of the four blocks each; layer 3: its two accumulator chains on
+    // wavefronts 0 and 1 -- with the activations handed over through LDS (an MFMA result IS the next layer's B operand, lane for lane: a float4 per lane
+    // and block), and every wavefront takes its weights straight from the image in global memory (16 float4 per lane, all in flight at once; no staging
+    // of the 54 KB net, no barrier in front of the first MFMA).  Every accumulator sees the K order of k_sdcfr_traverse: results are bit-identical.
+    __shared__ float4 s_h1[8][64], s_h2[4][64], s_o[2][64];
+    __shared__ SdPos s_pos1;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // workgroups 0 .. kPolicyBlocks0 - 1 take the 47 tiles of player 0's plies (0, 2, 4, 6: 1 + 1 + 9 + 36), the rest the 58 of player 1's (1, 3, 5, 7: 1 + 3 + 18 + 36)
-    const int p = (int)blockIdx.x >= kPolicyBlocks0 ? 1 : 0;
-    for (int i = tid; i < kImgFloats / 4; i += blockDim.x)
-        reinterpret_cast<float4 *>(s_w)[i] = reinterpret_cast<const float4 *>(g_image + p * kImgFloats)[i];
-    __syncthreads();
-    int tile = ((int)blockIdx.x - (p ? kPolicyBlocks0 : 0)) * kPolicyWaves + wave;
-    if (tile >= (p ? 58 : 47)) return;
-    int d = p;
+    int tile = (int)blockIdx.x, d = 0;
 #pragma unroll
-    for (int k = 0; k < 3; k++) {                                           // which of the player's plies the tile belongs to
-        const int tiles_k = (level_width(2 * k + p) + 15) / 16;
-        if (d == 2 * k + p && tile >= tiles_k) { tile -= tiles_k; d += 2; }
-    }
+    for (int k = 1; k < kPlies; k++) d += tile >= sd_tile_off(k);
+    tile -= sd_tile_off(d);
+    const int p = d & 1;
+    const float *Wn = g_image + p * kImgFloats;
     const int wd = d == 0 ? 1 : d == 1 ? 4 : d == 2 ? 16 : d == 3 ? 48 : d == 4 ? 144 : d == 5 ? 288 : 576, nl = 4 - (d >> 1);
     const int nj = lane & 15, q = lane >> 4, j = tile * 16 + nj;
     const bool live = j < wd;
     const uint2 inf = g_ninfo[sd_level_off(d) + (live ? j : wd - 1)];
     const uint32_t xbits = inf.x, hand = inf.y;
+    float4 w1r[2][2], c1r[2], w2r[8], w3r[2];
+    {
+        const float4 *w1 = reinterpret_cast<const float4 *>(Wn + kImgW1) + lane, *c1 = reinterpret_cast<const float4 *>(Wn + kImgC1) + q;
+        const float4 *w2 = reinterpret_cast<const float4 *>(Wn + kImgW2) + lane, *w3 = reinterpret_cast<const float4 *>(Wn + kImgW3) + lane;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int mt = 2 * wave + h;
+            c1r[h] = c1[mt * 4];
+#pragma unroll
+            for (int g = 0; g < 2; g++) w1r[h][g] = w1[(mt * 2 + g) * 64];
+        }
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) w2r[mt] = w2[(wave * 8 + mt) * 64];
+#pragma unroll
+        for (int h = 0; h < 2; h++) w3r[h] = w3[((wave & 1) + 2 * h) * 64];
+    }
+    const float4 b2r = (reinterpret_cast<const float4 *>(Wn + kImgB2) + q)[wave * 4], b3r = (reinterpret_cast<const float4 *>(Wn + kImgB3) + q)[0];
+    {   // layer 1: unit blocks 2 wave, 2 wave + 1
+        v4f ha = to_v4f(c1r[0]), hb = to_v4f(c1r[1]);
+        const uint32_t xs = xbits >> q;
+#pragma unroll
+        for (int g = 0; g < 2; g++) {
+            const float x0 = (float)((xs >> (16 * g)) & 1u), x1 = (float)((xs >> (16 * g + 4)) & 1u);
+            const float x2 = (float)((xs >> (16 * g + 8)) & 1u), x3 = (float)((xs >> (16 * g + 12)) & 1u);
+            ha = mfma16(w1r[0][g].x, x0, ha); hb = mfma16(w1r[1][g].x, x0, hb);
+            ha = mfma16(w1r[0][g].y, x1, ha); hb = mfma16(w1r[1][g].y, x1, hb);
+            ha = mfma16(w1r[0][g].z, x2, ha); hb = mfma16(w1r[1][g].z, x2, hb);
+            ha = mfma16(w1r[0][g].w, x3, ha); hb = mfma16(w1r[1][g].w, x3, hb);
+        }
+        s_h1[2 * wave][lane] = make_float4(relu(ha[0]), relu(ha[1]), relu(ha[2]), relu(ha[3]));
+        s_h1[2 * wave + 1][lane] = make_float4(relu(hb[0]), relu(hb[1]), relu(hb[2]), relu(hb[3]));
+    }
+    __syncthreads();
+    {   // layer 2: unit block `wave`
+        v4f h2 = to_v4f(b2r);
+#pragma unroll
+        for (int mt = 0; mt < 8; mt++) {
+            const float4 a = s_h1[mt][lane];
+            h2 = mfma16(w2r[mt].x, a.x, h2);
+            h2 = mfma16(w2r[mt].y, a.y, h2);
+            h2 = mfma16(w2r[mt].z, a.z, h2);
+            h2 = mfma16(w2r[mt].w, a.w, h2);
+        }
+        s_h2[wave][lane] = make_float4(relu(h2[0]), relu(h2[1]), relu(h2[2]), relu(h2[3]));
+    }
+    __syncthreads();
+    if (wave < 2) {   // layer 3: chain 0 = bias + blocks 0, 2 (wavefront 0), chain 1 = blocks 1, 3 (wavefront 1)
+        v4f o = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (wave == 0) o = to_v4f(b3r);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const float4 a = s_h2[wave + 2 * h][lane];
+            o = mfma16(w3r[h].x, a.x, o);
+            o = mfma16(w3r[h].y, a.y, o);
+            o = mfma16(w3r[h].z, a.z, o);
+            o = mfma16(w3r[h].w, a.w, o);
+        }
+        s_o[wave][lane] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    __syncthreads();
+    if (wave != 0) return;
     float adv[4];
-    sd_mlp_tile(s_w, lane, xbits, adv);
-    float (*wpos)[16] = s_pos[wave].pos;
+    {
+        const float4 o0 = s_o[0][lane], o1 = s_o[1][lane];
+        adv[0] = o0.x + o1.x; adv[1] = o0.y + o1.y; adv[2] = o0.z + o1.z; adv[3] = o0.w + o1.w;
+    }
+    float (*wpos)[16] = s_pos1.pos;
     float z = 0.0f;
     {
         float4 pv;
@@ -1296,10 +1292,7 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         // the default: every decision node of the deal evaluated once (k_sdcfr_policy), then the traversals as walks over that table
         if (!ctx->d_sdpol) SC_HIP(ctx, hipMalloc(&ctx->d_sdpol, (sizeof(float4) + 3 * sizeof(unsigned long long)) * kDecision));   // policies, then thresholds
         unsigned long long *d_thr = reinterpret_cast<unsigned long long *>(reinterpret_cast<float4 *>(ctx->d_sdpol) + kDecision);
-        const size_t lds_p = (size_t)kImgFloats * sizeof(float) + (size_t)kPolicyWaves * sizeof(SdPos);
-        SC_REQUIRE(ctx, lds_p + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (policy kernel)");
-        SC_LDS_ATTR(ctx, scopa::kLdsSdPolicy, k_sdcfr_policy, ctx->lds_limit - 64);
-        hipLaunchKernelGGL(k_sdcfr_policy, dim3(kPolicyBlocks0 + kPolicyBlocks1), dim3(kPolicyWaves * 64), lds_p, ctx->stream,
+        hipLaunchKernelGGL(k_sdcfr_policy, dim3(kPolicyTiles), dim3(kPolicyWaves * 64), 0, ctx->stream,
                            (const uint2 *)ctx->d_sdnode, d_image, (float4 *)ctx->d_sdpol, d_thr);
         SC_HIP(ctx, hipGetLastError());
         // traversals per wavefront: 8 would use the 64 lanes best (frontiers 8 .. 192 wide), but the walk is a chain of LDS round trips and
