@@ -140,7 +140,7 @@ int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, so the "already raised" flag lives in the
 // context (one context = one device), not in a process-wide static: a second context on another device raises it again.
-enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsCfrSched = 512u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u, kLdsSdcfr2 = 1024u, kLdsSdcfr3 = 2048u, kLdsSdcfr4 = 4096u, kLdsSdcfr5 = 8192u, kLdsSdcfr6 = 16384u, kLdsSdcfr7 = 32768u, kLdsSdPolicy = 65536u, kLdsSdWalk2 = 131072u, kLdsSdWalk4 = 262144u, kLdsSdWalk8 = 524288u, kLdsSdWalk1 = 1048576u };
+enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsCfrSched = 512u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u, kLdsSdcfr2 = 1024u, kLdsSdcfr3 = 2048u, kLdsSdcfr4 = 4096u, kLdsSdcfr5 = 8192u, kLdsSdcfr6 = 16384u, kLdsSdcfr7 = 32768u, kLdsSdPolicy = 65536u, kLdsSdWalk2 = 131072u, kLdsSdWalk4 = 262144u, kLdsSdWalk8 = 524288u, kLdsSdWalk1 = 1048576u, kLdsSdWalk8b = 1u << 21, kLdsSdWalk4b = 1u << 22, kLdsSdWalk2b = 1u << 23, kLdsSdWalk1b = 1u << 24 };
 inline int32_t ensure_lds_attr(scopa_ctx *ctx, uint32_t kernel_bit, const void *fn, int bytes) {
     if (ctx->lds_attr_done & kernel_bit) return SCOPA_OK;
     SC_HIP(ctx, hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));

@@ -1014,20 +1014,27 @@ struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a fr
     };
 };
 struct __attribute__((aligned(8))) SdF4A8 { float x, y, z, w; };   // sixteen bytes of a 136-byte feature row: rows alternate between 16- and 8-byte alignment
-__host__ __device__ constexpr int sd_walk_waves(int T) { return 16; }   // wavefronts per workgroup; two workgroups per compute unit at T <= 2 (26 KB of tables + 16 x 3 KB each)
+__host__ __device__ constexpr int sd_walk_waves(int T) { return T <= 2 ? 12 : 16; }   // wavefronts per workgroup; T <= 2: two workgroups per compute unit (26 KB of tables + 12 x 3 KB each), six wavefronts per SIMD
 }  // namespace
 
+#ifdef SCOPA_WALK_STAMPS   // development build only: the same stamps for wavefront 0 of workgroup 0 of k_sdcfr_walk
+__device__ unsigned long long g_wk_stamps[16];   // 0 staging the tables | 1 draws | 2 forward | 3 feature / mask sweep | 4 leaves + backward | 5 take | 13 shader clocks, 14 100 MHz ticks of whole tasks | 15 tasks
+#endif
 #ifdef SCOPA_WALK_ROWMASK   // development builds only: every memory row lands in a ring of SCOPA_WALK_ROWMASK + 1 rows (L2-resident) -- the same instruction stream without its HBM traffic
 #define SD_WALK_ROWMASK(row) (row) &= (uint32_t)(SCOPA_WALK_ROWMASK)
 #else
 #define SD_WALK_ROWMASK(row) (void)0
 #endif
-template <int T>
-__global__ void __launch_bounds__(sd_walk_waves(T) * 64, 8)   // (second figure, HIP: wavefronts per SIMD to stay eligible for -- at most 64 registers)
+// The traverser is a template parameter and the ply loops are unrolled: every per-ply quantity (legal actions, frontier width, table offsets, which
+// plies sample) is then a constant, the frontier loops have known trip counts, and the scalar selects and branches that decided them per ply at run time
+// -- about 600 scalar and 250 vector instructions per traversal of a chain that a lone wavefront executes at one instruction per 8 clocks -- are gone.
+template <int T, int TR>
+__global__ void __launch_bounds__(sd_walk_waves(T) * 64, T <= 2 ? 6 : 4)   // (second figure, HIP: wavefronts per SIMD to stay eligible for: two workgroups of twelve -- at most 80 registers)
 k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float4 *__restrict__ g_pol, const unsigned long long *__restrict__ g_thr,
-             int traverser, int batch,
+             int batch,
              float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask, uint32_t capacity, uint32_t write_base,
              float *__restrict__ root_values, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0) {
+    constexpr int traverser = TR;
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ int s_next[1];
     float4 *s_pol = reinterpret_cast<float4 *>(smem);                        // [kWalkTravNodes] policy of the traverser's nodes
@@ -1036,6 +1043,9 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
     int8_t *s_payoff = reinterpret_cast<int8_t *>(s_thr + kWalkThr);         // [kTerminal]
     SdWalk<T> *s_wave = reinterpret_cast<SdWalk<T> *>(s_payoff + kTerminal); // [wavefronts]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SCOPA_WALK_STAMPS
+    const unsigned long long wk_k0_ = clock64();
+#endif
     if (tid == 0) s_next[0] = sd_walk_waves(T);
     for (int i = tid; i < sd_trav_off(traverser, 3) + 576; i += blockDim.x) {
         const int m = (int)(i >= sd_trav_off(traverser, 1)) + (int)(i >= sd_trav_off(traverser, 2)) + (int)(i >= sd_trav_off(traverser, 3));
@@ -1050,6 +1060,9 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
     }
     for (int i = tid; i < kTerminal / 4; i += blockDim.x) reinterpret_cast<uint32_t *>(s_payoff)[i] = reinterpret_cast<const uint32_t *>(g_payoff)[i];
     __syncthreads();
+#ifdef SCOPA_WALK_STAMPS
+    if (blockIdx.x == 0 && tid == 0) g_wk_stamps[0] += clock64() - wk_k0_;
+#endif
     SdWalk<T> &ws = s_wave[wave];
     const int n_tasks = (batch + T - 1) / T;
     const int per_wg = (n_tasks + (int)gridDim.x - 1) / (int)gridDim.x;
@@ -1059,6 +1072,11 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
         const int n_live = batch - tb0 < T ? batch - tb0 : T;               // traversals t >= n_live are walked like the others but write nothing
         uint32_t row0 = write_base + 41u * (uint32_t)tb0;                   // ring row of the task's first memory row (see k_sdcfr_traverse)
         row0 = row0 >= capacity ? row0 - capacity : row0;
+#ifdef SCOPA_WALK_STAMPS
+        unsigned long long sd_acc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const unsigned long long sd_t0_ = clock64(), sd_r0_ = wall_clock64();
+        unsigned long long sd_prev_ = sd_t0_;
+#endif
         if (lane < T) ws.idx[0][lane] = 0;
         // ---- the task's draws: a draw is keyed by (position within the traversal's frontier + 1024 ply, traversal id, iteration, stream) and by nothing the walk
         // decides, so all of them -- the three sampled opponent plies, 4 + 12 + 24 positions per traversal for traverser 0, 1 + 4 + 12 for traverser 1 -- are
@@ -1078,16 +1096,17 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
             }
         }
         sd_order();
+        SD_STAMP(1);
         int width = 1, cb = 0, dbase = 0;
         // ---- forward --------------------------------------------------------------------------------------------------------------
-#pragma unroll 1
+#pragma unroll
         for (int d = 0; d < kPlies; d++) {
             const int p = d & 1, nl = 4 - (d >> 1);
             const bool trav_ply = p == traverser;
             if (!trav_ply && nl == 1) continue;                             // forced child, same position, same index within the next ply
             const int n_nodes = T * width, m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
             const int toff = sd_trav_off(traverser, m & 3), per = nl - 1, thr_off = sd_thr_off(traverser, (d >> 1) < 2 ? (d >> 1) : 2);
-#pragma unroll 1
+#pragma unroll
             for (int f = lane; f < n_nodes; f += 64) {
                 const uint32_t node = ws.idx[cb][f];
                 if (trav_ply) {
@@ -1119,6 +1138,7 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
             if (trav_ply) width *= nl; else dbase += n_nodes;
             sd_order();
         }
+        SD_STAMP(2);
         // ---- the task's memory rows (:339-346), features and masks: 41 n_live rows, consecutive in the ring (up to its wrap) ------------------
         {
             const uint32_t *xbv = &ws.xb[0][0];
@@ -1141,19 +1161,20 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                 reinterpret_cast<float4 *>(mem_mask + (size_t)row * 16)[i] = make_float4((float)(hb & 1u), (float)((hb >> 1) & 1u), (float)((hb >> 2) & 1u), (float)((hb >> 3) & 1u));
             }
         }
+        SD_STAMP(3);
         // ---- leaves, then backward -------------------------------------------------------------------------------------------------
         for (int f = lane; f < T * width; f += 64) {
             const int p0 = s_payoff[ws.idx[cb][f]];
             ws.val[f] = 0.5f * (float)(traverser == 0 ? p0 : -p0);
         }
         sd_order();
-#pragma unroll 1
+#pragma unroll
         for (int d = kPlies - 1; d >= 0; d--) {
             const int p = d & 1, nl = 4 - (d >> 1);
             if (p != traverser) continue;                                  // opponent ply: the sampled child's value is returned unchanged (:363-365), same position
             width /= nl;
             const int m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_trav_off(traverser, m);
-#pragma unroll 1
+#pragma unroll
             for (int f0 = 0; f0 < T * width; f0 += 64) {
             const int f = f0 + lane;
             uint32_t rrow = 0xFFFFFFFFu, hand_l = 0;                        // this lane's regret row of the round: ring position (none: beyond the frontier / a dead traversal)
@@ -1225,13 +1246,26 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
         }
         if (lane < n_live) root_values[tb0 + lane] = ws.val[lane];
         sd_order();
+        SD_STAMP(4);
         int got = 0;
         if (lane == 0) got = atomicAdd(s_next, 1);
         c = __builtin_amdgcn_readfirstlane(got);
+        SD_STAMP(5);
+#ifdef SCOPA_WALK_STAMPS
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            for (int i = 1; i < 8; i++) g_wk_stamps[i] += sd_acc_[i];
+            g_wk_stamps[13] += clock64() - sd_t0_; g_wk_stamps[14] += wall_clock64() - sd_r0_; g_wk_stamps[15] += 1;
+        }
+#endif
     }
 }
 
 #ifdef SCOPA_WALK_STAMPS
+extern "C" int scopa_debug_sdwalk_stamps(unsigned long long *out16, int reset) {
+    if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_wk_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_wk_stamps), z, sizeof z) != hipSuccess) return -1; }
+    return 0;
+}
 extern "C" int scopa_debug_sdcfr_stamps(unsigned long long *out16, int reset) {
     if (hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_sd_stamps), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; if (hipMemcpyToSymbol(HIP_SYMBOL(g_sd_stamps), z, sizeof(z)) != hipSuccess) return -1; }
@@ -1304,17 +1338,24 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : Tw == 2 ? sizeof(SdWalk<2>) : sizeof(SdWalk<1>);
         const size_t lds_w = (size_t)kWalkTravNodes * (sizeof(float4) + sizeof(uint2)) + (size_t)kWalkThr * sizeof(unsigned long long) + (size_t)kTerminal + (size_t)sd_walk_waves(Tw) * wave_w;
         SC_REQUIRE(ctx, lds_w + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (walk kernel)");
-#define SD_WALK(TT, BIT)                                                                                                                          \
+#define SD_WALK(TT, TR, BIT)                                                                                                                      \
     do {                                                                                                                                          \
-        SC_LDS_ATTR(ctx, BIT, k_sdcfr_walk<TT>, ctx->lds_limit - 64);                                                                             \
-        hipLaunchKernelGGL(k_sdcfr_walk<TT>, dim3(grid_w), dim3(sd_walk_waves(TT) * 64), lds_w, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, \
-                           (const float4 *)ctx->d_sdpol, (const unsigned long long *)d_thr, (int)traverser, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, \
+        SC_LDS_ATTR(ctx, BIT, (k_sdcfr_walk<TT, TR>), ctx->lds_limit - 64);                                                                       \
+        hipLaunchKernelGGL((k_sdcfr_walk<TT, TR>), dim3(grid_w), dim3(sd_walk_waves(TT) * 64), lds_w, ctx->stream, (const uint2 *)ctx->d_sdnode, ctx->d_payoff, \
+                           (const float4 *)ctx->d_sdpol, (const unsigned long long *)d_thr, (int)batch, d_mem_feat, d_mem_regret, d_mem_mask, (uint32_t)capacity, \
                            (uint32_t)write_base, d_root_values, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), iteration, b0);                  \
     } while (0)
-        if (Tw == 8) SD_WALK(8, scopa::kLdsSdWalk8);
-        else if (Tw == 4) SD_WALK(4, scopa::kLdsSdWalk4);
-        else if (Tw == 2) SD_WALK(2, scopa::kLdsSdWalk2);
-        else SD_WALK(1, scopa::kLdsSdWalk1);
+        if (traverser == 0) {
+            if (Tw == 8) SD_WALK(8, 0, scopa::kLdsSdWalk8);
+            else if (Tw == 4) SD_WALK(4, 0, scopa::kLdsSdWalk4);
+            else if (Tw == 2) SD_WALK(2, 0, scopa::kLdsSdWalk2);
+            else SD_WALK(1, 0, scopa::kLdsSdWalk1);
+        } else {
+            if (Tw == 8) SD_WALK(8, 1, scopa::kLdsSdWalk8b);
+            else if (Tw == 4) SD_WALK(4, 1, scopa::kLdsSdWalk4b);
+            else if (Tw == 2) SD_WALK(2, 1, scopa::kLdsSdWalk2b);
+            else SD_WALK(1, 1, scopa::kLdsSdWalk1b);
+        }
 #undef SD_WALK
         SC_HIP(ctx, hipGetLastError());
         ctx->sdcfr_visits += (uint64_t)batch * (traverser == 0 ? 105 : 82);
