@@ -1002,7 +1002,6 @@ template <int T>
 struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a frontier node addressed by its position f = t * width + j
     float val[T * 24];            // values of the frontier on the way back up, replaced in place (see SdTeam::val)
     uint16_t idx[2][T * 24];      // tree index of the frontier nodes of the current / the next ply
-    uint16_t trav_node[T][41];    // tree index (within its ply) of every traverser node, plies m = 0..3 at offsets 0, 1, 5, 17
     uint32_t xb[T][41];           // feature bits of every traverser node BY MEMORY-ROW RANK: features and masks of the task's rows are written from
                                   // here in one sweep of consecutive addresses (a lane per row piece, rows in memory order) instead of a lane per row
     union alignas(16) {
@@ -1098,19 +1097,24 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
         sd_order();
         SD_STAMP(1);
         int width = 1, cb = 0, dbase = 0;
+        uint32_t kept[4][(T * 24 + 63) / 64];
         // ---- forward --------------------------------------------------------------------------------------------------------------
 #pragma unroll
         for (int d = 0; d < kPlies; d++) {
             const int p = d & 1, nl = 4 - (d >> 1);
             const bool trav_ply = p == traverser;
             if (!trav_ply && nl == 1) continue;                             // forced child, same position, same index within the next ply
-            const int n_nodes = T * width, m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17;
+            const int n_nodes = T * width, m = (d - traverser) >> 1;
             const int toff = sd_trav_off(traverser, m & 3), per = nl - 1, thr_off = sd_thr_off(traverser, (d >> 1) < 2 ? (d >> 1) : 2);
 #pragma unroll
-            for (int f = lane; f < n_nodes; f += 64) {
+            for (int r = 0; r * 64 < n_nodes; r++) {
+                const int f = r * 64 + lane;
+                if (f >= n_nodes) continue;
                 const uint32_t node = ws.idx[cb][f];
                 if (trav_ply) {
-                    const uint32_t xbits = s_node[toff + (int)node].x;
+                    const uint2 inf = s_node[toff + (int)node];
+                    const uint32_t xbits = inf.x;
+                    kept[m & 3][r] = node | (inf.y << 16);                 // the way back visits position f of this ply from the same lane: tree index and hand nibbles stay in a register
                     int t = 0;
 #pragma unroll
                     for (int k = 1; k < T; k++) t += f >= k * width;
@@ -1118,7 +1122,6 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                     // recurse on ALL legal actions, hand order (:326-336)
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (k < nl) ws.idx[cb ^ 1][f * nl + k] = (uint16_t)(node * nl + k);
-                    ws.trav_node[t][moff + j] = (uint16_t)node;
                     ws.xb[t][sd_rank(m, j)] = xbits;                       // its memory row's features and mask follow in the sweep below
                 } else {
                     // opponent: sample ONE action (:347-365): k_sdcfr_expand's Philox keying, its float comparisons as integer ones (k_sdcfr_policy)
@@ -1140,6 +1143,9 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
         }
         SD_STAMP(2);
         // ---- the task's memory rows (:339-346), features and masks: 41 n_live rows, consecutive in the ring (up to its wrap) ------------------
+        // A lane per piece, pieces in memory order, a row's nine pieces in nine consecutive lanes of ONE store instruction: the L2 sees each 136-byte row
+        // whole.  (Measured and not kept: the [32], [33] pair of every row in a loop of its own -- 8-byte stores 136 bytes apart -- and the loops unrolled
+        // four times or fully: a lone wavefront's sweep got 35 % shorter, the launch at 32768 traversals 25 % LONGER -- the stores arrive in a worse order.)
         {
             const uint32_t *xbv = &ws.xb[0][0];
             for (int e = lane; e < n_live * 41 * 9; e += 64) {              // features: eight 16-byte pieces and one of 8 bytes per 136-byte row
@@ -1173,10 +1179,10 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
             const int p = d & 1, nl = 4 - (d >> 1);
             if (p != traverser) continue;                                  // opponent ply: the sampled child's value is returned unchanged (:363-365), same position
             width /= nl;
-            const int m = (d - traverser) >> 1, moff = m == 0 ? 0 : m == 1 ? 1 : m == 2 ? 5 : 17, off_d = sd_trav_off(traverser, m);
+            const int m = (d - traverser) >> 1, off_d = sd_trav_off(traverser, m);
 #pragma unroll
-            for (int f0 = 0; f0 < T * width; f0 += 64) {
-            const int f = f0 + lane;
+            for (int r = 0; r * 64 < T * width; r++) {
+            const int f0 = r * 64, f = f0 + lane;
             uint32_t rrow = 0xFFFFFFFFu, hand_l = 0;                        // this lane's regret row of the round: ring position (none: beyond the frontier / a dead traversal)
             float rv_l[4] = {0.f, 0.f, 0.f, 0.f}, ri_l = 0.f;
             if (f < T * width) {
@@ -1184,8 +1190,8 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
 #pragma unroll
                 for (int k = 1; k < T; k++) t += f >= k * width;
                 const int j = f - t * width;
-                const int node = ws.trav_node[t][moff + j];
-                const uint32_t hand = s_node[off_d + node].y;
+                const int node = (int)(kept[m][r] & 0xFFFFu);
+                const uint32_t hand = kept[m][r] >> 16;
                 const float4 pol = s_pol[off_d + node];
                 const float pl[4] = {pol.x, pol.y, pol.z, pol.w};
                 // value = sum policy * action value (float32, hand order, :335); regrets = counterfactual_values - value over all 16 slots, where
