@@ -1145,7 +1145,8 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
         // ---- the task's memory rows (:339-346), features and masks: 41 n_live rows, consecutive in the ring (up to its wrap) ------------------
         // A lane per piece, pieces in memory order, a row's nine pieces in nine consecutive lanes of ONE store instruction: the L2 sees each 136-byte row
         // whole.  (Measured and not kept: the [32], [33] pair of every row in a loop of its own -- 8-byte stores 136 bytes apart -- and the loops unrolled
-        // four times or fully: a lone wavefront's sweep got 35 % shorter, the launch at 32768 traversals 25 % LONGER -- the stores arrive in a worse order.)
+        // four times or fully: a lone wavefront's sweep got 35 % shorter, the launch at 32768 traversals 25 % LONGER -- the stores arrive in a worse order;
+        // the 8-byte-aligned 16-byte pieces as ONE store each (inline asm; the compiler emits two 8-byte stores): no difference.)
         {
             const uint32_t *xbv = &ws.xb[0][0];
             for (int e = lane; e < n_live * 41 * 9; e += 64) {              // features: eight 16-byte pieces and one of 8 bytes per 136-byte row

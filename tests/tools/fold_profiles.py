@@ -98,10 +98,12 @@ def sd_counters(path, kernel):
 
 
 def sd_stats(path, kernel):
+    # every instantiation whose name contains `kernel` (k_sdcfr_walk<2, 0> and <2, 1>: one per traverser), averaged over their calls
+    ns, calls = 0.0, 0
     for r in csv.DictReader(open(path)):
         if kernel in r["Name"]:
-            return float(r["AverageNs"]) / 1e3, int(r["Calls"])
-    return None, 0
+            ns += float(r["AverageNs"]) * int(r["Calls"]); calls += int(r["Calls"])
+    return (ns / calls / 1e3, calls) if calls else (None, 0)
 
 
 for batch in (4096, 32768):
