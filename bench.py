@@ -316,7 +316,7 @@ def run_sdcfr(args, emit=True):
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[{3 if world == 1 else 4}]: SDCFR on MiniScopa, {batch} external-sampling traversals per player per iteration per GPU "
-                                      f"(k_sdcfr_traverse fills the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch {args.sdcfr_train_batch} per player on PyTorch-ROCm",
+                                      f"({'k_sdcfr_traverse fills' if per_visit_default else 'k_sdcfr_policy + k_sdcfr_walk fill'} the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch {args.sdcfr_train_batch} per player on PyTorch-ROCm",
                           "batch_per_gpu": batch, "global_batch": batch * world, "iterations": args.steps,
                           "parallelism": f"dp{world}" + (" + 1 gradient all-reduce of 55104 B per optimiser step (RCCL)" if world > 1 else ""),
                           "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)",
@@ -336,7 +336,7 @@ def run_sdcfr(args, emit=True):
                                     "advantage nets are frozen during a launch and a node's features depend on the tree node alone, so the deal's 1 653 decision nodes are "
                                     "evaluated once (MFMA tiles, k_sdcfr_policy) and the traversals walk the 26 KB policy table in LDS; HBM sees the 41 x 264 B memory rows per "
                                     "traversal, which is what bounds it.  Forward-per-visit form (bounds.mfma-f32): both nets as MFMA operand images in LDS, activations in "
-                                    "registers; SQ counter passes: profiles/r03_pmc_sq_sdcfr_traverse_b*.json"},
+                                    "registers; SQ counter passes: profiles/r03_pmc_sq_sdcfr_walk_b*.json (default form), profiles/r03_pmc_sq_sdcfr_traverse_b*.json"},
                "decision_visits": visits, "world": roster}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sdcfr(nets)

@@ -325,8 +325,9 @@ class DeepCFR:
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}
         self._iteration = 0
         self._eval_calls = 0
-        # the one-launch traversal kernel (forward pass on the matrix cores) is the faster path at every batch size measured
-        # (9.2e8 visits/s at B=4096, 1.55e9 at B=32768 against 3.2e8 / 9e8 for the ply-by-ply path); the latter stays selectable
+        # the library's traversal call (scopa_sdcfr_traverse_fused: the deal's decision nodes evaluated once per launch on the matrix cores, then the
+        # traversals as walks over that policy table) is the faster path at every batch size measured (1.6e10 visits/s at B=4096, 3.1-3.8e10 at
+        # B=32768 against 3.2e8 / 9e8 for the ply-by-ply path around a PyTorch forward); the latter stays selectable
         self.fused_traversal = True if fused_traversal is None else bool(fused_traversal)
         self.rank, self.world = int(rank), int(world)
         if self.world > 1:
@@ -392,8 +393,9 @@ class DeepCFR:
         return self._wpack
 
     def _traverse_batch_fused(self, player, batch, uniforms=None, sync=True):
-        """One launch: k_sdcfr_traverse (four traversals per wavefront, both MLPs in LDS, forward pass on the matrix cores).  sync=False leaves the launch on the solver's
-        stream (the training loop: the host goes on to draw the training batches while the kernel runs)."""
+        """The library's traversal call: k_sdcfr_policy + k_sdcfr_walk (every decision node of the deal evaluated once per launch, the traversals as
+        walks over that table), or k_sdcfr_traverse (a forward pass per visit in one launch) under `ctx.sdcfr_mode(1)` and for replayed draws.
+        sync=False leaves the launches on the solver's stream (the training loop: the host goes on to draw the training batches while they run)."""
         ctx, dev = self._engine.ctx, self.device
         mem = self.advantage_nets[player].buffer
         with torch.cuda.stream(self._stream), torch.no_grad():

@@ -13,5 +13,6 @@ python bench.py --gpus 1 --force-dist --exchange p2p --no-sdcfr > $O/bench_n1_di
 python bench.py --gpus 1 --force-dist --exchange rccl --no-sdcfr > $O/bench_n1_dist_path_rccl.json 2> $O/rccl.err || exit 1
 python bench.py --gpus 2 --share-gpu --no-sdcfr --steps 500 > $O/bench_2ranks_shared_gpu_spawn.json 2> $O/2r.err || exit 1
 for B in 4096 32768; do SCOPA_HIP_LIBRARY=$PWD/build/libscopa_stamps.so python tests/tools/sdcfr_stamps.py $B 10 2>&1 | grep -v amdgpu.ids; done > $O/sdcfr_stamps.txt
+for B in 64 4096 32768; do SCOPA_HIP_LIBRARY=$PWD/build/libscopa_stamps.so python tests/tools/sdwalk_stamps.py $B 10 2>&1 | grep -v "amdgpu.ids\|Estimated"; done > $O/sdwalk_stamps.txt
 python tests/tools/exact_cfr_timing.py > $O/exact_cfr_timing.json 2> $O/exact.err
 ls -la $O | head -30
