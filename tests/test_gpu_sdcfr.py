@@ -521,6 +521,46 @@ def test_traversal_on_other_deals_vs_oracle(ctx, golden, oracle, seed):
             np.testing.assert_allclose(vals.cpu().numpy(), ov, atol=ATOL, rtol=0)
 
 
+@pytest.mark.parametrize("shift", [-10.0, -0.35])
+def test_uniform_fallback_when_no_advantage_is_positive(ctx, golden, oracle, shift):
+    """positive_regret_policy gives an ALL-ZERO row when no legal action has a positive advantage (nets.py:93-101), and the sampler then
+    takes np.random.choice(legal_actions) -- uniform, numpy's float64 arithmetic on the same draw (deep_cfr.py:353-359); a traverser node
+    there has value 0.  With the head bias lowered by 10 every node is such a node (the walk kernel's thr[0] = ~0 branch at every opponent
+    visit); lowered by 0.35 about 30 % are (asserted: both branches run in one launch; with the fixture's nets as they are, none is).  All three forms against the oracle, and the walk
+    against the per-visit kernel bit for bit."""
+    import torch
+    B = 67
+    d, g = _solver_with_reference_nets(golden, batch=B)
+    d._iteration = 5
+    with torch.no_grad():
+        for a in d.advantage_nets:
+            a.net.head.bias.add_(shift)
+            a._weights_changed()
+    nets, t = _nets_flat(d), oracle.Tree(seed=42)
+    for trav in (0, 1):
+        feat, reg, mask, ovals, visits = t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=5, b0=0, nb=B)
+        with torch.no_grad():
+            adv = d.advantage_nets[trav].net(torch.from_numpy(feat).to("cuda:0")).cpu().numpy()
+        no_positive = ~((adv > 0) & (mask > 0)).any(1)    # traverser rows whose policy is the all-zero row (the opponent's nodes are the other traverser's rows)
+        if shift == -10.0:
+            assert no_positive.all() and (ovals == 0).all()   # every traverser node's value is 0 (:335 with an all-zero policy)
+        else:
+            assert 0.05 < no_positive.mean() < 0.95           # a mixture: both sampling branches run in one launch
+        got = {}
+        for name, fused, per_visit in (("table", True, 0), ("per-visit", True, 1), ("ply-by-ply", False, 0)):
+            d._engine.ctx.sdcfr_mode(per_visit)
+            mem = d.advantage_nets[trav].buffer
+            mem.total = 0
+            vals = d._traverse_batch(trav, B, fused=fused)
+            f, r, m = mem.rows(torch.arange(41 * B, device="cuda:0"))
+            assert np.array_equal(f.cpu().numpy(), feat) and np.array_equal(m.cpu().numpy(), mask), (name, trav)
+            np.testing.assert_allclose(r.cpu().numpy(), reg, atol=ATOL, rtol=0)
+            np.testing.assert_allclose(vals.cpu().numpy(), ovals, atol=ATOL, rtol=0)
+            got[name] = (r.clone(), vals.clone())
+        assert torch.equal(got["table"][0], got["per-visit"][0]) and torch.equal(got["table"][1], got["per-visit"][1])
+    d._engine.ctx.sdcfr_mode(0)
+
+
 def test_walk_and_per_visit_forms_are_bitwise_the_same(dcfr):
     """k_sdcfr_policy evaluates a node with the tile arithmetic of k_sdcfr_traverse (same MFMA sequence): the two forms of the one-call
     traversal produce the SAME BITS -- rows, regrets, root values -- at every task shape of the walk kernel (1, 2, 4, 8 traversals per
