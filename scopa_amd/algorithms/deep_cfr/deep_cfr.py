@@ -122,6 +122,7 @@ class AdvantageNetwork:
     def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4, memory_size=100000, use_graph=False):
         self.device = device
         self.use_graph = use_graph   # replay the optimiser step as one HIP graph (same ops, ~10x less launch overhead)
+        self.lean_step = True        # graph mode: the step with its backward pass written out (_step_lean: 28 kernels instead of ~45); False = autograd's step in the graph
         self._graphs = {}            # batch_size -> (graph, static index tensor, static loss tensor)
         self.num_actions = num_actions
         self.net = FlexibleNet(mode="mlp", input_shape=(input_dim,), output_dim=num_actions, mlp_hidden=HIDDEN,
@@ -210,6 +211,46 @@ class AdvantageNetwork:
         self.optimizer.step()
         return loss
 
+    def _lean_setup(self):
+        """Gradients of the six parameter tensors as views of ONE flat buffer (so the clip's norm and its scaling are one kernel each)."""
+        params = list(self.net.parameters())
+        flat = torch.zeros(sum(p.numel() for p in params), dtype=torch.float32, device=self.device)
+        off = 0
+        for p in params:
+            p.grad = flat[off:off + p.numel()].view_as(p)
+            off += p.numel()
+        self._lean = (flat, params)
+
+    def _step_lean(self, rows):
+        """The same optimiser step (deep_cfr.py:99-112) with the backward pass of the 34-128-64-16 MLP written out in PyTorch ops instead
+        of recorded by autograd -- graph mode only.  An Adam step on a 128-row batch is launch-bound (every kernel of it costs the 4-5 us
+        of a dependent launch whatever it does), so what counts is the NUMBER of kernels: autograd's step is ~45 (accumulate / fill /
+        per-tensor norm / foreach kernels included), this one 28.  Same arithmetic: MSE over all 16 outputs of pred * mask - target * mask
+        (mask is 0 / 1, so (pred - target) * mask is the same numbers), relu backward by aten's threshold_backward, clip_grad_norm_'s
+        min(1, 1 / (norm + 1e-6)) on the 2-norm of all gradients, the optimizer's own (fused) Adam."""
+        if getattr(self, "_lean", None) is None or self._lean[1][0].grad is None or self._lean[1][0].grad.data_ptr() != self._lean[0].data_ptr():
+            self._lean_setup()                                               # (first use, or autograd's step has replaced the .grad tensors since)
+        flat, (w1, b1, w2, b2, w3, b3) = self._lean[0], self._lean[1]
+        with torch.no_grad():
+            x, t, m = self.buffer.feat[rows], self.buffer.regret[rows], self.buffer.mask[rows]
+            h1 = torch._addmm_activation(b1, x, w1.t())                   # relu(x W1^T + b1), one kernel
+            h2 = torch._addmm_activation(b2, h1, w2.t())
+            y = torch.addmm(b3, h2, w3.t())
+            e = (y - t) * m
+            loss = (e * e).mean()
+            d = e * (2.0 / e.numel())                                       # dL/dy (m * m = m)
+            torch.mm(d.t(), h2, out=w3.grad)
+            torch.sum(d, 0, out=b3.grad)
+            dz2 = torch.ops.aten.threshold_backward(torch.mm(d, w3), h2, 0)
+            torch.mm(dz2.t(), h1, out=w2.grad)
+            torch.sum(dz2, 0, out=b2.grad)
+            dz1 = torch.ops.aten.threshold_backward(torch.mm(dz2, w2), h1, 0)
+            torch.mm(dz1.t(), x, out=w1.grad)
+            torch.sum(dz1, 0, out=b1.grad)
+            flat.mul_(torch.clamp(torch.reciprocal(torch.linalg.vector_norm(flat) + 1e-6), max=1.0))   # clip_grad_norm_(max_norm=1.0)
+        self.optimizer.step()
+        return loss
+
     def _train_graphed(self, n, batch_size, epochs):
         """The same step, captured once per batch size into a HIP graph and replayed with fresh row indices."""
         if batch_size not in self._graphs:
@@ -222,13 +263,14 @@ class AdvantageNetwork:
             saved_p = [p.detach().clone() for p in params]
             saved_s = {i: {k: v.clone() for k, v in self.optimizer.state[p].items() if torch.is_tensor(v)}
                        for i, p in enumerate(params) if p in self.optimizer.state}
+            step = self._step_lean if self.lean_step else self._step
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    self._step(rows)
+                    step(rows)
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                loss = self._step(rows)
+                loss = step(rows)
             with torch.no_grad():
                 for i, p in enumerate(params):
                     p.copy_(saved_p[i])

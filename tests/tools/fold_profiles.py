@@ -178,3 +178,9 @@ for batch in (4096, 32768):
     open(f"{P}/{tag}_sdcfr_kernel_stats_b{batch}.csv", "w").write(open(stats_csv).read())
     open(f"{P}/{tag}_bench_sdcfr_b{batch}_under_rocprof_stats.json", "w").write(json.dumps(line) + "\n")
     print(batch, "table", json.dumps(wd, indent=1), json.dumps({"bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1e3, "rows": rows_bytes}))
+
+# the names round 2's review asked for (the B = 4096 files: BASELINE configs[3]'s batch)
+import shutil
+for a, b in ((f"{P}/{tag}_pmc_sq_sdcfr_traverse_b4096.json", f"{P}/{tag}_pmc_sq_sdcfr_traverse.json"), (f"{P}/{tag}_sdcfr_kernel_stats_b4096.csv", f"{P}/{tag}_sdcfr_kernel_stats.csv")):
+    if os.path.exists(a):
+        shutil.copyfile(a, b)
