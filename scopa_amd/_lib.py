@@ -456,6 +456,10 @@ class Context:
                  "scopa_full_step_batch_host")
         return states
 
+    def full_step_batch(self, states_ptr, actions_ptr, decks_ptr, n):
+        """device pointers: states[n] (64 B each) <- step(states[i], decks[states[i].game], actions[i])"""
+        self._ck(self._L.scopa_full_step_batch(self._h, C.c_void_p(states_ptr), C.c_void_p(actions_ptr), C.c_void_p(decks_ptr), int(n)), "scopa_full_step_batch")
+
     def full_random_playouts(self, seeds):
         seeds = np.ascontiguousarray(seeds, np.int64)
         r2, plies = np.zeros(seeds.size, np.int8), np.zeros(seeds.size, np.int16)
@@ -499,6 +503,10 @@ class Context:
         actions = np.ascontiguousarray(actions, np.uint8)
         self._ck(self._L.scopa_team_step_batch_host(self._h, _ptr(states), _ptr(actions), states.size), "scopa_team_step_batch_host")
         return states
+
+    def team_step_batch(self, states_ptr, actions_ptr, n):
+        """device pointers: states[n] (40 B each) <- step(states[i], actions[i])"""
+        self._ck(self._L.scopa_team_step_batch(self._h, C.c_void_p(states_ptr), C.c_void_p(actions_ptr), int(n)), "scopa_team_step_batch")
 
     def team_random_playouts(self, seeds):
         """-> (reward x2 of team 0 per game, scopas[n][4] per seat)"""

@@ -16,13 +16,44 @@ using scopa::Mt;
 static_assert(sizeof(scopa_full_state) == 64, "scopa_full_state must be 64 bytes");
 
 
+// A lane per game, but the 64-byte states move between HBM and the lanes THROUGH LDS: a wavefront's 64 states are 4 KB of consecutive memory, which
+// it loads and stores as 256 sixteen-byte pieces in memory order (four instructions of one contiguous kilobyte each) and transposes in LDS (state j at
+// 80 j: the 16-byte pad keeps both the piece-order and the lane-order accesses free of bank conflicts).  A lane loading its own state directly reads
+// 16 bytes out of every 64: four (or, member by member, ten) instructions that each touch all 64 cache lines of the wavefront.
+constexpr int kFullLdsStride = 80;
 __global__ void __launch_bounds__(256)
 k_full_step_batch(scopa_full_state *__restrict__ states, const uint8_t *__restrict__ actions, const uint8_t *__restrict__ decks, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    scopa_full_state s = states[i];
-    step(s, decks + (size_t)s.game * 40, actions[i] % 40);
-    states[i] = s;
+    __shared__ __align__(16) unsigned char s_stage[4][64 * kFullLdsStride];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long w0 = ((long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63));   // first game of this wavefront
+    if (w0 >= n) return;
+    const long long left = n - w0;                                                       // games of this wavefront that exist (>= 1)
+    unsigned char *st = s_stage[wave];
+    const uint4 *src = reinterpret_cast<const uint4 *>(states + w0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = k * 64 + lane, j = c >> 2, part = c & 3;
+        if (j < left) *reinterpret_cast<uint4 *>(st + j * kFullLdsStride + part * 16) = src[c];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < left) {
+        uint4 raw[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint4 *>(st + lane * kFullLdsStride + k * 16);
+        scopa_full_state s;
+        memcpy(&s, raw, 64);
+        step(s, decks + (size_t)s.game * 40, actions[w0 + lane] % 40);
+        memcpy(raw, &s, 64);
+#pragma unroll
+        for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(st + lane * kFullLdsStride + k * 16) = raw[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4 *dst = reinterpret_cast<uint4 *>(states + w0);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const int c = k * 64 + lane, j = c >> 2, part = c & 3;
+        if (j < left) dst[c] = *reinterpret_cast<const uint4 *>(st + j * kFullLdsStride + part * 16);
+    }
 }
 
 // One lane per game: deal from the seed, then uniform-random legal play to the end (36 plies without no-ops).
@@ -40,7 +71,7 @@ k_full_random_playouts(const int64_t *__restrict__ seeds, long long n, int8_t *_
     state_init(s, deck, (uint32_t)i);
     int ply = 0;
     while (!s.terminal && ply < 200) {
-        const int p = s.step & 1, nl = s.nh[p];
+        const int p = s.step & 1, nl = nh_of(s, p);
         const scopa::philox_out x = scopa::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)ply, 32u, seed_lo, seed_hi);
         int k = (int)(scopa::u53(x.x0, x.x1) * (double)(nl > 0 ? nl : 1));
         k = k < nl - 1 ? k : (nl > 0 ? nl - 1 : 0);
@@ -110,6 +141,7 @@ int32_t scopa_full_state_infoset_string(const scopa_full_state *s, int32_t playe
 int32_t scopa_full_step_batch(scopa_ctx *ctx, scopa_full_state *d_states, const uint8_t *d_actions, const uint8_t *d_decks, int64_t n) {
     if (!ctx || n < 0 || (n && (!d_states || !d_actions || !d_decks))) return SCOPA_EINVAL;
     if (!n) return SCOPA_OK;
+    SC_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0, SCOPA_EINVAL, "scopa_full_step_batch: states must be 16-byte aligned");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_full_step_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, d_actions, d_decks, (long long)n);
     SC_HIP(ctx, hipGetLastError());

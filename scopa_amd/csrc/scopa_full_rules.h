@@ -17,16 +17,29 @@ namespace scopa_full {
 constexpr int kMaxTable = 20;  // 2 x 10 six-bit slots
 
 SCF_HD int rank_of(int c) { return c % 10 + 1; }
-SCF_HD int tab_get(const scopa_full_state &s, int i) { return (int)((s.table[i / 10] >> (6 * (i % 10))) & 63u); }
-SCF_HD void tab_set(scopa_full_state &s, int i, int c) {
-    const int sh = 6 * (i % 10);
-    s.table[i / 10] = (s.table[i / 10] & ~(63ull << sh)) | ((uint64_t)c << sh);
+// The two-element arrays of the state are never indexed with a run-time value: a run-time index into a struct member sends the whole state
+// to scratch memory on the device (84 scratch accesses per step in the first form of k_full_step_batch); a select between the two words keeps
+// it in registers.
+SCF_HD int tab_get(const scopa_full_state &s, int i) {
+    const int w = i >= 10;
+    return (int)(((w ? s.table[1] : s.table[0]) >> (6 * (i - 10 * w))) & 63u);
 }
-SCF_HD int hand_get(const scopa_full_state &s, int p, int i) { return (int)((s.hand[p] >> (6 * i)) & 63u); }
+SCF_HD void tab_set(scopa_full_state &s, int i, int c) {
+    const int w = i >= 10, sh = 6 * (i - 10 * w);
+    const uint64_t keep = ~(63ull << sh), put = (uint64_t)c << sh;
+    s.table[0] = w ? s.table[0] : (s.table[0] & keep) | put;
+    s.table[1] = w ? (s.table[1] & keep) | put : s.table[1];
+}
+SCF_HD uint32_t hand_of(const scopa_full_state &s, int p) { return p ? s.hand[1] : s.hand[0]; }
+SCF_HD int nh_of(const scopa_full_state &s, int p) { return p ? s.nh[1] : s.nh[0]; }
+SCF_HD int hand_get(const scopa_full_state &s, int p, int i) { return (int)((hand_of(s, p) >> (6 * i)) & 63u); }
+SCF_HD void cap_add(scopa_full_state &s, int p, uint64_t bits) { s.cap[0] |= p ? 0ull : bits; s.cap[1] |= p ? bits : 0ull; }   // (both words written: an if / else the compiler folds back into an indexed access)
 
 SCF_HD void deal_round(scopa_full_state &s, const uint8_t *deck) {  // 3 cards to player 0, then 3 to player 1
+#pragma unroll
     for (int p = 0; p < 2; p++) {
         uint32_t h = 0;
+#pragma unroll
         for (int i = 0; i < 3; i++) h |= (uint32_t)deck[s.deck_pos++] << (6 * i);
         s.hand[p] = h;
         s.nh[p] = 3;
@@ -42,27 +55,42 @@ SCF_HD void state_init(scopa_full_state &s, const uint8_t *deck, uint32_t game) 
     deal_round(s, deck);
 }
 
-// sums reachable with table cards 0..upto-1 (bit k = sum k), sums above 10 dropped
-SCF_HD uint32_t reach(const scopa_full_state &s, int upto) {
-    uint32_t r = 1u;
-    for (int i = 0; i < upto; i++) r |= (r << rank_of(tab_get(s, i))) & 0x7FFu;
-    return r;
-}
-
 // find_capture_combinations()[0] (:90-118): the first table card of the played rank if any; else the subset whose
 // membership mask is the SMALLEST integer among all subsets summing to the rank (the reference enumerates masks
 // 1, 2, 3, ... and play_card takes the first).  Smallest integer = decide bits from the top: leave card i out whenever
 // the remaining sum is still reachable with the cards below it.
+// pre[i] = sums reachable with table cards 0..i-1 (bit k = sum k, sums above 10 dropped), built ONCE in a pass up the table and read in
+// the pass down (first form: the reachable set recomputed from card 0 at every step of the way down -- quadratic in the table, behind
+// divisions by 10 for the slot of every card it touched).  Both loops are unrolled over the table's twenty slots, so slot shifts are
+// constants and pre[] / rk[] live in registers; iterations above every lane's table length are skipped by the guard.
 SCF_HD uint32_t capture_mask(const scopa_full_state &s, int target) {
     const int nt = s.nt;
-    for (int i = 0; i < nt; i++) if (rank_of(tab_get(s, i)) == target) return 1u << i;
-    if (nt == 0 || !((reach(s, nt) >> target) & 1u)) return 0u;
+    if (nt == 0) return 0u;
+    uint32_t pre[kMaxTable + 1];
+    int rk[kMaxTable];
+    pre[0] = 1u;
+    int match = -1;
+#pragma unroll
+    for (int i = 0; i < kMaxTable; i++) {
+        rk[i] = 0;
+        pre[i + 1] = pre[i];
+        if (i < nt) {
+            const int r = rank_of(tab_get(s, i));
+            rk[i] = r;
+            if (r == target && match < 0) match = i;
+            pre[i + 1] = pre[i] | ((pre[i] << r) & 0x7FFu);
+        }
+    }
+    if (match >= 0) return 1u << match;
+    if (!((pre[kMaxTable] >> target) & 1u)) return 0u;    // (pre[kMaxTable] == pre[nt])
     uint32_t mask = 0u;
     int rem = target;
-    for (int i = nt - 1; i >= 0 && rem > 0; i--) {
-        if ((reach(s, i) >> rem) & 1u) continue;  // still reachable without card i
-        mask |= 1u << i;
-        rem -= rank_of(tab_get(s, i));
+#pragma unroll
+    for (int i = kMaxTable - 1; i >= 0; i--) {
+        if (i < nt && rem > 0 && !((pre[i] >> rem) & 1u)) {   // not reachable without card i: it is in
+            mask |= 1u << i;
+            rem -= rk[i];
+        }
     }
     return mask;
 }
@@ -90,7 +118,11 @@ SCF_HD int popc64(uint64_t x) {
 
 SCF_HD void evaluate(scopa_full_state &s) {  // evaluate_game (:166-228)
     if (s.nt > 0 && s.last_capture != 0xFF)
-        for (int i = 0; i < s.nt; i++) s.cap[s.last_capture] |= 1ull << tab_get(s, i);
+    {
+        uint64_t left = 0ull;                                  // the cards left on the table go to the last capturer (:170-173)
+        for (int i = 0; i < s.nt; i++) left |= 1ull << tab_get(s, i);
+        cap_add(s, s.last_capture, left);
+    }
     int sc[2] = {0, 0};
     const int c0 = popc64(s.cap[0]), c1 = popc64(s.cap[1]);
     if (c0 != c1) sc[c0 > c1 ? 0 : 1]++;
@@ -108,21 +140,25 @@ SCF_HD void step(scopa_full_state &s, const uint8_t *deck, int action) {  // Ful
     if (s.terminal) return;
     const int p = s.step & 1;
     int pos = -1;
-    for (int i = s.nh[p] - 1; i >= 0; i--) if (hand_get(s, p, i) == action) pos = i;
+#pragma unroll
+    for (int i = 2; i >= 0; i--) if (i < nh_of(s, p) && hand_get(s, p, i) == action) pos = i;
     if (pos >= 0) {  // play_card (:120-150), capture_choice None
         const uint32_t cm = capture_mask(s, rank_of(action));
         if (cm) {
             scopa_full_state t = s;
             int nk = 0;
             t.table[0] = t.table[1] = 0;
-            for (int i = 0; i < s.nt; i++) {
-                const int c = tab_get(s, i);
-                if ((cm >> i) & 1u) t.cap[p] |= 1ull << c; else tab_set(t, nk++, c);
+#pragma unroll
+            for (int i = 0; i < kMaxTable; i++) {
+                if (i < s.nt) {
+                    const int c = tab_get(s, i);
+                    if ((cm >> i) & 1u) cap_add(t, p, 1ull << c); else tab_set(t, nk++, c);
+                }
             }
-            t.cap[p] |= 1ull << action;
+            cap_add(t, p, 1ull << action);
             t.nt = (uint8_t)nk;
             t.last_capture = (uint8_t)p;
-            if (nk == 0) t.scopas[p]++;
+            if (nk == 0) { t.scopas[0] = (uint8_t)(t.scopas[0] + (p ? 0 : 1)); t.scopas[1] = (uint8_t)(t.scopas[1] + (p ? 1 : 0)); }
             s = t;
         } else if (s.nt < kMaxTable) {
             tab_set(s, s.nt, action);
@@ -130,9 +166,9 @@ SCF_HD void step(scopa_full_state &s, const uint8_t *deck, int action) {  // Ful
         } else {
             s.flags |= 1u;  // table capacity exceeded (never seen in play: the reference's tables stay below 12)
         }
-        const uint32_t h = s.hand[p], lo = h & ((1u << (6 * pos)) - 1u), hi = (h >> (6 * (pos + 1))) << (6 * pos);
-        s.hand[p] = lo | hi;
-        s.nh[p]--;
+        const uint32_t h = hand_of(s, p), lo = h & ((1u << (6 * pos)) - 1u), hi = (h >> (6 * (pos + 1))) << (6 * pos);
+        s.hand[0] = p ? s.hand[0] : (lo | hi); s.hand[1] = p ? (lo | hi) : s.hand[1];
+        s.nh[0] = (uint8_t)(s.nh[0] - (p ? 0 : 1)); s.nh[1] = (uint8_t)(s.nh[1] - (p ? 1 : 0));
     }
     s.step++;
     if ((s.nh[0] | s.nh[1]) == 0) {
@@ -145,7 +181,7 @@ SCF_HD void step(scopa_full_state &s, const uint8_t *deck, int action) {  // Ful
 SCF_HD int legal(const scopa_full_state &s, int player, int out[3]) {  // openspiel_full_scopa.py:22-42
     if (s.terminal) return 0;
     if (player < 0) player = s.step & 1;
-    const int n = s.nh[player];
+    const int n = nh_of(s, player);
     for (int i = 0; i < n; i++) out[i] = hand_get(s, player, i);
     if (n == 0) { out[0] = 0; return 1; }
     return n;

@@ -37,6 +37,13 @@ SC_HD int subtree_size(int d) {  // nodes (incl. itself and terminals) below a n
 // ---- cards -----------------------------------------------------------------------------------------------
 // rank of card id c (MiniDeck.ranks, mini_scopa_game.py:18-23): 2 5 8 10 | 2 5 7 9 | 3 6 8 9 | 3 6 7 10
 constexpr uint64_t kRankLut = 0xA76398639752A852ull;
+SC_HD int sc_clz32(uint32_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __clz((int)x);
+#else
+    return __builtin_clz(x);
+#endif
+}
 SC_HD int card_rank(int c) { return (int)((kRankLut >> (4 * c)) & 15u); }
 SC_HD int nib(uint32_t list, int i) { return (int)((list >> (4 * i)) & 15u); }
 // remove nibble i from a nibble list, keeping the order of the rest
@@ -83,23 +90,20 @@ SC_HD uint32_t capture_mask(uint32_t table, int nt, int target) {
     for (int i = 0; i < 8; i++) {
         if (i >= nt) break;
         const int r = card_rank(nib(table, i));
-        const uint32_t fresh = (valid << r) & ~valid & upto;
-        if (fresh) {
-            uint64_t nlo = sub_lo;
-            uint32_t nhi = sub_hi;
-#pragma unroll
-            for (int s = 2; s <= 10; s++) {  // ranks are >= 2
-                if ((fresh >> s) & 1u) {
-                    const int q = s - r;  // q >= 0 because bit s of (valid << r) is set
-                    const uint32_t prev = q < 8 ? (uint32_t)((sub_lo >> (8 * q)) & 0xFFu) : ((sub_hi >> (8 * (q - 8))) & 0xFFu);
-                    const uint32_t now = prev | (1u << i);
-                    if (s < 8) nlo |= (uint64_t)now << (8 * s);
-                    else       nhi |= now << (8 * (s - 8));
-                }
-            }
-            sub_lo = nlo; sub_hi = nhi;
-            valid |= fresh;
+        uint32_t fresh = (valid << r) & ~valid & upto;
+        valid |= fresh;
+        uint64_t nlo = sub_lo;
+        uint32_t nhi = sub_hi;
+        while (fresh) {        // the sums this card reaches first: one or two as a rule (a walk over set bits instead of a test of every sum 2..10)
+            const int s = 31 - sc_clz32(fresh);   // any order: every fresh sum reads the state BEFORE this card (sub_lo / sub_hi) and writes its own byte
+            fresh &= ~(1u << s);
+            const int q = s - r;  // q >= 0 because bit s of (valid << r) is set
+            const uint32_t prev = q < 8 ? (uint32_t)((sub_lo >> (8 * q)) & 0xFFu) : ((sub_hi >> (8 * (q - 8))) & 0xFFu);
+            const uint32_t now = prev | (1u << i);
+            if (s < 8) nlo |= (uint64_t)now << (8 * s);
+            else       nhi |= now << (8 * (s - 8));
         }
+        sub_lo = nlo; sub_hi = nhi;
     }
     if (!((valid >> target) & 1u)) return 0u;
     return target < 8 ? (uint32_t)((sub_lo >> (8 * target)) & 0xFFu) : ((sub_hi >> (8 * (target - 8))) & 0xFFu);
