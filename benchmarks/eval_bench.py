@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""The on-device evaluator (evaluate_agent, vanilla_cfr.py:157-216 / mc_cfr.py:146-206): episodes of "tabular average policy vs
+uniform random, seats swapped at half time" advanced in lockstep, one lane per episode, one launch per ply (k_eval_tabular_step: 16-byte state
+in / out, 4-byte tree index in / out, 4-byte seat, a 32-byte policy row from cache = 44 algorithmic bytes per episode-ply).  Reports episodes/s and
+achieved GB/s of the eight launches, and the estimate next to the exact expectation from tree enumeration.
+    python benchmarks/eval_bench.py [--episodes 16777216]"""
+import argparse, json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--episodes", type=int, default=1 << 24)
+    ap.add_argument("--cfr-iterations", type=int, default=200)
+    a = ap.parse_args()
+    import torch
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.vanilla_cfr import CFRTrainer
+    from scopa_amd.algorithms.evaluation import evaluate_agent_device
+    tr = CFRTrainer(load_game("mini_scopa"))
+    tr.train(steps=a.cfr_iterations)
+    evaluate_agent_device(tr, 4096)                       # warm-up (kernel load)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    reward, stats = evaluate_agent_device(tr, a.episodes)
+    wall = time.perf_counter() - t0
+    ctx = tr._engine.ctx
+    n = a.episodes
+    pol = torch.as_tensor(np.ascontiguousarray(ctx.exploitability(return_policy=True)["policy"], np.float64), device="cuda:0")
+    states = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0"); idx = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+    seat = torch.as_tensor(np.array([0 if e < n / 2 else 1 for e in range(n)], np.int32), device="cuda:0")
+    ctx.eval_init_states(states.data_ptr(), n)
+    times = []
+    for ply in range(8):
+        torch.cuda.synchronize(); ctx.synchronize(); t0 = time.perf_counter()
+        ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, pol.data_ptr(), seat.data_ptr(), 16)
+        ctx.synchronize(); times.append(time.perf_counter() - t0)
+    k = sum(times)
+    print(json.dumps({"kernel": "k_eval_tabular_step", "episodes": n, "policy": f"average policy after {a.cfr_iterations} vanilla-CFR iterations", "reward_vs_random": reward,
+                      "reward_std_error": stats["reward_std_error"], "scopas_trained_vs_random": [stats["trained_avg"], stats["opponent_avg"]],
+                      "seconds_8_launches": k, "seconds_per_ply": times, "episodes_per_s_kernels": n / k, "episode_plies_per_s": 8 * n / k,
+                      "algorithmic_bytes_per_episode_ply": 44, "achieved_GBps": 8 * n * 44 / k / 1e9, "frac_of_hbm_peak": 8 * n * 44 / k / 1e9 / 8000.0,
+                      "evaluate_agent_device_wall_s": wall, "episodes_per_s_incl_host_statistics": n / wall,
+                      "reference_python_episodes_per_s": "~550 (500 episodes every 5 iterations dominate run_mccfr_experiment.py; BASELINE.md section 2)"}))
+
+
+if __name__ == "__main__":
+    main()
