@@ -40,7 +40,7 @@ def main():
                       "reward_std_error": stats["reward_std_error"], "scopas_trained_vs_random": [stats["trained_avg"], stats["opponent_avg"]],
                       "seconds_8_launches": k, "seconds_per_ply": times, "episodes_per_s_kernels": n / k, "episode_plies_per_s": 8 * n / k,
                       "algorithmic_bytes_per_episode_ply": 44, "achieved_GBps": 8 * n * 44 / k / 1e9, "frac_of_hbm_peak": 8 * n * 44 / k / 1e9 / 8000.0,
-                      "evaluate_agent_device_wall_s": wall, "episodes_per_s_incl_statistics": n / wall,
+                      "evaluate_agent_device_wall_s": wall, "episodes_per_s_incl_host_statistics": n / wall,
                       "reference_python_episodes_per_s": "~550 (500 episodes every 5 iterations dominate run_mccfr_experiment.py; BASELINE.md section 2)"}))
 
 
