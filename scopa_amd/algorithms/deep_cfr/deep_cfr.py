@@ -527,7 +527,7 @@ class DeepCFR:
         with torch.cuda.stream(self._stream), torch.no_grad():
             states = torch.zeros((n, 4), dtype=torch.int32, device=dev)  # 16-byte packed states
             ctx.eval_init_states(states.data_ptr(), n)
-            seat = torch.tensor([0 if e < n / 2 else 1 for e in range(n)], dtype=torch.int32, device=dev)
+            seat = (torch.arange(n, device=dev) >= (n + 1) // 2).to(torch.int32)     # episode e < n / 2: the trained agent sits in seat 0 (deep_cfr.py:386-389)
             feats = torch.empty((n, 34), dtype=torch.float32, device=dev)
             mask = torch.empty((n, 16), dtype=torch.float32, device=dev)
             for ply in range(8):
@@ -536,7 +536,7 @@ class DeepCFR:
                 ctx.eval_step(states.data_ptr(), n, probs.data_ptr(), seat.data_ptr(), 8, (self._eval_calls << 4) | ply)
             raw = states.cpu().numpy().view(_lib.STATE_DTYPE).reshape(-1)
         self._stream.synchronize()
-        seat_h = np.array([0 if e < n / 2 else 1 for e in range(n)])
+        seat_h = (np.arange(n) >= (n + 1) // 2).astype(np.int64)
         r = raw["ncap"].astype(np.int64) + 2 * raw["scopas"].astype(np.int64)
         total = r.sum(1)
         rewards = np.where(total[:, None] == 0, 0.0, r - total[:, None] / 2.0)   # evaluate_game (mini_scopa_game.py:106-114)
