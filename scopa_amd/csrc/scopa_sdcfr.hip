@@ -1005,15 +1005,12 @@ struct alignas(16) SdWalk {       // per wavefront: T traversals in flight, a fr
     uint32_t xb[T][41];           // feature bits of every traverser node BY MEMORY-ROW RANK: features and masks of the task's rows are written from
                                   // here in one sweep of consecutive addresses (a lane per row piece, rows in memory order) instead of a lane per row
     union alignas(16) {
-        struct {
-            float stage[32][16];      // regrets of 32 traverser nodes on their way to memory: written a lane per row, stored four lanes per row (whole 64-byte rows
-            uint32_t stage_row[32];   // per store instruction, 16 of them, instead of 64 rows x 16 bytes), with the rows' ring positions
-        };
+        float regs[T * 41][16];            // way back: the task's regret rows by memory-row rank, assembled a lane per row, stored in one sweep of consecutive addresses
         unsigned long long draw[T * 40];   // forward pass only: the task's opponent draws N (u = N * 2^-53), all of them taken before the walk in full 64-lane rounds
     };
 };
 struct __attribute__((aligned(8))) SdF4A8 { float x, y, z, w; };   // sixteen bytes of a 136-byte feature row: rows alternate between 16- and 8-byte alignment
-__host__ __device__ constexpr int sd_walk_waves(int T) { return T <= 2 ? 12 : 16; }   // wavefronts per workgroup; T <= 2: two workgroups per compute unit (26 KB of tables + 12 x 3 KB each), six wavefronts per SIMD
+__host__ __device__ constexpr int sd_walk_waves(int T) { return T == 1 ? 12 : T == 2 ? 16 : T == 4 ? 8 : 4; }   // wavefronts per workgroup by LDS (a task's regret rows: 2.6 KB per traversal); T = 1: two workgroups per compute unit
 }  // namespace
 
 #ifdef SCOPA_WALK_STAMPS   // development build only: the same stamps for wavefront 0 of workgroup 0 of k_sdcfr_walk
@@ -1028,7 +1025,7 @@ __device__ unsigned long long g_wk_stamps[16];   // 0 staging the tables | 1 dra
 // plies sample) is then a constant, the frontier loops have known trip counts, and the scalar selects and branches that decided them per ply at run time
 // -- about 600 scalar and 250 vector instructions per traversal of a chain that a lone wavefront executes at one instruction per 8 clocks -- are gone.
 template <int T, int TR>
-__global__ void __launch_bounds__(sd_walk_waves(T) * 64, T <= 2 ? 6 : 4)   // (second figure, HIP: wavefronts per SIMD to stay eligible for: two workgroups of twelve -- at most 80 registers)
+__global__ void __launch_bounds__(sd_walk_waves(T) * 64, T == 1 ? 6 : 4)   // (second figure, HIP: wavefronts per SIMD to stay eligible for: two workgroups of twelve -- at most 80 registers)
 k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_payoff, const float4 *__restrict__ g_pol, const unsigned long long *__restrict__ g_thr,
              int batch,
              float *__restrict__ mem_feat, float *__restrict__ mem_regret, float *__restrict__ mem_mask, uint32_t capacity, uint32_t write_base,
@@ -1184,8 +1181,6 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
 #pragma unroll
             for (int r = 0; r * 64 < T * width; r++) {
             const int f0 = r * 64, f = f0 + lane;
-            uint32_t rrow = 0xFFFFFFFFu, hand_l = 0;                        // this lane's regret row of the round: ring position (none: beyond the frontier / a dead traversal)
-            float rv_l[4] = {0.f, 0.f, 0.f, 0.f}, ri_l = 0.f;
             if (f < T * width) {
                 int t = 0;
 #pragma unroll
@@ -1215,41 +1210,24 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
 #pragma unroll
                     for (int k = 0; k < 4; k++) if (k < nl) rv[k] = rv[k] / den;
                 }
-                uint32_t row = row0 + 41u * (uint32_t)t + (uint32_t)sd_rank(m, j);
-                row = row >= capacity ? row - capacity : row;
-                SD_WALK_ROWMASK(row);
-                rrow = t < n_live ? row : 0xFFFFFFFFu;
-                hand_l = hand; ri_l = ri;
+                // the row is assembled in LDS at its rank within the task -- sixteen times the illegal slots' value, then the legal cards' values over it (a
+                // wavefront's LDS writes land in program order) -- and leaves for memory with the task's other regret rows in ONE sweep after the pass
+                float *srow = &ws.regs[41 * t + sd_rank(m, j)][0];
 #pragma unroll
-                for (int k = 0; k < 4; k++) rv_l[k] = rv[k];
-            }
-            // the round's regret rows through the stage, 32 at a time: lane L puts its row down -- sixteen times the illegal slots' value, then the legal cards'
-            // values over it (a wavefront's LDS writes land in program order) -- then four lanes store each row
-            const int n_round = T * width - f0;                             // frontier positions of this round (wavefront-uniform)
+                for (int i = 0; i < 4; i++) reinterpret_cast<float4 *>(srow)[i] = make_float4(ri, ri, ri, ri);
 #pragma unroll
-            for (int half = 0; half < 2; half++) {
-                if (half * 32 >= n_round) break;
-                if ((lane >> 5) == half) {
-                    ws.stage_row[lane & 31] = rrow;
-                    if (rrow != 0xFFFFFFFFu) {
-                        float *srow = &ws.stage[lane & 31][0];
-#pragma unroll
-                        for (int i = 0; i < 4; i++) reinterpret_cast<float4 *>(srow)[i] = make_float4(ri_l, ri_l, ri_l, ri_l);
-#pragma unroll
-                        for (int k = 0; k < 4; k++) if (k < nl) srow[(hand_l >> (4 * k)) & 15u] = rv_l[k];
-                    }
-                }
-                sd_order();
-#pragma unroll
-                for (int it = 0; it < 2; it++) {
-                    const int e = it * 64 + lane, rl = e >> 2, i = e & 3;
-                    const uint32_t row = ws.stage_row[rl];
-                    if (row != 0xFFFFFFFFu) reinterpret_cast<float4 *>(mem_regret + (size_t)row * 16)[i] = reinterpret_cast<const float4 *>(&ws.stage[rl][0])[i];
-                }
-                sd_order();
+                for (int k = 0; k < 4; k++) if (k < nl) srow[(hand >> (4 * k)) & 15u] = rv[k];
             }
             }
             sd_order();
+        }
+        // the task's regret rows: 41 n_live rows of 64 bytes, consecutive in the ring like its feature and mask rows, four lanes to a row
+        for (int e = lane; e < n_live * 41 * 4; e += 64) {
+            const int rr = e >> 2, i = e & 3;
+            uint32_t row = row0 + (uint32_t)rr;
+            row = row >= capacity ? row - capacity : row;
+            SD_WALK_ROWMASK(row);
+            reinterpret_cast<float4 *>(mem_regret + (size_t)row * 16)[i] = reinterpret_cast<const float4 *>(&ws.regs[rr][0])[i];
         }
         if (lane < n_live) root_values[tb0 + lane] = ws.val[lane];
         sd_order();
@@ -1336,12 +1314,13 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
         hipLaunchKernelGGL(k_sdcfr_policy, dim3(kPolicyTiles), dim3(kPolicyWaves * 64), 0, ctx->stream,
                            (const uint2 *)ctx->d_sdnode, d_image, (float4 *)ctx->d_sdpol, d_thr);
         SC_HIP(ctx, hipGetLastError());
-        // traversals per wavefront: 8 would use the 64 lanes best (frontiers 8 .. 192 wide), but the walk is a chain of LDS round trips and
-        // float64 sampling arithmetic per ply, and more, smaller tasks hide it better: measured 40.7 / 120.9 us (policy + walk) at 4096 /
-        // 32768 traversals with 2 per wavefront, 51.8 / 126.5 with 8
+        // traversals per wavefront: more would use the 64 lanes better (frontiers T .. 24 T wide), but a task keeps its regret rows in LDS until its last
+        // ply (2.6 KB per traversal), and ONE traversal per wavefront is what lets two workgroups of twelve wavefronts share a compute unit: measured
+        // (policy + walk, one call) 24.2 / 86.2 us at 4096 / 32768 traversals with 1, 28.0 / 85.1 with 2 (one workgroup of sixteen per compute unit)
         int Tw = ctx->sdcfr_tile_t;
-        if (Tw != 1 && Tw != 2 && Tw != 4 && Tw != 8) Tw = 2;
-        const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < 2 * ctx->n_cus ? tasks_w : 2 * ctx->n_cus;   // two workgroups per compute unit
+        if (Tw != 1 && Tw != 2 && Tw != 4 && Tw != 8) Tw = 1;
+        const int wgs_per_cu = Tw == 1 ? 2 : 1;
+        const int tasks_w = (batch + Tw - 1) / Tw, grid_w = tasks_w < wgs_per_cu * ctx->n_cus ? tasks_w : wgs_per_cu * ctx->n_cus;
         const size_t wave_w = Tw == 8 ? sizeof(SdWalk<8>) : Tw == 4 ? sizeof(SdWalk<4>) : Tw == 2 ? sizeof(SdWalk<2>) : sizeof(SdWalk<1>);
         const size_t lds_w = (size_t)kWalkTravNodes * (sizeof(float4) + sizeof(uint2)) + (size_t)kWalkThr * sizeof(unsigned long long) + (size_t)kTerminal + (size_t)sd_walk_waves(Tw) * wave_w;
         SC_REQUIRE(ctx, lds_w + 64 <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "scopa_sdcfr_traverse_fused: LDS (walk kernel)");
