@@ -123,7 +123,7 @@ class AdvantageNetwork:
         self.device = device
         self.use_graph = use_graph   # replay the optimiser step as one HIP graph (same ops, ~10x less launch overhead)
         self.lean_step = True        # graph mode: the step with its backward pass written out (_step_lean: 28 kernels instead of ~45); False = autograd's step in the graph
-        self._graphs = {}            # batch_size -> (graph, static index tensor, static loss tensor)
+        self._graphs = {}            # (batch_size, epochs) -> (graph of all the epochs' steps, static index tensor [epochs, batch], static loss tensor [epochs])
         self.num_actions = num_actions
         self.net = FlexibleNet(mode="mlp", input_shape=(input_dim,), output_dim=num_actions, mlp_hidden=HIDDEN,
                                mlp_act="relu", mlp_norm="none", mlp_dropout=0.0).to(device)
@@ -252,13 +252,16 @@ class AdvantageNetwork:
         return loss
 
     def _train_graphed(self, n, batch_size, epochs):
-        """The same step, captured once per batch size into a HIP graph and replayed with fresh row indices."""
-        if batch_size not in self._graphs:
-            rows = torch.zeros(batch_size, dtype=torch.long, device=self.device)
+        """The same steps -- all `epochs` of a train() call -- captured once per (batch size, epochs) into ONE HIP graph and replayed with
+        fresh row indices: one upload of the [epochs, batch] index batches, one replay, one read-back of the mean loss."""
+        key = (batch_size, epochs)
+        if key not in self._graphs:
+            rows = torch.zeros((epochs, batch_size), dtype=torch.long, device=self.device)
+            losses = torch.zeros(epochs, dtype=torch.float32, device=self.device)
             side = torch.cuda.Stream(device=self.device)
             side.wait_stream(torch.cuda.current_stream())
-            # warm-up + capture run real optimiser steps: snapshot parameters and Adam state BY VALUE first and restore
-            # them IN PLACE afterwards (the graph keeps pointing at these very tensors), so capturing changes nothing
+            # warm-up runs real optimiser steps: snapshot parameters and Adam state BY VALUE first and restore them IN PLACE afterwards
+            # (the graph keeps pointing at these very tensors), so capturing changes nothing
             params = list(self.net.parameters())
             saved_p = [p.detach().clone() for p in params]
             saved_s = {i: {k: v.clone() for k, v in self.optimizer.state[p].items() if torch.is_tensor(v)}
@@ -266,11 +269,12 @@ class AdvantageNetwork:
             step = self._step_lean if self.lean_step else self._step
             with torch.cuda.stream(side):
                 for _ in range(3):
-                    step(rows)
+                    step(rows[0])
             torch.cuda.current_stream().wait_stream(side)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
-                loss = step(rows)
+                for e in range(epochs):
+                    losses[e].copy_(step(rows[e]))
             with torch.no_grad():
                 for i, p in enumerate(params):
                     p.copy_(saved_p[i])
@@ -280,14 +284,10 @@ class AdvantageNetwork:
                                 v.copy_(saved_s[i][k])
                             else:
                                 v.zero_()   # a fresh optimiser: moments and step count start at zero
-            self._graphs[batch_size] = (g, rows, loss)
-        g, rows, loss = self._graphs[batch_size]
-        rows_all = self._sample_rows(n, batch_size, epochs)
-        losses = torch.empty(epochs, dtype=loss.dtype, device=self.device)
-        for e in range(epochs):
-            rows.copy_(rows_all[e])
-            g.replay()
-            losses[e].copy_(loss)
+            self._graphs[key] = (g, rows, losses)
+        g, rows, losses = self._graphs[key]
+        rows.copy_(self._sample_rows(n, batch_size, epochs))
+        g.replay()
         return float(losses.sum().item()) / epochs
 
 

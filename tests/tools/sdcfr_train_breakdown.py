@@ -30,15 +30,13 @@ for lean in (True, False):
             a._rng.seed(42); a._rng.shuffle(list(range(16)))
             rows_all = a._sample_rows(n, 128, E)
         torch.cuda.synchronize(); t_sample = (time.perf_counter() - t0) / 20
-        g, rows, loss = a._graphs[128]
+        g, rows, losses = a._graphs[(128, E)]
         t0 = time.perf_counter()
         for _ in range(20):
-            for e in range(E):
-                g.replay()
+            g.replay()
         torch.cuda.synchronize(); t_replay = (time.perf_counter() - t0) / 20 / E
         t0 = time.perf_counter()
         for _ in range(20):
-            for e in range(E):
-                rows.copy_(rows_all[e]); g.replay()
+            rows.copy_(rows_all); g.replay()
         torch.cuda.synchronize(); t_replay_copy = (time.perf_counter() - t0) / 20 / E
-    print(f"lean={lean}: train({E} epochs) {1e6 * t_train:.0f} us; drawing + uploading the index batches {1e6 * t_sample:.0f} us; one graph replay {1e6 * t_replay:.0f} us; with its index copy {1e6 * t_replay_copy:.0f} us")
+    print(f"lean={lean}: train({E} epochs) {1e6 * t_train:.0f} us; drawing + uploading the index batches {1e6 * t_sample:.0f} us; the graph of all epochs, per epoch {1e6 * t_replay:.0f} us; with its index copy {1e6 * t_replay_copy:.0f} us")
