@@ -204,7 +204,8 @@ def run_sdcfr(args, emit=True):
     torch.manual_seed(0)
     _so = os.dup(1)
     os.dup2(2, 1)                                              # the constructor prints the reference's "Estimated input dimension" line
-    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=batch, rank=rank, world=world, graph_training=(world == 1))
+    d = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=batch, rank=rank, world=world, graph_training=(world == 1),
+                train_backend=(args.sdcfr_train_backend if world == 1 else "torch"))
     sys.stdout.flush()
     os.dup2(_so, 1)
     ctx = d._engine.ctx
@@ -279,6 +280,30 @@ def run_sdcfr(args, emit=True):
         d.kernel_events = None
         ctx.sdcfr_mode(0)
     per_visit_default = os.environ.get("SCOPA_SDCFR_MODE") == "1"
+    # beside the timed region too: the same iteration with the OPT-IN hand-written optimiser step (train_backend="hip": two launches per Adam step
+    # instead of PyTorch's thirty) -- the default trains on PyTorch-ROCm, as north_star asks
+    hip_train = None
+    if world == 1 and args.sdcfr_train_backend == "torch" and args.sdcfr_train_batch % 16 == 0:
+        _so2 = os.dup(1); os.dup2(2, 1)
+        d2 = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=batch, train_backend="hip")
+        sys.stdout.flush(); os.dup2(_so2, 1)
+
+        def step2():
+            for p in range(2):
+                d2._traverse_batch(p, batch, sync=False)
+                with torch.cuda.stream(d2._stream):
+                    d2.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
+                d2._stream.synchronize()
+            d2._iteration += 1
+        for _ in range(10):
+            step2()
+        torch.cuda.synchronize(); t2 = time.perf_counter()
+        for _ in range(20):
+            step2()
+        torch.cuda.synchronize()
+        hip_train = {"ms_per_step": 1e3 * (time.perf_counter() - t2) / 20, "iterations_timed": 20,
+                     "what": "the same iteration with train_backend='hip' (scopa_sdcfr_train_steps: k_sdcfr_train_grad + k_sdcfr_train_adam per Adam step; tests hold it to the PyTorch step at 2e-5)"}
+        del d2
     out = None
     if rank == 0:
         kern_s = 1e-3 * sum(kern_ms) / max(len(kern_ms), 1)              # one launch = one player's batch
@@ -316,10 +341,10 @@ def run_sdcfr(args, emit=True):
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
                "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "config": {"workload": f"BASELINE configs[{3 if world == 1 else 4}]: SDCFR on MiniScopa, {batch} external-sampling traversals per player per iteration per GPU "
-                                      f"({'k_sdcfr_traverse fills' if per_visit_default else 'k_sdcfr_policy + k_sdcfr_walk fill'} the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch {args.sdcfr_train_batch} per player on PyTorch-ROCm",
+                                      f"({'k_sdcfr_traverse fills' if per_visit_default else 'k_sdcfr_policy + k_sdcfr_walk fill'} the device memory ring), advantage MLP 34-128-64-16 f32, {epochs} Adam steps x batch {args.sdcfr_train_batch} per player on {'PyTorch-ROCm' if args.sdcfr_train_backend == 'torch' or world > 1 else 'the hand-written step'}",
                           "batch_per_gpu": batch, "global_batch": batch * world, "iterations": args.steps,
                           "parallelism": f"dp{world}" + (" + 1 gradient all-reduce of 55104 B per optimiser step (RCCL)" if world > 1 else ""),
-                          "training": "HIP-graph-replayed optimiser step" if world == 1 else "eager (gradient all-reduce between backward and step)",
+                          "training": ("hand-written optimiser step (train_backend='hip')" if args.sdcfr_train_backend == "hip" else "HIP-graph-replayed PyTorch optimiser step") if world == 1 else "eager (gradient all-reduce between backward and step)",
                           "replicas_bit_identical": replicas_identical, "shared_gpu_rehearsal": bool(args.share_gpu)},
                "traversal_only": {"visits_per_s_per_gpu": v_launch / kern_s, "kernel_avg_us": 1e6 * kern_s, "launches_timed": len(kern_ms),
                                   "form": "forward pass per visit (k_sdcfr_traverse)" if per_visit_default else "policy table per launch + walks (k_sdcfr_policy + k_sdcfr_walk)",
@@ -338,6 +363,8 @@ def run_sdcfr(args, emit=True):
                                     "traversal, which is what bounds it.  Forward-per-visit form (bounds.mfma-f32): both nets as MFMA operand images in LDS, activations in "
                                     "registers; SQ counter passes: profiles/r03_pmc_sq_sdcfr_walk_b*.json (default form), profiles/r03_pmc_sq_sdcfr_traverse_b*.json"},
                "decision_visits": visits, "world": roster}
+        if hip_train is not None:
+            out["with_hip_training_step"] = hip_train
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_sdcfr(nets)
             out["gpu_over_cpu_1core_traversal_only"] = out["traversal_only"]["visits_per_s_per_gpu"] / out["cpu_baseline"]["value"]
@@ -371,6 +398,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=None, help="untimed iterations (default 100 for mccfr, 3 for sdcfr)")
     ap.add_argument("--batch", type=int, default=4096, help="traversals per traverser per GPU per iteration")
     ap.add_argument("--sdcfr-epochs", type=int, default=5, help="Adam steps per player per iteration (sdcfr workload)")
+    ap.add_argument("--sdcfr-train-backend", choices=("torch", "hip"), default="torch", help="sdcfr workload: the optimiser step on PyTorch-ROCm (default) or the opt-in hand-written step")
     ap.add_argument("--sdcfr-train-batch", type=int, default=128, help="rows per Adam step (sdcfr workload; the reference trains on 128, SURVEY 8d also asks for a scaled setting of 4096)")
     ap.add_argument("--regions", type=int, default=REGIONS, help="how many times the --steps region is timed (median reported)")
     ap.add_argument("--pre-phase-s", type=float, default=PRE_PHASE_S, help="seconds of untimed iterations before anything is timed (0 for profiler passes that count every dispatch)")

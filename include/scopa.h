@@ -221,6 +221,19 @@ int32_t scopa_sdcfr_mode(scopa_ctx *ctx, int32_t forward_per_visit);
  * the forward-per-visit kernel) and wavefronts that share a task's tiles in the latter (0 = the library's choice, 1..3).  Results
  * do not depend on either. */
 int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t wavefronts_per_task);
+/* One optimiser step of an advantage net WITHOUT PyTorch kernels (AdvantageNetwork.train, deep_cfr.py:99-112): gather the n_rows ring rows d_rows[],
+ * forward 34-128-64-16, MSE(pred * mask, target * mask) over n_rows x 16, backward, clip_grad_norm_(1.0), Adam(lr, betas 0.9 / 0.999, eps 1e-8).
+ * OPT-IN (the default trains with PyTorch-ROCm): DeepCFR(train_backend="hip").  d_w1 .. d_b3 are the net's own tensors (torch layout W[out][in]),
+ * updated in place; d_state = [2][13776] float (exp_avg, exp_avg_sq in net.parameters() order), zero before the first step; step = 1, 2, ...;
+ * the step's loss is ADDED to d_loss[0].  n_rows: a multiple of 16.  Two launches (k_sdcfr_train_grad, k_sdcfr_train_adam), no host synchronisation. */
+int32_t scopa_sdcfr_train_params(void);   /* 13 776 */
+/* n_steps consecutive steps in one call: step e trains on d_rows[e * n_rows .. (e + 1) * n_rows) with step number first_step + e (the epochs of one train() call) */
+int32_t scopa_sdcfr_train_steps(scopa_ctx *ctx, const int64_t *d_rows, int32_t n_rows, int32_t n_steps, const float *d_feat, const float *d_regret, const float *d_mask,
+                                int64_t capacity, float *d_w1, float *d_b1, float *d_w2, float *d_b2, float *d_w3, float *d_b3, float *d_state,
+                                int32_t first_step, float lr, float *d_loss);
+int32_t scopa_sdcfr_train_step(scopa_ctx *ctx, const int64_t *d_rows, int32_t n_rows, const float *d_feat, const float *d_regret, const float *d_mask,
+                               int64_t capacity, float *d_w1, float *d_b1, float *d_w2, float *d_b2, float *d_w3, float *d_b3, float *d_state,
+                               int32_t step, float lr, float *d_loss);
 /* features / masks of arbitrary device-resident states for the player to move (DeepCFR.get_policy, :497-504) */
 int32_t scopa_features_from_states(scopa_ctx *ctx, const scopa_state *d_states, int64_t n, float *d_feats, float *d_mask);
 /* batched evaluation episodes (evaluate_vs_random :367-429; evaluate_agent vanilla_cfr.py:157-216): n copies of the deal's

@@ -26,7 +26,7 @@ SYMBOLS = [
     "scopa_visited_get", "scopa_cfr_exact_iterate", "scopa_cfr_exact_traverse", "scopa_cfr_exact_mode", "scopa_cfr_exact_traverse_from", "scopa_mccfr_replay", "scopa_mccfr_seed",
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_mccfr_graph_mode", "scopa_debug_lds_limit", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
-    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_sdcfr_mode", "scopa_features_from_states",
+    "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_sdcfr_mode", "scopa_sdcfr_train_params", "scopa_sdcfr_train_step", "scopa_sdcfr_train_steps", "scopa_features_from_states",
     "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
     "scopa_multi_cfr_exact_iterate_lanes", "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
@@ -133,6 +133,9 @@ def lib():
         "scopa_sdcfr_image_floats": (i32, []),
         "scopa_sdcfr_pack_weights": (i32, [vp, i32, vp, vp, vp, vp, vp, vp, vp]),
         "scopa_sdcfr_tuning": (i32, [vp, i32, i32]),
+        "scopa_sdcfr_train_params": (i32, []),
+        "scopa_sdcfr_train_step": (i32, [vp, vp, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, C.c_float, vp]),
+        "scopa_sdcfr_train_steps": (i32, [vp, vp, i32, i32, vp, vp, vp, i64, vp, vp, vp, vp, vp, vp, vp, i32, C.c_float, vp]),
         "scopa_sdcfr_mode": (i32, [vp, i32]),
         "scopa_features_from_states": (i32, [vp, vp, i64, vp, vp]),
         "scopa_eval_init_states": (i32, [vp, vp, i64]),
@@ -418,6 +421,18 @@ class Context:
     def sdcfr_tuning(self, traversals_per_task=0, wavefronts_per_task=0):
         """experiments: task shape of the fused traversal kernel (0 = the library's choice); results do not depend on it"""
         self._ck(self._L.scopa_sdcfr_tuning(self._h, traversals_per_task, wavefronts_per_task), "scopa_sdcfr_tuning")
+
+    def sdcfr_train_steps(self, rows_ptr, n_rows, n_steps, feat_ptr, regret_ptr, mask_ptr, capacity, param_ptrs, state_ptr, first_step, lr, loss_ptr):
+        """n_steps consecutive optimiser steps (the epochs of one train() call) on rows [n_steps][n_rows]"""
+        self._ck(self._L.scopa_sdcfr_train_steps(self._h, C.c_void_p(rows_ptr), int(n_rows), int(n_steps), C.c_void_p(feat_ptr), C.c_void_p(regret_ptr), C.c_void_p(mask_ptr),
+                                                 int(capacity), *(C.c_void_p(p) for p in param_ptrs), C.c_void_p(state_ptr), int(first_step), float(lr),
+                                                 C.c_void_p(loss_ptr)), "scopa_sdcfr_train_steps")
+
+    def sdcfr_train_step(self, rows_ptr, n_rows, feat_ptr, regret_ptr, mask_ptr, capacity, param_ptrs, state_ptr, step, lr, loss_ptr):
+        """one optimiser step of an advantage net in two HIP launches (include/scopa.h); param_ptrs = (w1, b1, w2, b2, w3, b3) device pointers"""
+        self._ck(self._L.scopa_sdcfr_train_step(self._h, C.c_void_p(rows_ptr), int(n_rows), C.c_void_p(feat_ptr), C.c_void_p(regret_ptr), C.c_void_p(mask_ptr),
+                                                int(capacity), *(C.c_void_p(p) for p in param_ptrs), C.c_void_p(state_ptr), int(step), float(lr),
+                                                C.c_void_p(loss_ptr)), "scopa_sdcfr_train_step")
 
     def sdcfr_traverse_fused(self, traverser, batch, weights_ptr, mem_feat_ptr, mem_regret_ptr, mem_mask_ptr, capacity, write_base,
                              root_values_ptr, uniforms_ptr, iteration, b0):

@@ -119,8 +119,16 @@ def reference_sample_stream(n, k, calls, rng=None):
 class AdvantageNetwork:
     """Advantage net + Adam + memory for one player (deep_cfr.py:24-116)."""
 
-    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4, memory_size=100000, use_graph=False):
+    def __init__(self, input_dim, num_actions, device="cuda", lr=5e-4, memory_size=100000, use_graph=False, train_backend="torch"):
         self.device = device
+        # "torch" (default; north_star: the advantage MLP trains on PyTorch-ROCm) or "hip": the whole optimiser step in two hand-written launches
+        # (scopa_sdcfr_train_step: forward, loss, backward on the matrix cores; clip + Adam), on the same tensors, opt-in
+        if train_backend not in ("torch", "hip"):
+            raise ValueError("train_backend must be 'torch' or 'hip'")
+        self.train_backend = train_backend
+        self._ctx = None             # the solver's library context (set by DeepCFR): the hip backend launches on its stream
+        self._hip = None             # hip backend: (moment buffer [2][13776], running loss [1]) and the step count
+        self._hip_step = 0
         self.use_graph = use_graph   # replay the optimiser step as one HIP graph (same ops, ~10x less launch overhead)
         self.lean_step = True        # graph mode: the step with its backward pass written out (_step_lean: 28 kernels instead of ~45); False = autograd's step in the graph
         self._graphs = {}            # (batch_size, epochs) -> (graph of all the epochs' steps, static index tensor [epochs, batch], static loss tensor [epochs])
@@ -183,6 +191,8 @@ class AdvantageNetwork:
         self._rng.seed(42)
         self._rng.shuffle(list(range(16)))
         self._weights_changed()
+        if self.train_backend == "hip" and self.grad_sync is None and batch_size % 16 == 0 and batch_size >= 16:
+            return self._train_hip(n, batch_size, epochs)
         if self.use_graph and self.grad_sync is None:
             return self._train_graphed(n, batch_size, epochs)
         rows_all = self._sample_rows(n, batch_size, epochs)
@@ -190,6 +200,27 @@ class AdvantageNetwork:
         for e in range(epochs):
             total_loss += self._step(rows_all[e]).item()
         return total_loss / epochs
+
+    def _train_hip(self, n, batch_size, epochs):
+        """The same steps through scopa_sdcfr_train_step (two launches per step, none of them PyTorch's): the net's own parameter tensors are
+        updated in place, Adam's moments live in one [2][13776] buffer.  Ragged batches (not a multiple of 16 rows) and N > 1 take the PyTorch path."""
+        if self._ctx is None:
+            raise RuntimeError("train_backend='hip' needs the solver's library context (construct the net through DeepCFR)")
+        params = list(self.net.parameters())
+        if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
+            raise RuntimeError("train_backend='hip' needs contiguous float32 parameters")
+        if self._hip is None:
+            self._hip = (torch.zeros(2 * sum(p.numel() for p in params), dtype=torch.float32, device=self.device),
+                         torch.zeros(1, dtype=torch.float32, device=self.device))
+        state, loss = self._hip
+        rows_all = self._sample_rows(n, batch_size, epochs).contiguous()
+        loss.zero_()
+        lr = float(self.optimizer.param_groups[0]["lr"])
+        ptrs = tuple(p.data_ptr() for p in params)
+        self._ctx.sdcfr_train_steps(rows_all.data_ptr(), batch_size, epochs, self.buffer.feat.data_ptr(), self.buffer.regret.data_ptr(), self.buffer.mask.data_ptr(),
+                                    self.buffer.capacity, ptrs, state.data_ptr(), self._hip_step + 1, lr, loss.data_ptr())
+        self._hip_step += epochs
+        return float(loss.item()) / epochs
 
     def _sample_rows(self, n, batch_size, epochs):
         """All `epochs` index batches of one train() call in ONE upload ([epochs, batch] ring rows): the reference draws them one after
@@ -337,7 +368,7 @@ class DeepCFR:
     """`DeepCFR(game, num_players=2, device="cuda").train(iterations, advantage_epochs, eval_freq)`."""
 
     def __init__(self, game, num_players=2, device="cuda", batch=1, seed=0x5C09A, stream=None, rank=0, world=1,
-                 memory_size=None, graph_training=False, fused_traversal=None):
+                 memory_size=None, graph_training=False, fused_traversal=None, train_backend="torch"):
         """rank/world: data parallelism over torch.distributed (one process per GPU).  Each rank traverses `batch`
         traversals with global ids [rank*batch, (rank+1)*batch) into its own memory ring and the advantage-net
         gradients are averaged with one all-reduce per optimiser step (55 104 B), so every replica's nets stay equal."""
@@ -360,8 +391,10 @@ class DeepCFR:
                 memory_size = max(100000, 8 * ROWS_PER_TRAVERSAL * self.batch)
             if memory_size < ROWS_PER_TRAVERSAL * self.batch:
                 raise ValueError("memory_size must hold at least one batch of traversals (41 rows each)")
-            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device, memory_size=memory_size, use_graph=graph_training)
+            self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device, memory_size=memory_size, use_graph=graph_training, train_backend=train_backend)
                                    for _ in range(num_players)]
+            for a in self.advantage_nets:
+                a._ctx = self._engine.ctx
         self.strategy_buffers = [StrategyBuffer() for _ in range(num_players)]
         self.training_history = {"losses": [[] for _ in range(num_players)], "values": [[] for _ in range(num_players)],
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}

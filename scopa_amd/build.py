@@ -10,7 +10,7 @@ import subprocess
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(_HERE, "csrc")
 LIB = os.path.join(_HERE, "libscopa_hip.so")
-SOURCES = ["scopa_host.hip", "scopa_tree.hip", "scopa_mccfr.hip", "scopa_cfr.hip", "scopa_eval.hip", "scopa_sdcfr.hip", "scopa_multi.hip", "scopa_full.hip", "scopa_team.hip", "scopa_p2p.hip"]
+SOURCES = ["scopa_host.hip", "scopa_tree.hip", "scopa_mccfr.hip", "scopa_cfr.hip", "scopa_eval.hip", "scopa_sdcfr.hip", "scopa_train.hip", "scopa_multi.hip", "scopa_full.hip", "scopa_team.hip", "scopa_p2p.hip"]
 # -ffp-contract=off: float64 arithmetic must round once per operation, like numpy (the one fused
 #   product, np.dot, is written as an explicit fma chain); -munsafe-fp-atomics: float64 atomic adds
 #   become ds_add_f64 / global_atomic_add_f64 instead of compare-and-swap loops.
