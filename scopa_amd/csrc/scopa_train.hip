@@ -28,7 +28,7 @@ __device__ __forceinline__ v4f mfma(float a, float b, v4f c) { return __builtin_
 }  // namespace
 
 __global__ void __launch_bounds__(256)
-k_sdcfr_train_grad(const int64_t *__restrict__ g_rows, int n_rows, const float *__restrict__ g_feat, const float *__restrict__ g_regret, const float *__restrict__ g_mask,
+k_sdcfr_train_grad(const int64_t *__restrict__ g_rows, int n_rows, long long capacity, const float *__restrict__ g_feat, const float *__restrict__ g_regret, const float *__restrict__ g_mask,
                    const float *__restrict__ W1, const float *__restrict__ B1, const float *__restrict__ W2, const float *__restrict__ B2,
                    const float *__restrict__ W3, const float *__restrict__ B3, float *__restrict__ g_partial /* [gridDim.x][kParams + 1] */) {
     __shared__ float s_x[16 * kSX], s_h1[16 * kS1], s_h2[16 * kS2], s_d[16 * kSD], s_dz2[16 * kS2], s_dz1[16 * kS1];
@@ -55,7 +55,7 @@ k_sdcfr_train_grad(const int64_t *__restrict__ g_rows, int n_rows, const float *
 
     for (int tile = blockIdx.x; tile < n_tiles; tile += gridDim.x) {
         __syncthreads();                                   // the previous tile's LDS is no longer read
-        if (tid < 16) s_row[tid] = g_rows[tile * 16 + tid];
+        if (tid < 16) { const long long r = g_rows[tile * 16 + tid]; s_row[tid] = r < 0 ? 0 : r >= capacity ? capacity - 1 : r; }   // (a row index outside the ring is clamped, never dereferenced)
         __syncthreads();
         for (int e = tid; e < 16 * kIn; e += 256) { const int r = e / kIn, c = e - r * kIn; s_x[r * kSX + c] = g_feat[(size_t)s_row[r] * kIn + c]; }
         { const int r = tid >> 4, c = tid & 15; s_t[r * kSD + c] = g_regret[(size_t)s_row[r] * kOut + c]; s_m[r * kSD + c] = g_mask[(size_t)s_row[r] * kOut + c]; }
@@ -257,7 +257,7 @@ int32_t scopa_sdcfr_train_steps(scopa_ctx *ctx, const int64_t *d_rows, int32_t n
     if (!ctx->d_train_partial) SC_HIP(ctx, hipMalloc(&ctx->d_train_partial, sizeof(float) * (size_t)kMaxPartials * (kParams + 1)));
     const int n_tiles = n_rows / 16, grid = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
     for (int e = 0; e < n_steps; e++) {
-        hipLaunchKernelGGL(k_sdcfr_train_grad, dim3(grid), dim3(256), 0, ctx->stream, d_rows + (size_t)e * n_rows, (int)n_rows, d_feat, d_regret, d_mask, (const float *)d_w1,
+        hipLaunchKernelGGL(k_sdcfr_train_grad, dim3(grid), dim3(256), 0, ctx->stream, d_rows + (size_t)e * n_rows, (int)n_rows, (long long)capacity, d_feat, d_regret, d_mask, (const float *)d_w1,
                            (const float *)d_b1, (const float *)d_w2, (const float *)d_b2, (const float *)d_w3, (const float *)d_b3, (float *)ctx->d_train_partial);
         hipLaunchKernelGGL(k_sdcfr_train_adam, dim3(1), dim3(1024), 0, ctx->stream, (const float *)ctx->d_train_partial, grid, (int)n_rows, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3,
                            d_state, (int)(first_step + e), lr, 0.9f, 0.999f, 1e-8f, d_loss);

@@ -425,6 +425,36 @@ def test_hip_training_step_matches_the_pytorch_step(ctx, batch_rows, epochs):
     assert ds[1].advantage_nets[0]._hip_step == 3 * epochs and ds[0].advantage_nets[0]._hip_step == 0
 
 
+def test_hip_training_step_rejects_bad_arguments_and_trains(ctx):
+    """scopa_sdcfr_train_steps: ragged batches, step 0 and misaligned weights are refused (SCOPA_EINVAL) -- AdvantageNetwork falls back to the PyTorch
+    path for ragged batches by itself; and 200 iterations of DeepCFR.train on the hip backend bring the loss down and keep everything finite."""
+    import torch
+    from scopa_amd import _lib
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=64, train_backend="hip")
+    a = d.advantage_nets[0]
+    d._traverse_batch(0, 64)
+    ptrs = tuple(p.data_ptr() for p in a.net.parameters())
+    rows = torch.zeros(64, dtype=torch.long, device="cuda:0")
+    state, loss = torch.zeros(2 * 13776, device="cuda:0"), torch.zeros(1, device="cuda:0")
+    c = d._engine.ctx
+    args = lambda n, step, p=ptrs: (rows.data_ptr(), n, 1, a.buffer.feat.data_ptr(), a.buffer.regret.data_ptr(), a.buffer.mask.data_ptr(), a.buffer.capacity, p, state.data_ptr(), step, 5e-4, loss.data_ptr())
+    for bad in (args(20, 1), args(0, 1), args(32, 0), args(32, 1, (ptrs[0] + 4,) + ptrs[1:])):
+        with pytest.raises(_lib.ScopaError):
+            c.sdcfr_train_steps(*bad)
+    a.buffer.total = 20                                          # 20 rows in memory: the reference's min(n, 32) batch is 20 -- not whole tiles -> PyTorch path
+    with torch.cuda.stream(d._stream):
+        a.train(epochs=1)
+    d._stream.synchronize()
+    assert a._hip_step == 0
+    a.buffer.total = 41 * 64
+    d.train(iterations=200, advantage_epochs=5, eval_freq=10 ** 9)
+    L = np.array(d.training_history["losses"])
+    assert np.isfinite(L).all() and L[:, -20:].mean() < 0.5 * L[:, :5].mean() and all(x._hip_step == 1000 for x in d.advantage_nets)
+    assert all(bool(torch.isfinite(p).all()) for x in d.advantage_nets for p in x.net.parameters())
+
+
 def _nets_flat(d):
     return np.stack([np.concatenate([v.cpu().numpy().reshape(-1) for v in d.advantage_nets[p].net.state_dict().values()]) for p in range(2)])
 
