@@ -226,8 +226,13 @@ class AdvantageNetwork:
         """All `epochs` index batches of one train() call in ONE upload ([epochs, batch] ring rows): the reference draws them one after
         the other from the same `random` stream (:88), so drawing them up front gives the same batches; a per-step list -> device copy
         made the optimiser step host-bound."""
-        idx = torch.from_numpy(reference_sample_stream(n, batch_size, epochs, self._rng)).to(self.device)
-        return self.buffer.logical_to_physical(idx)
+        # Every train() call re-seeds the stream (seed 42 + one shuffle, as the reference's MiniDeck() does), so the index batches are a pure
+        # function of (rows in memory, batch, epochs): once the ring is full they are the SAME deque positions call after call (the reference's
+        # own artefact, SURVEY section 5) and the device copy of the last draw is reused -- only the ring's start moves (logical_to_physical).
+        key = (n, batch_size, epochs)
+        if getattr(self, "_sample_cache", None) is None or self._sample_cache[0] != key:
+            self._sample_cache = (key, torch.from_numpy(reference_sample_stream(n, batch_size, epochs, self._rng)).to(self.device))
+        return self.buffer.logical_to_physical(self._sample_cache[1])
 
     def _step(self, rows):
         """One optimiser step on the ring rows `rows` (deep_cfr.py:99-112); returns the loss tensor."""
