@@ -129,6 +129,7 @@ class AdvantageNetwork:
         self._ctx = None             # the solver's library context (set by DeepCFR): the hip backend launches on its stream
         self._hip = None             # hip backend: (moment buffer [2][13776], running loss [1]) and the step count
         self._hip_step = 0
+        self._sample_cache = None    # ((rows in memory, batch, epochs), device tensor of the index batches): see _sample_rows
         self.use_graph = use_graph   # replay the optimiser step as one HIP graph (same ops, ~10x less launch overhead)
         self.lean_step = True        # graph mode: the step with its backward pass written out (_step_lean: 28 kernels instead of ~45); False = autograd's step in the graph
         self._graphs = {}            # (batch_size, epochs) -> (graph of all the epochs' steps, static index tensor [epochs, batch], static loss tensor [epochs])
@@ -230,7 +231,7 @@ class AdvantageNetwork:
         # function of (rows in memory, batch, epochs): once the ring is full they are the SAME deque positions call after call (the reference's
         # own artefact) and the device copy of the last draw is reused -- only the ring's start moves (logical_to_physical).
         key = (n, batch_size, epochs)
-        if getattr(self, "_sample_cache", None) is None or self._sample_cache[0] != key:
+        if self._sample_cache is None or self._sample_cache[0] != key:
             self._sample_cache = (key, torch.from_numpy(reference_sample_stream(n, batch_size, epochs, self._rng)).to(self.device))
         return self.buffer.logical_to_physical(self._sample_cache[1])
 

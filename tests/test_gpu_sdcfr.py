@@ -341,9 +341,9 @@ def test_packed_weights_follow_the_nets(ctx):
         d._stream.synchronize()
         return w.cpu().numpy()
 
-    for graph in (False, True):
+    for graph in (False, True, "hip"):                     # "hip": the opt-in hand-written step updates the tensors in place, outside ATen as well
         torch.manual_seed(3)
-        d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=64, graph_training=graph)
+        d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=64, graph_training=(graph is True), train_backend="hip" if graph == "hip" else "torch")
         assert packed(d).shape == (2, 13520) and np.array_equal(packed(d), fresh(d))
         for p in (0, 1):
             d._traverse_batch(p, 64)
