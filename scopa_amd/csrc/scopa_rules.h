@@ -37,13 +37,6 @@ SC_HD int subtree_size(int d) {  // nodes (incl. itself and terminals) below a n
 // ---- cards -----------------------------------------------------------------------------------------------
 // rank of card id c (MiniDeck.ranks, mini_scopa_game.py:18-23): 2 5 8 10 | 2 5 7 9 | 3 6 8 9 | 3 6 7 10
 constexpr uint64_t kRankLut = 0xA76398639752A852ull;
-SC_HD int sc_clz32(uint32_t x) {   // x != 0
-#if defined(__HIP_DEVICE_COMPILE__)
-    return __clz((int)x);
-#else
-    return __builtin_clz(x);
-#endif
-}
 SC_HD int card_rank(int c) { return (int)((kRankLut >> (4 * c)) & 15u); }
 SC_HD int nib(uint32_t list, int i) { return (int)((list >> (4 * i)) & 15u); }
 // remove nibble i from a nibble list, keeping the order of the rest
@@ -77,36 +70,52 @@ SC_HD void state_init(scopa_state &s, const uint8_t *perm16) {  // MiniScopaGame
 //      kept (comb_sums[s] is written only while None, :81-85).  `valid` is the set of reachable sums, sub[s]
 //      (8 bits each, packed) the subset that first reached s; one table card updates all sums at once from
 //      the previous card's state, which is what the reference's descending-s inner loop computes.
+SC_HD int sc_ctz32(uint32_t x) {   // x != 0
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __ffs((int)x) - 1;
+#else
+    return __builtin_ctz(x);
+#endif
+}
 SC_HD uint32_t capture_mask(uint32_t table, int nt, int target) {
     if (nt == 0 || target <= 0) return 0u;
+    uint32_t ranks = 0u;       // the table as a nibble list of RANKS (2..10), zero beyond nt
 #pragma unroll
     for (int i = 0; i < 8; i++)
-        if (i < nt && card_rank(nib(table, i)) == target) return 1u << i;
+        if (i < nt) ranks |= (uint32_t)card_rank(nib(table, i)) << (4 * i);
+    {   // (1) the first table card of the played rank: the lowest zero nibble of ranks ^ (target in every nibble) -- nibbles beyond nt hold `target` != 0
+        const uint32_t x = ranks ^ ((uint32_t)target * 0x11111111u);
+        const uint32_t z = (x - 0x11111111u) & ~x & 0x88888888u;   // bit 4 i + 3 set for the lowest zero nibble i (higher ones may be false, the lowest never is)
+        if (z) return 1u << (sc_ctz32(z) >> 2);
+    }
+    // (2) the reference's subset-sum: comb_sums[s] is written once, when card i first makes s reachable, as comb_sums[s - rank_i] (as it stood BEFORE card i) +
+    // [i].  Kept here: the reachable set and, per sum, the index of the card that first reached it (a nibble each); the subset of `target` is then read
+    // back along that chain -- card first[target], then the subset of target - rank, which was complete before that card -- instead of carrying an 8-bit
+    // subset per sum through every card.
     uint32_t valid = 1u;       // bit s: sum s reachable
-    uint64_t sub_lo = 0ull;    // sub[0..7], 8 bits each
-    uint32_t sub_hi = 0u;      // sub[8..10]
+    uint64_t first = 0ull;     // nibble s: index of the card at which s became reachable
     const uint32_t upto = (2u << target) - 1u;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
         if (i >= nt) break;
-        const int r = card_rank(nib(table, i));
+        const int r = (int)((ranks >> (4 * i)) & 15u);
         uint32_t fresh = (valid << r) & ~valid & upto;
         valid |= fresh;
-        uint64_t nlo = sub_lo;
-        uint32_t nhi = sub_hi;
-        while (fresh) {        // the sums this card reaches first: one or two as a rule (a walk over set bits instead of a test of every sum 2..10)
-            const int s = 31 - sc_clz32(fresh);   // any order: every fresh sum reads the state BEFORE this card (sub_lo / sub_hi) and writes its own byte
-            fresh &= ~(1u << s);
-            const int q = s - r;  // q >= 0 because bit s of (valid << r) is set
-            const uint32_t prev = q < 8 ? (uint32_t)((sub_lo >> (8 * q)) & 0xFFu) : ((sub_hi >> (8 * (q - 8))) & 0xFFu);
-            const uint32_t now = prev | (1u << i);
-            if (s < 8) nlo |= (uint64_t)now << (8 * s);
-            else       nhi |= now << (8 * (s - 8));
+        while (fresh) {        // one or two sums as a rule
+            const int s = sc_ctz32(fresh);
+            fresh &= fresh - 1u;
+            first |= (uint64_t)i << (4 * s);
         }
-        sub_lo = nlo; sub_hi = nhi;
     }
     if (!((valid >> target) & 1u)) return 0u;
-    return target < 8 ? (uint32_t)((sub_lo >> (8 * target)) & 0xFFu) : ((sub_hi >> (8 * (target - 8))) & 0xFFu);
+    uint32_t mask = 0u;
+    int rem = target;
+    for (int step = 0; step < 5 && rem > 0; step++) {   // at most five cards (ranks >= 2, target <= 10)
+        const int i = (int)((first >> (4 * rem)) & 15ull);
+        mask |= 1u << i;
+        rem -= (int)((ranks >> (4 * i)) & 15u);
+    }
+    return mask;
 }
 
 // ---- MiniScopaEnv.step + MiniScopaGame.play_card, mini_scopa_game.py:93-104,140-167 ------------------------
