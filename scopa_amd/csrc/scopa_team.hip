@@ -14,13 +14,49 @@ using namespace scopa_team;
 using scopa::fail;
 static_assert(sizeof(scopa_team_state) == 40, "scopa_team_state must be 40 bytes");
 
+// A lane per game; the 40-byte states cross between HBM and the lanes through LDS, as in k_full_step_batch: a wavefront's 64 states are 2 560 consecutive
+// bytes (16-byte aligned: 64 x 40), loaded and stored as 160 sixteen-byte pieces in memory order and picked up by their lanes as five 8-byte words each.
 __global__ void __launch_bounds__(256)
 k_team_step_batch(scopa_team_state *__restrict__ states, const uint8_t *__restrict__ actions, long long n) {
-    const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    scopa_team_state s = states[i];
-    step(s, actions[i]);
-    states[i] = s;
+    __shared__ __align__(16) unsigned char s_stage[4][64 * 40];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const long long w0 = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63);   // first game of this wavefront
+    if (w0 >= n) return;
+    const long long left = n - w0;
+    const int pieces = left >= 64 ? 160 : (int)((left * 40 + 15) / 16);             // whole 16-byte pieces covering the wavefront's states ...
+    const bool tail8 = left < 64 && ((left * 40) & 15);                               // ... of which the last is half a piece when an odd number of states is left
+    unsigned char *st = s_stage[wave];
+    const uint4 *src = reinterpret_cast<const uint4 *>(states + w0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c = k * 64 + lane;
+        if (c < pieces) {
+            if (tail8 && c == pieces - 1) *reinterpret_cast<uint2 *>(st + c * 16) = *reinterpret_cast<const uint2 *>(src + c);
+            else *reinterpret_cast<uint4 *>(st + c * 16) = src[c];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (lane < left) {
+        uint2 raw[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) raw[k] = *reinterpret_cast<const uint2 *>(st + lane * 40 + k * 8);
+        scopa_team_state s;
+        memcpy(&s, raw, 40);
+        step(s, actions[w0 + lane]);
+        memcpy(raw, &s, 40);
+#pragma unroll
+        for (int k = 0; k < 5; k++) *reinterpret_cast<uint2 *>(st + lane * 40 + k * 8) = raw[k];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint4 *dst = reinterpret_cast<uint4 *>(states + w0);
+#pragma unroll
+    for (int k = 0; k < 3; k++) {
+        const int c = k * 64 + lane;
+        if (c < pieces) {
+            if (tail8 && c == pieces - 1) *reinterpret_cast<uint2 *>(dst + c) = *reinterpret_cast<const uint2 *>(st + c * 16);
+            else dst[c] = *reinterpret_cast<const uint4 *>(st + c * 16);
+        }
+    }
 }
 
 // One lane per game: deal from the seed (MiniDeck(seed), team_mini_scopa_game.py:31-34), then uniform-random legal play.
@@ -107,7 +143,7 @@ int32_t scopa_team_state_infoset_string(const scopa_team_state *s, int32_t team,
 int32_t scopa_team_step_batch(scopa_ctx *ctx, scopa_team_state *d_states, const uint8_t *d_actions, int64_t n) {
     if (!ctx || n < 0 || (n && (!d_states || !d_actions))) return SCOPA_EINVAL;
     if (!n) return SCOPA_OK;
-    SC_REQUIRE(ctx, ((uintptr_t)d_states & 7) == 0, SCOPA_EINVAL, "scopa_team_step_batch: states must be 8-byte aligned");
+    SC_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0, SCOPA_EINVAL, "scopa_team_step_batch: states must be 16-byte aligned");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     hipLaunchKernelGGL(k_team_step_batch, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, d_actions, (long long)n);
     SC_HIP(ctx, hipGetLastError());
