@@ -988,7 +988,8 @@ k_sdcfr_policy(const uint2 *__restrict__ g_ninfo, const float *__restrict__ g_im
 namespace {
 // What a walk keeps in LDS is per TRAVERSER: policies and node words of the traverser's plies only (the walk recurses there and needs the policy on the way
 // back), sampling thresholds of the opponent's three sampled plies only, nl - 1 of them per node -- 22-24 KB instead of the 80 KB of every node's
-// everything, so that TWO workgroups of sixteen wavefronts fit a compute unit (the walk is a chain of LDS round trips: eight wavefronts per SIMD hide what four did not)
+// everything, so that TWO workgroups of twelve wavefronts fit a compute unit beside their per-wavefront scratch (measured: the staging per workgroup shrinks
+// with the tables; the doubled occupancy by itself changed nothing -- at 32768 traversals the launch is bound by its row stores)
 constexpr int kWalkTravNodes = 916;        // traverser 1's plies 1, 3, 5, 7: 4 + 48 + 288 + 576  (traverser 0's plies 0, 2, 4, 6: 1 + 16 + 144 + 576 = 737)
 constexpr int kWalkThr = 396;              // traverser 0's opponent plies 1, 3, 5: 4 x 3 + 48 x 2 + 288 x 1  (traverser 1's plies 0, 2, 4: 1 x 3 + 16 x 2 + 144 x 1 = 179)
 __host__ __device__ constexpr int sd_trav_off(int traverser, int m) {   // the traverser's ply m = 0..3 within its compact tables
