@@ -221,6 +221,8 @@ def run_sdcfr(args, emit=True):
             with torch.cuda.stream(d._stream):
                 d.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
             d._stream.synchronize()
+        if d._iteration > 0:
+            d._snapshot_strategies(d._iteration)                 # the iteration's strategy snapshots (deep_cfr.py:460-471) belong to it
         d._iteration += 1
 
     def fence():
@@ -294,6 +296,8 @@ def run_sdcfr(args, emit=True):
                 with torch.cuda.stream(d2._stream):
                     d2.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
                 d2._stream.synchronize()
+            if d2._iteration > 0:
+                d2._snapshot_strategies(d2._iteration)
             d2._iteration += 1
         for _ in range(10):
             step2()
