@@ -34,6 +34,7 @@ def test_bench_line_contract_n1(ctx):
     assert set(sd["roofline"]["bounds"]) == {"hbm-memory-rows", "mfma-f32"} and sd["roofline"]["bound"] == "hbm-memory-rows" and sd["roofline"]["hbm_algorithmic"]["GBps"] > 0
     assert all(0.0 < b["frac"] <= 1.0 for b in sd["roofline"]["bounds"].values())
     assert sd["traversal_only"]["forward_per_visit_kernel_avg_us"] > sd["traversal_only"]["kernel_avg_us"]   # a forward pass per visit costs more than one per node
+    assert 0.0 < sd["with_hip_training_step"]["ms_per_step"] < sd["ms_per_step"]                             # the opt-in hand-written optimiser step, measured beside the default
     w = d["world"]
     assert w["world_size"] == 1 and len(w["ranks"]) == 1 and w["ranks"][0]["rank"] == 0 and w["ranks"][0]["ms_per_step"] > 0
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
