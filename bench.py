@@ -216,11 +216,11 @@ def run_sdcfr(args, emit=True):
     epochs = args.sdcfr_epochs
 
     def step():
-        for p in range(2):
+        for p in range(2):                                       # as DeepCFR.train: the iteration is queued on the solver's stream and waited for once
             d._traverse_batch(p, batch, sync=False)
             with torch.cuda.stream(d._stream):
-                d.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
-            d._stream.synchronize()
+                d.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs, defer=True)
+        d._stream.synchronize()
         if d._iteration > 0:
             d._snapshot_strategies(d._iteration)                 # the iteration's strategy snapshots (deep_cfr.py:460-471) belong to it
         d._iteration += 1
@@ -294,8 +294,8 @@ def run_sdcfr(args, emit=True):
             for p in range(2):
                 d2._traverse_batch(p, batch, sync=False)
                 with torch.cuda.stream(d2._stream):
-                    d2.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs)
-                d2._stream.synchronize()
+                    d2.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs, defer=True)
+            d2._stream.synchronize()
             if d2._iteration > 0:
                 d2._snapshot_strategies(d2._iteration)
             d2._iteration += 1

@@ -183,7 +183,9 @@ class AdvantageNetwork:
         the sample is a deterministic function of the buffer length; the same stream is rebuilt here privately."""
         return self._rng.sample(range(n), batch_size)
 
-    def train(self, batch_size=128, epochs=1):
+    def train(self, batch_size=128, epochs=1, defer=False):
+        """deep_cfr.py:77-116.  defer=True (the solver's own loop): the graph-replayed and the hand-written paths return the mean loss as a 0-dim DEVICE
+        tensor instead of waiting for it -- the caller reads it after it has queued the rest of the iteration."""
         n = len(self.buffer)
         if n < batch_size:
             batch_size = min(n, 32)
@@ -193,16 +195,16 @@ class AdvantageNetwork:
         self._rng.shuffle(list(range(16)))
         self._weights_changed()
         if self.train_backend == "hip" and self.grad_sync is None and batch_size % 16 == 0 and batch_size >= 16:
-            return self._train_hip(n, batch_size, epochs)
+            return self._train_hip(n, batch_size, epochs, defer)
         if self.use_graph and self.grad_sync is None:
-            return self._train_graphed(n, batch_size, epochs)
+            return self._train_graphed(n, batch_size, epochs, defer)
         rows_all = self._sample_rows(n, batch_size, epochs)
         total_loss = 0.0
         for e in range(epochs):
             total_loss += self._step(rows_all[e]).item()
         return total_loss / epochs
 
-    def _train_hip(self, n, batch_size, epochs):
+    def _train_hip(self, n, batch_size, epochs, defer=False):
         """The same steps through scopa_sdcfr_train_step (two launches per step, none of them PyTorch's): the net's own parameter tensors are
         updated in place, Adam's moments live in one [2][13776] buffer.  Ragged batches (not a multiple of 16 rows) and N > 1 take the PyTorch path."""
         if self._ctx is None:
@@ -221,7 +223,7 @@ class AdvantageNetwork:
         self._ctx.sdcfr_train_steps(rows_all.data_ptr(), batch_size, epochs, self.buffer.feat.data_ptr(), self.buffer.regret.data_ptr(), self.buffer.mask.data_ptr(),
                                     self.buffer.capacity, ptrs, state.data_ptr(), self._hip_step + 1, lr, loss.data_ptr())
         self._hip_step += epochs
-        return float(loss.item()) / epochs
+        return loss[0] / epochs if defer else float(loss.item()) / epochs
 
     def _sample_rows(self, n, batch_size, epochs):
         """All `epochs` index batches of one train() call in ONE upload ([epochs, batch] ring rows): the reference draws them one after
@@ -288,7 +290,7 @@ class AdvantageNetwork:
         self.optimizer.step()
         return loss
 
-    def _train_graphed(self, n, batch_size, epochs):
+    def _train_graphed(self, n, batch_size, epochs, defer=False):
         """The same steps -- all `epochs` of a train() call -- captured once per (batch size, epochs) into ONE HIP graph and replayed with
         fresh row indices: one upload of the [epochs, batch] index batches, one replay, one read-back of the mean loss."""
         key = (batch_size, epochs)
@@ -325,7 +327,7 @@ class AdvantageNetwork:
         g, rows, losses = self._graphs[key]
         rows.copy_(self._sample_rows(n, batch_size, epochs))
         g.replay()
-        return float(losses.sum().item()) / epochs
+        return losses.sum() / epochs if defer else float(losses.sum().item()) / epochs
 
 
 class _SnapshotView:
@@ -631,19 +633,23 @@ class DeepCFR:
     # ---- training loop (deep_cfr.py:431-495) -------------------------------------------------------------------------
     def train(self, iterations=100, advantage_epochs=10, eval_freq=5, verbose=False):
         for iteration in range(iterations):
-            iteration_losses, iteration_values = [], []
+            iteration_losses, iteration_values, pending = [], [], []
             for player in range(self.num_players):
+                # the whole iteration is QUEUED on the solver's stream -- traversal, optimiser epochs, the other player's traversal (which reads the nets
+                # just trained: stream order), its epochs -- and read back once: waiting for each loss before preparing the next launch left the GPU
+                # idle for a quarter of the iteration
                 vals = self._traverse_batch(player, self.batch, sync=False)
                 with torch.cuda.stream(self._stream):
-                    loss = self.advantage_nets[player].train(epochs=advantage_epochs)
-                    mean_value = vals.mean()
-                self._stream.synchronize()
-                value = float(mean_value.item())
+                    loss = self.advantage_nets[player].train(epochs=advantage_epochs, defer=True)
+                    pending.append((loss, vals.mean()))
+                self.training_history["buffer_sizes"][player].append(len(self.advantage_nets[player].buffer))
+            self._stream.synchronize()
+            for player, (loss, mean_value) in enumerate(pending):
+                loss, value = float(loss), float(mean_value.item())
                 iteration_losses.append(loss)
                 iteration_values.append(value)
                 self.training_history["losses"][player].append(loss)
                 self.training_history["values"][player].append(value)
-                self.training_history["buffer_sizes"][player].append(len(self.advantage_nets[player].buffer))
             if iteration > 0:
                 self._snapshot_strategies(iteration)
             if iteration % eval_freq == 0:
