@@ -215,17 +215,18 @@ def run_sdcfr(args, emit=True):
         ctx.sdcfr_tuning(int(os.environ.get("SCOPA_SDCFR_T", "0")), int(os.environ.get("SCOPA_SDCFR_W", "0")))
     epochs = args.sdcfr_epochs
 
-    def step():
-        for p in range(2):                                       # as DeepCFR.train: the iteration is queued on the solver's stream and waited for once
-            d._traverse_batch(p, batch, sync=False)
-            with torch.cuda.stream(d._stream):
-                d.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs, defer=True)
-        d._stream.synchronize()
-        if d._iteration > 0:
-            d._snapshot_strategies(d._iteration)                 # the iteration's strategy snapshots (deep_cfr.py:460-471) belong to it
-        d._iteration += 1
+    ahead = [None]
+
+    def step():                                                  # as DeepCFR.train: the iteration is queued on the solver's stream, the host stays one iteration ahead
+        q = d._queue_iteration(epochs, args.sdcfr_train_batch)
+        if ahead[0] is not None:
+            d._resolve(ahead[0])
+        ahead[0] = q
 
     def fence():
+        if ahead[0] is not None:
+            d._resolve(ahead[0])
+            ahead[0] = None
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -290,20 +291,19 @@ def run_sdcfr(args, emit=True):
         d2 = DeepCFR(load_game("mini_scopa"), device=f"cuda:{local}", batch=batch, train_backend="hip")
         sys.stdout.flush(); os.dup2(_so2, 1)
 
+        ahead2 = [None]
+
         def step2():
-            for p in range(2):
-                d2._traverse_batch(p, batch, sync=False)
-                with torch.cuda.stream(d2._stream):
-                    d2.advantage_nets[p].train(batch_size=args.sdcfr_train_batch, epochs=epochs, defer=True)
-            d2._stream.synchronize()
-            if d2._iteration > 0:
-                d2._snapshot_strategies(d2._iteration)
-            d2._iteration += 1
+            q = d2._queue_iteration(epochs, args.sdcfr_train_batch)
+            if ahead2[0] is not None:
+                d2._resolve(ahead2[0])
+            ahead2[0] = q
         for _ in range(10):
             step2()
         torch.cuda.synchronize(); t2 = time.perf_counter()
         for _ in range(20):
             step2()
+        d2._resolve(ahead2[0])
         torch.cuda.synchronize()
         hip_train = {"ms_per_step": 1e3 * (time.perf_counter() - t2) / 20, "iterations_timed": 20,
                      "what": "the same iteration with train_backend='hip' (scopa_sdcfr_train_steps: k_sdcfr_train_grad + k_sdcfr_train_adam per Adam step; tests hold it to the PyTorch step at 2e-5)"}

@@ -630,34 +630,59 @@ class DeepCFR:
                                               raw["scopas"][ar, 1 - seat_h].astype(np.float64), seat_h) if n else []
         return avg_reward, [trained, rnd]
 
+    def _queue_iteration(self, advantage_epochs, train_batch=128, loop_index=None):
+        """One iteration's device work, QUEUED on the solver's stream and not waited for: per player the traversal call and the optimiser epochs (the
+        other player's traversal reads the nets just trained: stream order), then the iteration's strategy snapshots.  Returns what `_resolve` reads
+        back: per player (mean loss, mean root value) as device scalars (or floats, on the eager path) and an event behind all of it."""
+        pending = []
+        for player in range(self.num_players):
+            vals = self._traverse_batch(player, self.batch, sync=False)
+            with torch.cuda.stream(self._stream):
+                loss = self.advantage_nets[player].train(batch_size=train_batch, epochs=advantage_epochs, defer=True)
+                pending.append((loss, vals.mean(), len(self.advantage_nets[player].buffer)))
+        # the snapshot rule counts iterations of THIS train() call, as the reference's loop variable does (deep_cfr.py:431, 460-471): none at its
+        # first iteration, weight = loop index + 1 (the kernels' draws are keyed by the solver's own running count, self._iteration)
+        loop_index = self._iteration if loop_index is None else loop_index
+        if loop_index > 0:
+            self._snapshot_strategies(loop_index)
+        done = torch.cuda.Event()
+        done.record(self._stream)
+        self._iteration += 1
+        return pending, done
+
+    def _resolve(self, queued):
+        """Waits for a queued iteration and appends its figures to training_history; returns (losses, values) per player."""
+        pending, done = queued
+        done.synchronize()
+        losses, values = [], []
+        for player, (loss, mean_value, rows) in enumerate(pending):
+            loss, value = float(loss), float(mean_value.item())
+            losses.append(loss)
+            values.append(value)
+            self.training_history["losses"][player].append(loss)
+            self.training_history["values"][player].append(value)
+            self.training_history["buffer_sizes"][player].append(rows)
+        return losses, values
+
     # ---- training loop (deep_cfr.py:431-495) -------------------------------------------------------------------------
     def train(self, iterations=100, advantage_epochs=10, eval_freq=5, verbose=False):
+        """The host stays ONE iteration ahead of the device: iteration t + 1 is queued before iteration t's losses are read back, so the GPU never waits
+        for Python between iterations (it did for a sixth of every iteration); an evaluation (every eval_freq iterations) drains the queue first."""
+        ahead = None
         for iteration in range(iterations):
-            iteration_losses, iteration_values, pending = [], [], []
-            for player in range(self.num_players):
-                # the whole iteration is QUEUED on the solver's stream -- traversal, optimiser epochs, the other player's traversal (which reads the nets
-                # just trained: stream order), its epochs -- and read back once: waiting for each loss before preparing the next launch left the GPU
-                # idle for a quarter of the iteration
-                vals = self._traverse_batch(player, self.batch, sync=False)
-                with torch.cuda.stream(self._stream):
-                    loss = self.advantage_nets[player].train(epochs=advantage_epochs, defer=True)
-                    pending.append((loss, vals.mean()))
-                self.training_history["buffer_sizes"][player].append(len(self.advantage_nets[player].buffer))
-            self._stream.synchronize()
-            for player, (loss, mean_value) in enumerate(pending):
-                loss, value = float(loss), float(mean_value.item())
-                iteration_losses.append(loss)
-                iteration_values.append(value)
-                self.training_history["losses"][player].append(loss)
-                self.training_history["values"][player].append(value)
-            if iteration > 0:
-                self._snapshot_strategies(iteration)
+            queued = self._queue_iteration(advantage_epochs, loop_index=iteration)
+            if ahead is not None:
+                self._resolve(ahead)
+            ahead = queued
             if iteration % eval_freq == 0:
+                iteration_losses, _ = self._resolve(ahead)
+                ahead = None
                 eval_reward, eval_scopas = self.evaluate_vs_random(num_episodes=50)
                 if verbose:
                     print(f"iter {iteration}: P0 loss {iteration_losses[0]:.4f} P1 loss {iteration_losses[1]:.4f} "
                           f"eval vs random {eval_reward:.3f} scopas {eval_scopas[0]:.2f}/{eval_scopas[1]:.2f}")
-            self._iteration += 1
+        if ahead is not None:
+            self._resolve(ahead)
 
     def _snapshot_strategies(self, iteration):
         """A copy of every player's advantage net into its strategy buffer, weight iteration + 1 (deep_cfr.py:460-471): one multi-tensor copy each."""

@@ -163,6 +163,13 @@ def test_train_loop_and_history(ctx):
     assert len(d.strategy_buffers[0].strategies) == 2 and d.strategy_buffers[0].weights == [2, 3]
     reward, scopas = d.evaluate_vs_random(200)
     assert -4 <= reward <= 4 and len(scopas) == 2
+    # a second train() call: the snapshot rule counts THIS call's iterations, as the reference's loop variable does (deep_cfr.py:431, 460-471: none at the
+    # call's first iteration, weight = loop index + 1), while the traversal draws go on from the solver's running count; the host runs one iteration ahead
+    # of the device and an evaluation drains that queue: the history stays in iteration order
+    d.train(iterations=4, advantage_epochs=2, eval_freq=3)
+    assert d.strategy_buffers[0].weights == [2, 3, 2, 3, 4] and d._iteration == 7
+    assert h["buffer_sizes"][1] == [328 * k for k in range(1, 8)] and len(h["losses"][0]) == 7 and len(h["values"][1]) == 7 and len(h["eval_rewards"]) == 3 + 1 + 2
+    assert all(np.isfinite(h["losses"][p]).all() and np.isfinite(h["values"][p]).all() for p in (0, 1))
 
 
 def test_evaluate_vs_random_uniform_is_zero_mean(ctx):
