@@ -353,6 +353,7 @@ class StrategyBuffer:
     def __init__(self, max_size=100):
         self.weights, self.max_size = [], max_size
         self._slots, self._free, self._store = [], list(range(max_size)), None
+        self._gathered = None        # (the stored snapshots' tensors in FIFO order, their normalised weights): rebuilt after the next add_strategy
 
     @property
     def strategies(self):
@@ -371,6 +372,7 @@ class StrategyBuffer:
             torch._foreach_copy_([t[slot] for t in self._store], params)
         self._slots.append(slot)
         self.weights.append(iteration + 1)
+        self._gathered = None
 
     def average_policy_batch(self, feats, masks):
         """[N,34],[N,16] device tensors -> [N,16] weighted average of the snapshots' regret-matching policies."""
@@ -379,13 +381,14 @@ class StrategyBuffer:
         total = float(sum(self.weights))
         with torch.no_grad():
             if feats.shape[0] <= 4096:                       # all snapshots at once: [S, N, .] activations
-                idx = torch.tensor(self._slots, device=feats.device)
-                w1, b1, w2, b2, w3, b3 = (t[idx] for t in self._store)
+                if self._gathered is None:                   # once per buffer state (an evaluation asks eight times, a ply each)
+                    idx = torch.tensor(self._slots, device=feats.device)
+                    self._gathered = (tuple(t[idx] for t in self._store), torch.tensor(self.weights, dtype=torch.float32, device=feats.device) / total)
+                (w1, b1, w2, b2, w3, b3), wk = self._gathered
                 x = feats.unsqueeze(0).expand(len(self._slots), -1, -1)
                 h = torch.relu(torch.baddbmm(b1.unsqueeze(1), x, w1.transpose(1, 2)))
                 h = torch.relu(torch.baddbmm(b2.unsqueeze(1), h, w2.transpose(1, 2)))
                 adv = torch.baddbmm(b3.unsqueeze(1), h, w3.transpose(1, 2))
-                wk = torch.tensor(self.weights, dtype=adv.dtype, device=adv.device) / total
                 return (positive_regret_policy(adv, masks.unsqueeze(0)) * wk.view(-1, 1, 1)).sum(0)
             out = torch.zeros_like(masks)                    # large batches: a forward pass per snapshot (large kernels, no [S, N, 128] intermediate)
             for net, w in zip(self.strategies, self.weights):
