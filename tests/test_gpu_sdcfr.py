@@ -510,6 +510,42 @@ def test_traversal_at_the_stated_batch_vs_oracle(ctx, golden, oracle, trav, per_
         assert abs(float(vals[tb]) - float(ov[0])) < ATOL
 
 
+@pytest.mark.parametrize("trav", [0, 1])
+def test_traversal_at_32768_both_forms_vs_each_other_and_oracle(ctx, golden, oracle, trav):
+    """BASELINE configs[2]/[4]'s per-GPU shard size, 32 768 traversals in one call: here every wavefront takes SEVERAL tasks from its workgroup's counter
+    (at 4 096 each takes at most one).  The table form and the forward-per-visit form write the same 1 343 488 rows and 32 768 root values bit for bit
+    (compared on the device), every row is well-formed, and traversals 0, 1, 6143, 6144, 20 000 and 32 767 equal the oracle's, row for row."""
+    import torch
+    B = 32768
+    d, g = _solver_with_reference_nets(golden, batch=B, memory_size=41 * B)
+    d._iteration = 9
+    mem = d.advantage_nets[trav].buffer
+    got = {}
+    for name, per_visit in (("table", 0), ("per-visit", 1)):
+        d._engine.ctx.sdcfr_mode(per_visit)
+        mem.total = 0
+        v0 = d._engine.ctx.sdcfr_visits()
+        vals = d._traverse_batch(trav, B)
+        assert d._engine.ctx.sdcfr_visits() - v0 == (105, 82)[trav] * B
+        got[name] = (mem.feat.clone(), mem.regret.clone(), mem.mask.clone(), vals.clone())
+    d._engine.ctx.sdcfr_mode(0)
+    for a, b in zip(got["table"], got["per-visit"]):
+        assert torch.equal(a, b)
+    f, r, m, vals = got["table"]
+    assert torch.equal(f[:, :16], m) and bool((f[:, 32] == 1).all()) and bool((f[:, 33] == 0).all())
+    nl = m.sum(1).reshape(B, 41).sort(dim=1).values
+    assert torch.equal(nl, torch.tensor(sorted([4] + [3] * 4 + [2] * 12 + [1] * 24), dtype=nl.dtype, device=nl.device).expand(B, 41))
+    mx = r.abs().amax(1)
+    assert bool((((mx - 1.0).abs() < 1e-6) | (mx == 0)).all())
+    nets, t = _nets_flat(d), oracle.Tree(seed=42)
+    for tb in (0, 1, 6143, 6144, 20000, B - 1):
+        of, orr, om, ov, _ = t.sdcfr_traverse(nets, trav, seed=0x5C09A, iteration=9, b0=tb, nb=1)
+        sl = slice(41 * tb, 41 * tb + 41)
+        assert np.array_equal(f[sl].cpu().numpy(), of) and np.array_equal(m[sl].cpu().numpy(), om), tb
+        np.testing.assert_allclose(r[sl].cpu().numpy(), orr, atol=ATOL, rtol=0)
+        assert abs(float(vals[tb]) - float(ov[0])) < ATOL
+
+
 @pytest.mark.parametrize("fused", ["table", "per-visit", False])
 def test_memory_ring_wraps_like_a_deque(ctx, oracle, golden, fused):
     """The advantage memory is a FIFO (deque(maxlen=...), deep_cfr.py:52): two launches of B traversals into a ring of 41 B + 100 rows --
