@@ -505,13 +505,16 @@ class DeepCFR:
         if getattr(self, "_wpack", None) is None:
             self._wpack = torch.empty((len(self.advantage_nets), _lib.lib().scopa_sdcfr_image_floats()), dtype=torch.float32, device=self.device)
             self._wver = [None] * len(self.advantage_nets)
+            self._wparams = [None] * len(self.advantage_nets)
         for p, a in enumerate(self.advantage_nets):
-            sd = a.net.state_dict()
-            tensors = [sd[k] for k in self._PACK_KEYS]
+            if self._wparams[p] is None or self._wparams[p][0] is not a.net:      # the six parameters in the image's order, looked up once per net object
+                named = dict(a.net.named_parameters())
+                self._wparams[p] = (a.net, [named[k] for k in self._PACK_KEYS])
+            tensors = self._wparams[p][1]                                          # (a Parameter replaced by ANOTHER object around the class would go unseen: load_state_dict and in-place edits do not do that)
             ver = (a.weights_epoch,) + tuple((t.data_ptr(), t._version) for t in tensors)
             if ver != self._wver[p]:
                 if any(t.dtype != torch.float32 or not t.is_contiguous() for t in tensors):
-                    tensors = [t.to(torch.float32).contiguous() for t in tensors]
+                    tensors = [t.detach().to(torch.float32).contiguous() for t in tensors]
                 ctx.sdcfr_pack_weights(p, *(t.data_ptr() for t in tensors), self._wpack.data_ptr())
                 self._wver[p] = ver
         return self._wpack
