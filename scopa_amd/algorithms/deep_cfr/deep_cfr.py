@@ -130,6 +130,7 @@ class AdvantageNetwork:
         self._hip = None             # hip backend: (moment buffer [2][13776], running loss [1]) and the step count
         self._hip_step = 0
         self._sample_cache = None    # ((rows in memory, batch, epochs), device tensor of the index batches): see _sample_rows
+        self._plist = None           # (net object, list of its parameters): walking the module tree costs 25 us a time
         self.use_graph = use_graph   # replay the optimiser step as one HIP graph (same ops, ~10x less launch overhead)
         self.lean_step = True        # graph mode: the step with its backward pass written out (_step_lean: 28 kernels instead of ~45); False = autograd's step in the graph
         self._graphs = {}            # (batch_size, epochs) -> (graph of all the epochs' steps, static index tensor [epochs, batch], static loss tensor [epochs])
@@ -156,6 +157,12 @@ class AdvantageNetwork:
 
     def _weights_changed(self):
         self.weights_epoch += 1
+
+    def param_list(self):
+        """The net's parameters in net.parameters() order, looked up once per net object."""
+        if self._plist is None or self._plist[0] is not self.net:
+            self._plist = (self.net, list(self.net.parameters()))
+        return self._plist[1]
 
     def get_advantages(self, state_features, legal_actions_mask):
         with torch.no_grad():
@@ -209,7 +216,7 @@ class AdvantageNetwork:
         updated in place, Adam's moments live in one [2][13776] buffer.  Ragged batches (not a multiple of 16 rows) and N > 1 take the PyTorch path."""
         if self._ctx is None:
             raise RuntimeError("train_backend='hip' needs the solver's library context (construct the net through DeepCFR)")
-        params = list(self.net.parameters())
+        params = self.param_list()
         if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
             raise RuntimeError("train_backend='hip' needs contiguous float32 parameters")
         if self._hip is None:
@@ -359,9 +366,10 @@ class StrategyBuffer:
     def strategies(self):
         return [_SnapshotView([t[k] for t in self._store]) for k in self._slots]
 
-    def add_strategy(self, strategy_net, iteration):
-        """Stores a COPY of strategy_net's parameters (the reference's callers pass a deep copy they made; the copy made here makes that unnecessary)."""
-        params = [p.detach() for p in strategy_net.parameters()]
+    def add_strategy(self, strategy_net, iteration, params=None):
+        """Stores a COPY of strategy_net's parameters (the reference's callers pass a deep copy they made; the copy made here makes that unnecessary).
+        params: the net's parameter list, if the caller has it at hand."""
+        params = [p.detach() for p in (strategy_net.parameters() if params is None else params)]
         with torch.no_grad():
             if self._store is None:
                 self._store = [torch.empty((self.max_size,) + tuple(p.shape), dtype=p.dtype, device=p.device) for p in params]
@@ -694,7 +702,7 @@ class DeepCFR:
         """A copy of every player's advantage net into its strategy buffer, weight iteration + 1 (deep_cfr.py:460-471): one multi-tensor copy each."""
         with torch.cuda.stream(self._stream):
             for player in range(self.num_players):
-                self.strategy_buffers[player].add_strategy(self.advantage_nets[player].net, iteration)
+                self.strategy_buffers[player].add_strategy(self.advantage_nets[player].net, iteration, self.advantage_nets[player].param_list())
 
     def plot_training_progress(self, path="deep_cfr_training.png"):
         try:
