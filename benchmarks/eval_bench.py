@@ -29,17 +29,24 @@ def main():
     pol = torch.as_tensor(np.ascontiguousarray(ctx.exploitability(return_policy=True)["policy"], np.float64), device="cuda:0")
     states = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0"); idx = torch.zeros(n, dtype=torch.int32, device="cuda:0")
     seat = torch.as_tensor(np.array([0 if e < n / 2 else 1 for e in range(n)], np.int32), device="cuda:0")
-    ctx.eval_init_states(states.data_ptr(), n)
-    times = []
-    for ply in range(8):
-        torch.cuda.synchronize(); ctx.synchronize(); t0 = time.perf_counter()
-        ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, pol.data_ptr(), seat.data_ptr(), 16)
-        ctx.synchronize(); times.append(time.perf_counter() - t0)
-    k = sum(times)
+    by_form = {}
+    for form in ("float64 divisions per visit", "integer thresholds per infoset (scopa_eval_tabular_prepare)"):
+        ctx.eval_init_states(states.data_ptr(), n); idx.zero_()
+        torch.cuda.synchronize(); ctx.synchronize()
+        if form.startswith("integer"):
+            ctx.eval_tabular_prepare(pol.data_ptr())
+        times = []
+        for ply in range(8):
+            torch.cuda.synchronize(); ctx.synchronize(); t0 = time.perf_counter()
+            ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0 if form.startswith("integer") else pol.data_ptr(), seat.data_ptr(), 16)
+            ctx.synchronize(); times.append(time.perf_counter() - t0)
+        by_form[form] = {"seconds_8_launches": sum(times), "episodes_per_s": n / sum(times), "achieved_GBps": 8 * n * 44 / sum(times) / 1e9,
+                         "frac_of_hbm_peak": 8 * n * 44 / sum(times) / 1e9 / 8000.0, "seconds_per_ply": times}
+    k = sum(times)                                     # the form evaluate_agent_device uses (the last one timed)
     print(json.dumps({"kernel": "k_eval_tabular_step", "episodes": n, "policy": f"average policy after {a.cfr_iterations} vanilla-CFR iterations", "reward_vs_random": reward,
                       "reward_std_error": stats["reward_std_error"], "scopas_trained_vs_random": [stats["trained_avg"], stats["opponent_avg"]],
                       "seconds_8_launches": k, "seconds_per_ply": times, "episodes_per_s_kernels": n / k, "episode_plies_per_s": 8 * n / k,
-                      "algorithmic_bytes_per_episode_ply": 44, "achieved_GBps": 8 * n * 44 / k / 1e9, "frac_of_hbm_peak": 8 * n * 44 / k / 1e9 / 8000.0,
+                      "algorithmic_bytes_per_episode_ply": 44, "by_sampling_form": by_form, "achieved_GBps": 8 * n * 44 / k / 1e9, "frac_of_hbm_peak": 8 * n * 44 / k / 1e9 / 8000.0,
                       "evaluate_agent_device_wall_s": wall, "episodes_per_s_incl_host_statistics": n / wall,
                       "reference_python_episodes_per_s": "~550 (500 episodes every 5 iterations dominate run_mccfr_experiment.py; BASELINE.md section 2)"}))
 

@@ -245,6 +245,10 @@ int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const 
 
 /* one ply of n lockstep evaluation episodes of a TABULAR policy d_policy[n_infosets][4] (float64, hand order) vs uniform
  * random: evaluate_agent (vanilla_cfr.py:157-216).  d_node_idx[n] tracks each episode's tree node (start at 0). */
+/* the sampling thresholds of a tabular policy ([n_infosets][4] float64, device), computed once per evaluation: scopa_eval_tabular_step with d_policy = NULL then
+ * samples the trained seat by integer compares against them -- the same actions, bit for bit, as the float64 divisions of np.random.choice it performs when
+ * given the policy itself.  Invalidated by scopa_set_deal. */
+int32_t scopa_eval_tabular_prepare(scopa_ctx *ctx, const double *d_policy);
 int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *d_node_idx, int64_t n, int32_t ply,
                                 const double *d_policy, const int32_t *d_trained_seat, uint32_t stream_id);
 

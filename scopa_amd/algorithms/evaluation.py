@@ -73,8 +73,9 @@ def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16
     idx = torch.zeros(n, dtype=torch.int32, device=dev)
     seat = (torch.arange(n, device=dev) >= (n + 1) // 2).to(torch.int32)      # episode e < n / 2: the trained agent sits in seat 0 (vanilla_cfr.py:173-176)
     torch.cuda.synchronize()
+    ctx.eval_tabular_prepare(pol.data_ptr())                  # the policy's sampling thresholds, once: the plies compare integers (same actions, bit for bit)
     for ply in range(8):
-        ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, pol.data_ptr(), seat.data_ptr(), stream_id)
+        ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0, seat.data_ptr(), stream_id)
     ctx.synchronize()
     # the statistics are reduced on the device (float64; every term is a multiple of 0.5, so the sums are exact): only a dozen numbers
     # cross to the host instead of the 16 n bytes of final states

@@ -59,6 +59,8 @@ struct scopa_ctx {
     uint64_t sdcfr_visits = 0;  // decision-node visits of SDCFR traversals (one per frontier slot featurised)
     void *d_sdnode = nullptr;   // [kDecision] uint2: feature bits | mover's hand nibbles of every decision node (scopa_sdcfr.hip: k_sdcfr_nodeinfo), built at first use per deal
     bool sdnode_valid = false;  // false after scopa_set_deal
+    void *d_eval_thr = nullptr;        // [kDecision][3] uint64: sampling thresholds of the tabular policy last given to scopa_eval_tabular_prepare
+    bool eval_thr_valid = false;
     void *d_train_partial = nullptr;   // [32][13777] float: per-workgroup partial gradients (+ partial loss) of scopa_sdcfr_train_step
     void *d_sdpol = nullptr;    // [kDecision] float4: regret-matching policy of every decision node under the nets of the launch at hand (k_sdcfr_policy)
     int sdcfr_mode = 0;         // 0 = policy table per launch + walks (one deal: every node evaluated once), 1 = a forward pass per visit (k_sdcfr_traverse)

@@ -223,9 +223,36 @@ k_cfr_sync(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__ g_
 // Batched evaluation of a TABULAR policy against uniform random (evaluate_agent, vanilla_cfr.py:157-216 /
 // mc_cfr.py:146-206): n episodes of the context's deal in lockstep.  Each lane keeps the packed state (advanced
 // with the same device step as everything else) and its tree index, so the trained seat's policy row is one table lookup.
+// Sampling thresholds of a tabular policy, once per evaluation: np.random.choice(actions, p = probs) is index = #{q : cdf_q / cdf_last <= u}, and every u an
+// episode draws is N * 2^-53 with an integer N (u53 of two Philox words); x * 2^53 is exact in float64, so x <= u  <=>  ceil(x * 2^53) <= N -- the three
+// float64 divisions of a visit become three integer compares against rows computed here, the same answer bit for bit (the SDCFR policy table's idea).
+// thr[r][k] = 2^53 (never counted) for k >= n - 1 and for rows whose probabilities sum to 0 or NaN (the division gives NaN there and no compare holds).
+__global__ void __launch_bounds__(256)
+k_eval_thresholds(const uint64_t *__restrict__ g_key, const double *__restrict__ policy /*[I][4]*/, int n_infosets, unsigned long long *__restrict__ thr /*[I][3]*/) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n_infosets) return;
+    const int n = (int)((g_key[r] >> 1) & 7);
+    const double *row = policy + (size_t)r * 4;
+    double c = 0.0, cdf[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int q = 0; q < n; q++) { c = q ? c + row[q] : row[0]; cdf[q] = c; }
+    const double last = n > 0 ? cdf[n - 1] : 0.0;
+    for (int k = 0; k < 3; k++) {
+        unsigned long long t = 1ull << 53;
+        if (k < n - 1) {
+            const double x = cdf[k] / last;
+            if (x <= 0.0) t = 0ull;                                  // x <= u for every u >= 0
+            else if (x < 1.0) t = (unsigned long long)ceil(x * 9007199254740992.0);
+            // x >= 1 or NaN: never <= u (u < 1)
+        }
+        thr[(size_t)r * 3 + k] = t;
+    }
+}
+
+// THR: the trained seat samples by the prepared integer thresholds (scopa_eval_tabular_prepare) instead of by float64 divisions of the policy row
+template <bool THR>
 __global__ void __launch_bounds__(256)
 k_eval_tabular_step(scopa_state *__restrict__ states, int32_t *__restrict__ node_idx, long long n, int ply,
-                    const uint16_t *__restrict__ g_infoset, const double *__restrict__ policy /*[I][4]*/,
+                    const uint16_t *__restrict__ g_infoset, const double *__restrict__ policy /*[I][4]*/, const unsigned long long *__restrict__ thr /*[I][3]*/,
                     const int32_t *__restrict__ trained_seat, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -234,17 +261,24 @@ k_eval_tabular_step(scopa_state *__restrict__ states, int32_t *__restrict__ node
     const int p = s.step & 1, nl = s.nh[p];
     const int idx = node_idx[i];
     const philox_out x = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)ply, stream, seed_lo, seed_hi);
-    const double u = u53(x.x0, x.x1);
     int k = nl - 1;
     if (p == trained_seat[i]) {  // np.random.choice(actions, p=probs): cumsum, normalise, searchsorted right
-        const double *row = policy + (size_t)g_infoset[level_offset(ply) + idx] * 4;
-        double c = 0.0, cdf[4];
-        for (int q = 0; q < nl; q++) { c = q ? c + row[q] : row[0]; cdf[q] = c; }
-        const double last = cdf[nl - 1];
         int a = 0;
-        for (int q = 0; q < nl; q++) if (cdf[q] / last <= u) a = q + 1;
+        if (THR) {
+            const unsigned long long *t = thr + (size_t)g_infoset[level_offset(ply) + idx] * 3;
+            const unsigned long long N = ((unsigned long long)(x.x0 >> 5) << 26) | (unsigned long long)(x.x1 >> 6);   // u = N * 2^-53
+            a = (int)(t[0] <= N) + (int)(t[1] <= N) + (int)(t[2] <= N);
+        } else {
+            const double u = u53(x.x0, x.x1);
+            const double *row = policy + (size_t)g_infoset[level_offset(ply) + idx] * 4;
+            double c = 0.0, cdf[4];
+            for (int q = 0; q < nl; q++) { c = q ? c + row[q] : row[0]; cdf[q] = c; }
+            const double last = cdf[nl - 1];
+            for (int q = 0; q < nl; q++) if (cdf[q] / last <= u) a = q + 1;
+        }
         k = a < nl - 1 ? a : nl - 1;
     } else {  // uniform opponent
+        const double u = u53(x.x0, x.x1);
         const int a = (int)(u * (double)nl);
         k = a < nl - 1 ? a : nl - 1;
     }
@@ -271,14 +305,32 @@ int32_t scopa_cfr_sync_iterate(scopa_ctx *ctx, int32_t n_iters) {
     return SCOPA_OK;
 }
 
+int32_t scopa_eval_tabular_prepare(scopa_ctx *ctx, const double *d_policy) {
+    if (!ctx || !d_policy) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_eval_tabular_prepare: no deal set");
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    if (!ctx->d_eval_thr) SC_HIP(ctx, hipMalloc(&ctx->d_eval_thr, sizeof(unsigned long long) * 3 * (size_t)kDecision));
+    hipLaunchKernelGGL(k_eval_thresholds, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key, d_policy, ctx->n_infosets,
+                       (unsigned long long *)ctx->d_eval_thr);
+    SC_HIP(ctx, hipGetLastError());
+    ctx->eval_thr_valid = true;
+    return SCOPA_OK;
+}
+
 int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *d_node_idx, int64_t n, int32_t ply,
                                 const double *d_policy, const int32_t *d_trained_seat, uint32_t stream_id) {
-    if (!ctx || n < 0 || ply < 0 || ply >= kPlies || (n && (!d_states || !d_node_idx || !d_policy || !d_trained_seat))) return SCOPA_EINVAL;
+    if (!ctx || n < 0 || ply < 0 || ply >= kPlies || (n && (!d_states || !d_node_idx || !d_trained_seat))) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_eval_tabular_step: no deal set");
+    SC_REQUIRE(ctx, d_policy || ctx->eval_thr_valid, SCOPA_ESTATE, "scopa_eval_tabular_step: no policy given and none prepared (scopa_eval_tabular_prepare)");
     if (!n) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_eval_tabular_step, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, d_node_idx,
-                       (long long)n, (int)ply, ctx->d_infoset, d_policy, d_trained_seat, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), stream_id);
+    if (d_policy)
+        hipLaunchKernelGGL(k_eval_tabular_step<false>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, d_node_idx, (long long)n, (int)ply,
+                           ctx->d_infoset, d_policy, (const unsigned long long *)nullptr, d_trained_seat, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), stream_id);
+    else
+        hipLaunchKernelGGL(k_eval_tabular_step<true>, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ctx->stream, d_states, d_node_idx, (long long)n, (int)ply,
+                           ctx->d_infoset, (const double *)nullptr, (const unsigned long long *)ctx->d_eval_thr, d_trained_seat, (uint32_t)ctx->seed,
+                           (uint32_t)(ctx->seed >> 32), stream_id);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }

@@ -130,7 +130,7 @@ int32_t scopa_ctx_destroy(scopa_ctx *ctx) {
     scopa::mccfr_graphs_clear(ctx);
     for (hipEvent_t e : ctx->ev_pool) (void)hipEventDestroy(e);
     void *bufs[] = {ctx->d_states, ctx->d_infoset, ctx->d_payoff, ctx->d_key, ctx->d_meta, ctx->d_regret, ctx->d_strat,
-                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_visit, ctx->d_sigcdf, ctx->d_groups, ctx->d_clock, ctx->d_sched, ctx->d_lane_tab, ctx->d_sdnode, ctx->d_sdpol, ctx->d_train_partial};
+                    ctx->d_local, ctx->d_delta_own, ctx->d_scratch, ctx->d_counters, ctx->d_visit, ctx->d_sigcdf, ctx->d_groups, ctx->d_clock, ctx->d_sched, ctx->d_lane_tab, ctx->d_sdnode, ctx->d_sdpol, ctx->d_train_partial, ctx->d_eval_thr};
     for (void *b : bufs) if (b) (void)hipFree(b);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -226,6 +226,7 @@ int32_t scopa_set_deal(scopa_ctx *ctx, const uint8_t perm16[16]) {
     ctx->d_delta = ctx->d_delta_own;  // a new deal drops any caller-bound delta buffer
     ctx->sched_valid = false;         // ... and the exact-CFR schedule of the previous deal
     ctx->sdnode_valid = false;        // ... and the SDCFR traversal's per-node feature bits
+    ctx->eval_thr_valid = false;      // ... and an evaluation policy's thresholds (indexed by THIS deal's infoset ids)
     scopa::mccfr_graphs_clear(ctx);   // ... and captured iteration graphs (their launches carry the old deal's sizes)
     return scopa_tables_reset(ctx);
 }

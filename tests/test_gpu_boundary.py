@@ -267,6 +267,43 @@ def test_device_evaluation_agrees_with_host_evaluation(game):
     assert abs(avg_u) < 0.03
 
 
+def test_tabular_evaluator_thresholds_sample_like_the_float_divisions(game):
+    """scopa_eval_tabular_prepare + scopa_eval_tabular_step(policy = NULL) -- integer thresholds per infoset, computed once -- against the step given the
+    policy itself (np.random.choice's cumsum / normalise / searchsorted in float64 per visit): the SAME final states, episode for episode, for a trained
+    policy, the uniform one, a one-hot one and one with all-zero rows (no compare holds there: action 0)."""
+    import torch
+    from scopa_amd.algorithms import CFRTrainer
+    tr = CFRTrainer(game)
+    tr.train(steps=40)
+    ctx = tr._engine.ctx
+    trained = ctx.exploitability(return_policy=True)["policy"]
+    nl = np.asarray(tr._engine.nlegal)
+    uni = np.zeros_like(trained)
+    onehot = np.zeros_like(trained)
+    for i, k in enumerate(nl):
+        uni[i, :k] = 1.0 / k
+        onehot[i, (7 * i) % k] = 1.0
+    holes = trained.copy()
+    holes[::3] = 0.0
+    n = 300000
+    seat = (torch.arange(n, device="cuda:0") >= n // 2).to(torch.int32)
+    for name, P in (("trained", trained), ("uniform", uni), ("one-hot", onehot), ("zero rows", holes)):
+        pol = torch.as_tensor(np.ascontiguousarray(P, np.float64), device="cuda:0")
+        finals = []
+        for prepared in (False, True):
+            states = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+            idx = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+            ctx.eval_init_states(states.data_ptr(), n)
+            torch.cuda.synchronize()
+            if prepared:
+                ctx.eval_tabular_prepare(pol.data_ptr())
+            for ply in range(8):
+                ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0 if prepared else pol.data_ptr(), seat.data_ptr(), 77)
+            ctx.synchronize()
+            finals.append((states.clone(), idx.clone()))
+        assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]), name
+
+
 def test_device_clock_profile_of_sampled_traversal_launches(ctx, sl):
     ctx.set_deal(sl.deal_py_seed(42))
     ctx.mccfr_seed(5)
