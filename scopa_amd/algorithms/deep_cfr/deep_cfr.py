@@ -1,10 +1,12 @@
 """Single Deep CFR on MiniScopa with the reference's interface (mirrors src/algorithms/deep_cfr/deep_cfr.py).
 
-What moved to the GPU: the external-sampling traversal (level-synchronous HIP kernels, `batch` traversals at once,
-ONE batched MLP forward per ply instead of a batch-1 forward per node), feature/mask encoding, regret normalisation and
-the advantage memory (a device-resident FIFO ring the kernels write into directly), and evaluation vs random (all
-episodes in lockstep on the device step kernel).  What stays PyTorch: the advantage MLP, Adam, the MSE loss -- on
-PyTorch-ROCm.  `batch=1` is the reference's shape (one traversal per player per iteration, 41 rows each).
+What moved to the GPU: the external-sampling traversal (`batch` traversals per call: the deal's decision nodes evaluated once per
+call on the matrix cores, the traversals as walks over that policy table -- or a forward pass per visit in one launch, or ply by
+ply around a PyTorch forward), feature/mask encoding, regret normalisation and the advantage memory (a device-resident FIFO ring
+the kernels write into directly), the strategy snapshots (slots of preallocated tensors) and evaluation vs random (all episodes in
+lockstep on the device step kernel).  What stays PyTorch: the advantage MLP, Adam, the MSE loss -- on PyTorch-ROCm, graph-replayed
+on request; `train_backend="hip"` swaps the optimiser step for two hand-written launches (opt-in).  `batch=1` is the reference's
+shape (one traversal per player per iteration, 41 rows each).  DeepCFR.train keeps the host one iteration ahead of the device.
 """
 import random
 
