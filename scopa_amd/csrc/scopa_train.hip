@@ -4,9 +4,10 @@
 // is about thirty dependent PyTorch kernels of 4-5 us each whatever they compute.  The default stays PyTorch (north_star: "the SDCFR
 // advantage MLP trains on PyTorch-ROCm"); this file is the OPT-IN alternative (`DeepCFR(train_backend="hip")`), measured beside it:
 //   k_sdcfr_train_grad : a workgroup per group of 16-row tiles; forward and backward of a tile on v_mfma_f32_16x16x4_f32 with the activations in LDS
-//                        ([row][unit], odd strides), the weights read from the net's own torch tensors W[out][in] as MFMA operands; the weight gradients
-//                        accumulate in MFMA accumulators across the workgroup's tiles and leave as ONE partial gradient per workgroup (fixed order: the
-//                        result does not depend on scheduling);
+//                        ([row][unit], odd strides) and the weights staged there once per workgroup from the net's own torch tensors W[out][in] (coalesced
+//                        8- / 16-byte loads; both W and W^T operands are read from the one copy); the weight gradients accumulate in MFMA accumulators
+//                        across the workgroup's tiles and leave as ONE partial gradient per workgroup (summed later in fixed order: the result does not
+//                        depend on scheduling);
 //   k_sdcfr_train_adam : one workgroup: sums the partials in order, 2-norm of the whole gradient, clip coefficient min(1, 1 / (norm + 1e-6)), Adam's update
 //                        (bias-corrected, eps outside the square root, as torch.optim.Adam) in place on the net's tensors and on the [2][13776] moment buffer.
 // MFMA roles (one instruction = a 16 x 16 tile over 4 K values): A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16], D lane l register r = D[4 (l / 16) + r][l % 16].
