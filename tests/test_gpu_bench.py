@@ -93,6 +93,11 @@ def test_bench_sdcfr_workload(ctx):
     assert d["roofline"]["kernel"].startswith("k_sdcfr_walk") and 0.0 < d["roofline"]["frac"] <= 1.0
 
 
+def test_bench_sdcfr_with_the_hand_written_optimiser_step(ctx):
+    d = _bench("--workload", "sdcfr", "--steps", "3", "--warmup", "1", "--batch", "256", "--no-cpu-baseline", "--sdcfr-train-backend", "hip")
+    assert "hand-written" in d["config"]["training"] and "with_hip_training_step" not in d and d["decision_visits"] == (105 + 82) * 256 * 3
+
+
 def test_bench_sdcfr_two_ranks_spawned(ctx):
     """BASELINE configs[4] at rehearsal scale: `--workload sdcfr --gpus 2` started plainly, both ranks on the one GPU."""
     d = _bench("--workload", "sdcfr", "--gpus", "2", "--share-gpu", "--steps", "2", "--warmup", "1", "--batch", "128", "--no-cpu-baseline")
