@@ -51,13 +51,18 @@ enum {
 /* Packed game state, 16 bytes, the unit the kernels keep in HBM.  Hands and table are ORDERED lists of
  * 4-bit card ids (card id = action id = suit*4 + rank_idx, mini_scopa_game.py:17-23,149-153); list order
  * is part of the infoset identity (openspiel_mini_scopa.py:86-95).  Unused nibbles are zero.
- * to_move = step & 1; terminal iff (nh[0]==0 && nh[1]==0) || step >= 8 (mini_scopa_game.py:160). */
+ * to_move = step & 1; terminal iff (nh[0]==0 && nh[1]==0) || step_count >= max_steps (mini_scopa_game.py:160), where
+ * step_count = step & SCOPA_STEP_COUNT_MASK and max_steps = 8 (a fresh env, mini_scopa_game.py:127), or 16 when
+ * SCOPA_STEP_CLONED is set: the env of a MiniScopaState.clone() (openspiel_mini_scopa.py:108).  Only illegal no-op actions make
+ * the two differ; scopa_state_clone() sets the bit, every other entry point preserves it. */
+#define SCOPA_STEP_CLONED 0x80u
+#define SCOPA_STEP_COUNT_MASK 0x7Fu
 typedef struct scopa_state {
     uint16_t hand[2];   /* nibble i = i-th card of the hand                  */
     uint32_t table;     /* nibble i = i-th card on the table                 */
     uint8_t  nh[2];     /* cards in hand                                     */
     uint8_t  nt;        /* cards on table                                    */
-    uint8_t  step;      /* MiniScopaEnv.step_count                           */
+    uint8_t  step;      /* MiniScopaEnv.step_count | SCOPA_STEP_CLONED       */
     uint8_t  ncap[2];   /* len(player.captures)                              */
     uint8_t  scopas[2]; /* player.scopas                                     */
 } scopa_state;
@@ -80,6 +85,7 @@ int32_t scopa_ctx_synchronize(scopa_ctx *ctx);
 int32_t scopa_deal_py_seed(int64_t seed, uint8_t perm16[16]);              /* MiniDeck.__init__ :25-28        */
 int32_t scopa_state_init(const uint8_t perm16[16], scopa_state *out);      /* MiniScopaGame.reset :56-64      */
 int32_t scopa_state_step(scopa_state *s, int32_t action);                  /* MiniScopaEnv.step :140-167      */
+int32_t scopa_state_clone(const scopa_state *s, scopa_state *out);         /* MiniScopaState.clone, openspiel_mini_scopa.py:97-115: a copy whose max_steps is 16 (:108) */
 int32_t scopa_state_is_terminal(const scopa_state *s);                     /* 0/1                             */
 int32_t scopa_state_current_player(const scopa_state *s);                  /* 0/1, -4 at terminal             */
 int32_t scopa_state_legal(const scopa_state *s, int32_t player /* <0 = current */, int32_t out[4], int32_t *n);

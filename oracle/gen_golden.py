@@ -13,6 +13,7 @@ Fixtures (consumers: tests/, oracle pinning):
   deals.json          seed -> 16-card permutation of random.seed(seed)+shuffle   (mini_scopa_game.py:25-28)
   tree_seed<S>.npz    every node of the game tree in reference DFS order          (openspiel_mini_scopa.py:17-115)
   playouts.json       random action strings incl. ILLEGAL actions (silent no-op)  (mini_scopa_game.py:140-167)
+  playouts_cloned.json the same through MiniScopaState.clone(): a clone plays to step 16  (openspiel_mini_scopa.py:97-115, line 108)
   vanilla_cfr.npz     CFRTrainer tables after 1,2,5,50,200 iterations             (vanilla_cfr.py:56-120)
   mccfr.npz           MCCFRTrainer tables under np.random.seed(k)                 (mc_cfr.py:37-99)
   MiniScopa_MCCFR_data.reference.json  the reference's committed 10-run MCCFR experiment output (experiment_tracker.py:82-158)
@@ -176,6 +177,64 @@ def gen_playouts(ns):
     with open(os.path.join(OUT, "playouts.json"), "w") as f:
         json.dump(cases, f)
     print("playouts:", len(cases))
+
+
+# ----------------------------------------------------------------------------------
+def gen_playouts_cloned(ns):
+    """Playouts that go through MiniScopaState.clone() (openspiel_mini_scopa.py:97-115).  A clone's env has max_steps = 16 (:108)
+    where a fresh env has num_players * 4 = 8 (mini_scopa_game.py:127), so a cloned state that absorbs illegal no-op actions plays on
+    past step 8 until both hands are empty or step 16 (terminal rule mini_scopa_game.py:160).  Every ply records what playouts.json
+    records plus both players' legal actions, the rewards, and whether the live state is a clone (`cloned`); `clone_before[i]` says
+    that the state was replaced by its clone() just before action i.  Cases with k % 4 == 0 play legal actions only (clone or not,
+    the trail is the un-cloned one); the others draw 35 % of their actions from 0..15."""
+    import pyspiel
+    game = pyspiel.load_game("mini_scopa")
+    rng = np.random.RandomState(20261005)
+    cases = []
+    for seed in [42, 0, 1, 2, 3, 5, 7, 11, 13, 123, 2024, 99991]:
+        for k in range(20):
+            st = _new_state(ns, game, seed)
+            acts, trail, clone_before = [], [], []
+            cloned = False
+            p_clone = (0.35, 0.15, 0.35, 1.0)[k % 4]
+            while not st.is_terminal():
+                do_clone = bool(rng.rand() < p_clone)
+                if do_clone:
+                    st = st.clone()
+                    cloned = True
+                legal = st.legal_actions()
+                if k % 4 == 0 or rng.rand() < 0.65:
+                    a = int(legal[rng.randint(len(legal))])
+                else:
+                    a = int(rng.randint(16))
+                acts.append(a)
+                clone_before.append(do_clone)
+                st.apply_action(a)
+                hands, table, ncap, scopas, step = _snap(st)
+                term = bool(st.is_terminal())
+                trail.append(dict(hands=hands, table=table, ncap=ncap, scopas=scopas, step=step, term=term,
+                                  cur=int(st.current_player()) if not term else -4,
+                                  legal0=[int(x) for x in st.legal_actions(0)], legal1=[int(x) for x in st.legal_actions(1)],
+                                  info0=st.information_state_string(0), info1=st.information_state_string(1),
+                                  rewards=[float(r) for r in st.rewards()], hist=st.history_str(), cloned=cloned,
+                                  max_steps=int(st.env.max_steps)))
+            assert len(acts) <= 16
+            # a clone of a TERMINAL state stays terminal whatever its max_steps: _is_terminal and the terminations dict are copied
+            # (openspiel_mini_scopa.py:112-113, mini_scopa_game.py:193), so a further action is a dead step (:141-143)
+            cl = st.clone()
+            dead = int(rng.randint(16))
+            cl.apply_action(dead)
+            hands, table, ncap, scopas, step = _snap(cl)
+            after = dict(action=dead, hands=hands, table=table, ncap=ncap, scopas=scopas, step=step, term=bool(cl.is_terminal()),
+                         legal0=[int(x) for x in cl.legal_actions(0)], rewards=[float(r) for r in cl.rewards()], hist=cl.history_str(),
+                         info0=cl.information_state_string(0), max_steps=int(cl.env.max_steps))
+            cases.append(dict(seed=seed, actions=acts, clone_before=clone_before, trail=trail, rewards=[float(r) for r in st.rewards()],
+                              terminal_clone=after))
+    with open(os.path.join(OUT, "playouts_cloned.json"), "w") as f:
+        json.dump(cases, f, separators=(",", ":"))
+    past8 = sum(1 for c in cases if len(c["actions"]) > 8)
+    print("playouts_cloned:", len(cases), "cases,", past8, "play past step 8, longest", max(len(c["actions"]) for c in cases),
+          "plies; hands left at the end in", sum(1 for c in cases if any(c["trail"][-1]["hands"])), "cases")
 
 
 # ----------------------------------------------------------------------------------
@@ -822,7 +881,7 @@ def gen_exploitability(ns):
         json.dump(out, f, separators=(",", ":"))
 
 
-ALL = dict(exploitability=gen_exploitability, vanilla_experiment=gen_vanilla_experiment, experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, cfr=gen_cfr, mccfr=gen_mccfr,
+ALL = dict(exploitability=gen_exploitability, vanilla_experiment=gen_vanilla_experiment, experiment=gen_experiment, tracker=gen_tracker, mccfr_frozen=gen_mccfr_frozen, team=gen_team, full=gen_full, deals=gen_deals, tree=gen_tree, playouts=gen_playouts, playouts_cloned=gen_playouts_cloned, cfr=gen_cfr, mccfr=gen_mccfr,
            evaluate=gen_evaluate, sdcfr=gen_sdcfr)
 
 if __name__ == "__main__":

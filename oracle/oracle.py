@@ -22,7 +22,7 @@ def build(force=False):
 
 class _State(C.Structure):
     _fields_ = [("hand", (C.c_int8 * 4) * 2), ("nh", C.c_int8 * 2), ("table", C.c_int8 * 8), ("nt", C.c_int8),
-                ("ncap", C.c_int8 * 2), ("scopas", C.c_int8 * 2), ("step", C.c_int8)]
+                ("ncap", C.c_int8 * 2), ("scopas", C.c_int8 * 2), ("step", C.c_int8), ("max_steps", C.c_int8)]
 
 
 _lib = None
@@ -77,8 +77,10 @@ class State:
         lib().og_reset(C.byref(self.s), _p(self.perm))
 
     def clone(self):
+        """MiniScopaState.clone() (openspiel_mini_scopa.py:97-115): the copy's env has max_steps = 16 (:108)."""
         o = State.__new__(State)
-        o.s = _State.from_buffer_copy(self.s)
+        o.s = _State()
+        lib().og_clone(C.byref(self.s), C.byref(o.s))
         o.perm = self.perm
         return o
 
@@ -117,6 +119,10 @@ class State:
         table = [int(s.table[i]) for i in range(s.nt)]
         return dict(hands=hands, table=table, ncap=[int(s.ncap[0]), int(s.ncap[1])],
                     scopas=[int(s.scopas[0]), int(s.scopas[1])], step=int(s.step))
+
+    @property
+    def max_steps(self):
+        return int(self.s.max_steps)
 
 
 class Tree:

@@ -103,11 +103,22 @@ void og_reset(og_state *s, const uint8_t perm[16]) {
         s->nh[p] = 4;
     }
     memset(s->table, -1, sizeof s->table);
+    s->max_steps = 8; /* MiniScopaEnv.__init__: max_steps = num_players * 4 (:127) */
+}
+
+void og_clone(const og_state *src, og_state *dst) {
+    /* MiniScopaState.clone, src/envs/openspiel_mini_scopa.py:97-115: set_state(get_state()) copies hands, table, captures, scopas,
+       agent_selection and step_count (mini_scopa_game.py:169-194); the new env's max_steps is the literal 16 (:108) */
+    *dst = *src;
+    /* A terminal state's clone stays terminal: the terminations dict and _is_terminal travel with it (mini_scopa_game.py:193,
+       openspiel_mini_scopa.py:112), and step() on it is a dead step (:141-143).  og_state keeps no such flag -- terminal is recomputed
+       from the fields -- so the limit that made it terminal is kept. */
+    if (!og_is_terminal(src)) dst->max_steps = 16;
 }
 
 int og_is_terminal(const og_state *s) {
     /* mini_scopa_game.py:160 */
-    return (s->nh[0] == 0 && s->nh[1] == 0) || s->step >= 8;
+    return (s->nh[0] == 0 && s->nh[1] == 0) || s->step >= s->max_steps;
 }
 
 int og_current_player(const og_state *s) {
@@ -249,7 +260,7 @@ static int tree_rec(og_tree *t, const og_state *s, int depth) {
     t->infoset[idx] = (int16_t)id;
     for (int i = 0; i < n; i++) {
         t->legal[idx * 4 + i] = (int8_t)legal[i];
-        og_state c = *s;          /* clone() */
+        og_state c; og_clone(s, &c);   /* clone() */
         og_step(&c, legal[i]);    /* apply_action */
         t->child[idx * 4 + i] = tree_rec(t, &c, depth + 1);
     }

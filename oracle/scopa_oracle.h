@@ -33,6 +33,8 @@ typedef struct {
     int8_t ncap[2];      /* len(player.captures) (:98)                                 */
     int8_t scopas[2];    /* (:100-101)                                                 */
     int8_t step;         /* env.step_count (:138,159)                                  */
+    int8_t max_steps;    /* env.max_steps: num_players * 4 = 8 for a fresh env (:127), 16 for the env of a
+                            MiniScopaState.clone() (src/envs/openspiel_mini_scopa.py:108)                 */
 } og_state;
 
 /* card id = action id = suit_idx*4 + rank_idx (mini_scopa_game.py:17-23,149-153) */
@@ -45,7 +47,10 @@ void og_deal_py_seed(int64_t seed, uint8_t perm[16]);
 void og_reset(og_state *s, const uint8_t perm[16]);
 /* openspiel_mini_scopa.py:17-45: legal actions in HAND ORDER; [0] fallback; [] at terminal. player<0 = current */
 int  og_legal(const og_state *s, int player, int out[4]);
-int  og_is_terminal(const og_state *s);                 /* mini_scopa_game.py:160 */
+int  og_is_terminal(const og_state *s);                 /* mini_scopa_game.py:160: all hands empty or step_count >= max_steps */
+/* MiniScopaState.clone (src/envs/openspiel_mini_scopa.py:97-115): the copy's env is built by hand with max_steps = 16 (:108) and
+ * filled through get_state / set_state, which carry neither max_steps nor the seed's deck */
+void og_clone(const og_state *src, og_state *dst);
 int  og_current_player(const og_state *s);              /* -4 at terminal (openspiel…:17-20) */
 /* MiniScopaEnv.step (:140-167) incl. the silent no-op for a card not in hand */
 void og_step(og_state *s, int action);

@@ -19,7 +19,7 @@ N_NODES, N_DECISION, N_TERMINAL = 2229, 1653, 576
 # every symbol include/scopa.h declares (tests check that the library exports all of them)
 SYMBOLS = [
     "scopa_abi_version", "scopa_strerror", "scopa_last_error", "scopa_ctx_create", "scopa_ctx_destroy",
-    "scopa_ctx_synchronize", "scopa_deal_py_seed", "scopa_state_init", "scopa_state_step", "scopa_state_is_terminal",
+    "scopa_ctx_synchronize", "scopa_deal_py_seed", "scopa_state_init", "scopa_state_step", "scopa_state_clone", "scopa_state_is_terminal",
     "scopa_state_current_player", "scopa_state_legal", "scopa_state_rewards_x2", "scopa_state_infoset_key",
     "scopa_key_to_string", "scopa_state_infoset_string", "scopa_step_batch", "scopa_step_batch_host", "scopa_set_deal",
     "scopa_tree_counts", "scopa_tree_export", "scopa_tables_reset", "scopa_tables_get", "scopa_tables_set",
@@ -57,6 +57,7 @@ class State16(C.Structure):
                 ("step", C.c_uint8), ("ncap", C.c_uint8 * 2), ("scopas", C.c_uint8 * 2)]
 
 
+STEP_CLONED, STEP_COUNT_MASK = 0x80, 0x7F   # include/scopa.h: SCOPA_STEP_CLONED, SCOPA_STEP_COUNT_MASK
 STATE_DTYPE = np.dtype([("hand", "<u2", (2,)), ("table", "<u4"), ("nh", "u1", (2,)), ("nt", "u1"), ("step", "u1"),
                         ("ncap", "u1", (2,)), ("scopas", "u1", (2,))])
 assert STATE_DTYPE.itemsize == 16 and C.sizeof(State16) == 16
@@ -90,6 +91,7 @@ def lib():
         "scopa_deal_py_seed": (i32, [i64, vp]),
         "scopa_state_init": (i32, [vp, C.POINTER(State16)]),
         "scopa_state_step": (i32, [C.POINTER(State16), i32]),
+        "scopa_state_clone": (i32, [C.POINTER(State16), C.POINTER(State16)]),
         "scopa_state_is_terminal": (i32, [C.POINTER(State16)]),
         "scopa_state_current_player": (i32, [C.POINTER(State16)]),
         "scopa_state_legal": (i32, [C.POINTER(State16), i32, C.POINTER(i32 * 4), C.POINTER(i32)]),

@@ -238,6 +238,17 @@ int32_t scopa_state_step(scopa_state *s, int32_t action) {
     return SCOPA_OK;
 }
 
+int32_t scopa_state_clone(const scopa_state *s, scopa_state *out) {
+    // MiniScopaState.clone (openspiel_mini_scopa.py:97-115): set_state(get_state()) copies the position; the new env's max_steps is 16 (:108)
+    if (!s || !out) return SCOPA_EINVAL;
+    // a terminal state's clone stays terminal (the terminations dict and _is_terminal are copied, mini_scopa_game.py:193, openspiel…:112):
+    // terminal is recomputed from the fields here, so the limit that ended the game is kept
+    scopa_state c = *s;
+    if (!is_terminal(c)) c.step = (uint8_t)(c.step | SCOPA_STEP_CLONED);
+    *out = c;
+    return SCOPA_OK;
+}
+
 int32_t scopa_state_is_terminal(const scopa_state *s) { return s ? (is_terminal(*s) ? 1 : 0) : SCOPA_EINVAL; }
 
 int32_t scopa_state_current_player(const scopa_state *s) { return s ? current_player(*s) : SCOPA_EINVAL; }

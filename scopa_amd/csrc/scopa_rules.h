@@ -46,8 +46,13 @@ SC_HD uint32_t nib_remove(uint32_t list, int i) {
     return lo | hi;
 }
 
-SC_HD bool is_terminal(const scopa_state &s) {  // mini_scopa_game.py:160
-    return ((s.nh[0] | s.nh[1]) == 0) || s.step >= 8;
+// terminal iff all hands are empty or step_count >= env.max_steps (mini_scopa_game.py:160).  max_steps is num_players * 4 = 8 for a fresh
+// env (:127) and 16 for the env of a MiniScopaState.clone() (openspiel_mini_scopa.py:108): the state carries that as SCOPA_STEP_CLONED in
+// `step`.  Only illegal no-op actions (:155-159) can make the difference visible -- legal play empties both hands at step 8 either way --
+// so every solver kernel, which plays hand cards only, sees the bit clear; parity (step & 1 = the mover) is unaffected by it.
+SC_HD int step_count(const scopa_state &s) { return s.step & SCOPA_STEP_COUNT_MASK; }
+SC_HD bool is_terminal(const scopa_state &s) {
+    return ((s.nh[0] | s.nh[1]) == 0) || step_count(s) >= ((s.step & SCOPA_STEP_CLONED) ? 16 : 8);
 }
 SC_HD int current_player(const scopa_state &s) {  // openspiel_mini_scopa.py:17-20; PlayerId.TERMINAL = -4
     return is_terminal(s) ? -4 : (s.step & 1);

@@ -187,14 +187,23 @@ class MiniScopaEnv:
             return  # _was_dead_step
         agent = self.agent_selection
         idx = self.agent_name_mapping[agent]
+        self._sync_limit()
         self.game.play_action(int(action), idx)
-        self.step_count = int(self.game.packed.step)
+        self.step_count = int(self.game.packed.step) & _lib.STEP_COUNT_MASK
         if _lib.lib().scopa_state_is_terminal(C.byref(self.game.packed)):
             r = self.game.evaluate_game()
             for i, a in enumerate(self.agents):
                 self.rewards[a] = r[i]
                 self.terminations[a] = True
         self.agent_selection = self.agents[(self.agents.index(agent) + 1) % self.num_players]
+
+    def _sync_limit(self):
+        """env.max_steps -> the packed state: 8 for a fresh env (mini_scopa_game.py:127), 16 for a clone's (openspiel_mini_scopa.py:108);
+        the terminal rule (:160) reads it from the state's SCOPA_STEP_CLONED bit."""
+        if self.max_steps not in (8, 16):
+            raise ValueError("MiniScopaEnv.max_steps is 8 (fresh env) or 16 (clone) in the reference; the packed state carries no other limit")
+        s = self.game.packed
+        s.step = (s.step & _lib.STEP_COUNT_MASK) | (_lib.STEP_CLONED if self.max_steps == 16 else 0)
 
     def get_state(self):
         g = self.game
@@ -228,26 +237,31 @@ class MiniScopaEnv:
         self.agent_selection = state["agent_selection"]
         self.step_count = state["step_count"]
         s.step = self.step_count
+        self._sync_limit()                 # set_state leaves max_steps as it is (mini_scopa_game.py:184-194)
         self.agents = state["agents"][:]
         self.rewards = dict(state["rewards"])
         self.terminations = dict(state["terminations"])
         self.truncations = dict(state["truncations"])
 
     def clone(self):
-        """Cheap copy used by MiniScopaState.clone(): 16 bytes + the capture lists."""
+        """Cheap copy used by MiniScopaState.clone(): 16 bytes + the capture lists.  As in the reference (openspiel_mini_scopa.py:97-115)
+        the copy's max_steps is 16 (:108), not num_players * 4: a clone fed illegal no-op actions plays on past step 8."""
         e = MiniScopaEnv.__new__(MiniScopaEnv)
         e.num_players = self.num_players
         e.possible_agents = self.possible_agents
         e.agent_name_mapping = self.agent_name_mapping
         e._action_spaces = self._action_spaces
-        e.max_steps = self.max_steps
+        e.max_steps = 16
         e.seed = self.seed
         g = MiniScopaGame.__new__(MiniScopaGame)
         g.num_players = self.game.num_players
         g.players = [Player(p.name) for p in self.game.players]
         for q, p in zip(g.players, self.game.players):
             q.captures = list(p.captures)
-        g.packed = _lib.State16.from_buffer_copy(self.game.packed)
+        g.packed = _lib.State16()
+        rc = _lib.lib().scopa_state_clone(C.byref(self.game.packed), C.byref(g.packed))
+        if rc:
+            raise _lib.ScopaError(rc, "scopa_state_clone")
         g.perm = self.game.perm
         g.deck = self.game.deck
         g.last_capture = None

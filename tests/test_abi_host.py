@@ -52,6 +52,47 @@ def test_host_state_protocol_on_golden_playouts(sl, golden):
         assert [r2[0] / 2, r2[1] / 2] == c["rewards"]
 
 
+def test_host_state_protocol_on_cloned_playouts(sl, golden):
+    """scopa_state_clone = MiniScopaState.clone (openspiel_mini_scopa.py:97-115): the copy's step limit is 16 (:108), carried in the packed
+    state (SCOPA_STEP_CLONED); every ply of the reference's cloned playouts through the C ABI."""
+    L = sl.lib()
+    buf = C.create_string_buffer(96)
+    for c in golden.json("playouts_cloned.json"):
+        s = sl.State16()
+        perm = sl.deal_py_seed(c["seed"])
+        assert L.scopa_state_init(perm.ctypes.data_as(C.c_void_p), C.byref(s)) == 0
+        for a, cb, tr in zip(c["actions"], c["clone_before"], c["trail"]):
+            if cb:
+                t = sl.State16()
+                assert L.scopa_state_clone(C.byref(s), C.byref(t)) == 0
+                s = t
+            assert L.scopa_state_step(C.byref(s), a) == 0
+            assert bool(s.step & sl.STEP_CLONED) == tr["cloned"]
+            sn = unpack_state(s)
+            sn["step"] &= sl.STEP_COUNT_MASK
+            for k in sn:
+                assert sn[k] == tr[k], (c["seed"], c["actions"], k)
+            assert bool(L.scopa_state_is_terminal(C.byref(s))) == tr["term"]
+            assert L.scopa_state_current_player(C.byref(s)) == tr["cur"]
+            out, n = (C.c_int32 * 4)(), C.c_int32()
+            for pl, k in ((0, "legal0"), (1, "legal1")):
+                assert L.scopa_state_legal(C.byref(s), pl, C.byref(out), C.byref(n)) == 0
+                assert [out[i] for i in range(n.value)] == tr[k]
+            for pl, k in ((0, "info0"), (1, "info1")):
+                L.scopa_state_infoset_string(C.byref(s), pl, buf, 96)
+                assert buf.value.decode() == tr[k]
+            r2 = (C.c_int32 * 2)()
+            L.scopa_state_rewards_x2(C.byref(s), C.byref(r2))
+            assert [r2[0] / 2, r2[1] / 2] == tr["rewards"]
+        t, tc = sl.State16(), c["terminal_clone"]   # a terminal state's clone stays terminal; a further action is a dead step
+        assert L.scopa_state_clone(C.byref(s), C.byref(t)) == 0 and L.scopa_state_step(C.byref(t), tc["action"]) == 0
+        sn = unpack_state(t)
+        sn["step"] &= sl.STEP_COUNT_MASK
+        assert all(sn[k] == tc[k] for k in sn) and L.scopa_state_is_terminal(C.byref(t)) == 1
+        L.scopa_state_rewards_x2(C.byref(t), C.byref(r2))
+        assert [r2[0] / 2, r2[1] / 2] == tc["rewards"]
+
+
 def test_host_rules_match_oracle_on_random_states(sl, oracle):
     """capture rule / step on 20k random (deal, action string) pairs, incl. illegal actions, vs the oracle."""
     L = sl.lib()

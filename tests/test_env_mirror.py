@@ -45,6 +45,32 @@ def test_state_protocol_follows_the_reference_playouts(envs, golden):
         assert st.legal_actions() == [] and st.information_state_string() == "TERMINAL"
 
 
+def test_cloned_states_follow_the_reference_past_step_8(envs, golden):
+    """MiniScopaState.clone() (openspiel_mini_scopa.py:97-115) hands back a state whose env has max_steps = 16 (:108): fed illegal no-op
+    actions it plays on past step 8 until the hands are empty or step 16.  Every ply of the reference's cloned playouts, incl. both
+    players' legal actions, the rewards and history_str; the un-cloned original is left where it was."""
+    for c in golden.json("playouts_cloned.json"):
+        st = new_state(envs, c["seed"])
+        for a, cb, want in zip(c["actions"], c["clone_before"], c["trail"]):
+            if cb:
+                orig, before = st, snap(st)
+                st = st.clone()
+                assert st.env.max_steps == 16 and snap(st) == before
+            st.apply_action(a)
+            got = snap(st)
+            got.update(legal0=st.legal_actions(0), legal1=st.legal_actions(1), rewards=[float(r) for r in st.rewards()],
+                       cloned=want["cloned"], max_steps=st.env.max_steps)
+            assert got == want, (c["seed"], c["actions"])
+            if cb:
+                assert snap(orig) == before
+        assert st.is_terminal() and st.rewards() == c["rewards"]
+        cl, tc = st.clone(), c["terminal_clone"]    # a terminal state's clone stays terminal; a further action is a dead step
+        cl.apply_action(tc["action"])
+        got = snap(cl)
+        got.update(legal0=cl.legal_actions(0), rewards=[float(r) for r in cl.rewards()], max_steps=cl.env.max_steps, action=tc["action"])
+        assert {k: got[k] for k in tc} == tc
+
+
 def test_clone_is_an_independent_copy_at_every_ply(envs, golden):
     """clone() at ply k, then both copies are played on: the clone follows the reference's trail, and playing the clone never
     disturbs the original (hands, table, captures, scopas, turn, history, terminal flag, rewards)."""

@@ -58,6 +58,83 @@ def test_step_batch_edge_cases(ctx, sl):
     assert s.tobytes() == before.tobytes()
 
 
+def test_step_batch_cloned_states_play_to_step_16(ctx, sl, golden):
+    """a MiniScopaState.clone() has max_steps 16 (openspiel_mini_scopa.py:108).  The 240 reference playouts that clone
+    at random plies (tests/golden/playouts_cloned.json), all stepped in lockstep by k_step_batch through scopa_step_batch: every ply of
+    every game bit-exact, incl. the plies past step 8 that an un-cloned state never reaches; finished games take dead steps."""
+    cases = golden.json("playouts_cloned.json")
+    n = len(cases)
+    L = sl.lib()
+    import ctypes as C
+    states = np.zeros(n, sl.STATE_DTYPE)
+    for i, c in enumerate(cases):
+        s = sl.State16()
+        L.scopa_state_init(sl.deal_py_seed(c["seed"]).ctypes.data_as(C.c_void_p), C.byref(s))
+        states[i] = np.frombuffer(bytes(s), sl.STATE_DTYPE)[0]
+    past8 = 0
+    for ply in range(17):
+        actions = np.zeros(n, np.uint8)
+        for i, c in enumerate(cases):
+            if ply < len(c["actions"]):
+                actions[i] = c["actions"][ply]
+                if c["clone_before"][ply]:
+                    states[i]["step"] |= sl.STEP_CLONED        # what scopa_state_clone does (checked on the host in test_abi_host)
+            else:
+                actions[i] = (7 * i + ply) & 15                # game over: any action is a dead step
+        before = states.copy()
+        ctx.step_batch_host(states, actions)
+        for i, c in enumerate(cases):
+            if ply >= len(c["actions"]):
+                assert states[i].tobytes() == before[i].tobytes(), (i, ply)
+                continue
+            tr = c["trail"][ply]
+            sn = unpack_state(states[i])
+            assert bool(sn["step"] & sl.STEP_CLONED) == tr["cloned"]
+            sn["step"] &= sl.STEP_COUNT_MASK
+            assert sn == {k: tr[k] for k in sn}, (i, ply)
+            past8 += tr["step"] > 8
+    assert past8 > 300
+    r2 = np.array([[2 * r for r in c["rewards"]] for c in cases])
+    got = np.stack([states["ncap"][:, 0] + 2.0 * states["scopas"][:, 0], states["ncap"][:, 1] + 2.0 * states["scopas"][:, 1]], 1)
+    assert np.array_equal(got - got[:, ::-1], r2)          # evaluate_game x 2 = own points - the other's (mini_scopa_game.py:106-114)
+
+
+def test_step_batch_random_cloned_states_vs_oracle(ctx, sl, oracle):
+    """65 536 random games, each cloned at a random ply (or never), 35 % arbitrary actions, 16 lockstep plies on the GPU against the
+    oracle's literal max_steps rule."""
+    rng = np.random.RandomState(2026)
+    n = 65536
+    perms = np.stack([rng.permutation(16) for _ in range(n)]).astype(np.uint8)
+    states = np.zeros(n, sl.STATE_DTYPE)
+    states["hand"][:, 0] = (perms[:, 0] | (perms[:, 1] << 4)).astype(np.uint16) | ((perms[:, 2].astype(np.uint16) | (perms[:, 3].astype(np.uint16) << 4)) << 8)
+    states["hand"][:, 1] = (perms[:, 4] | (perms[:, 5] << 4)).astype(np.uint16) | ((perms[:, 6].astype(np.uint16) | (perms[:, 7].astype(np.uint16) << 4)) << 8)
+    states["nh"][:] = 4
+    clone_at = rng.randint(0, 20, n)                           # >= 16: never cloned
+    acts = rng.randint(0, 16, (16, n)).astype(np.uint8)
+    play_legal = rng.rand(16, n) < 0.65
+    ref = [oracle.State(perm=perms[i]) for i in range(2048)]   # the oracle follows the first 2048 games ply by ply
+    for ply in range(16):
+        hand = states["hand"][np.arange(n), ply & 1].astype(np.uint32)
+        nh = states["nh"][np.arange(n), ply & 1].astype(np.uint32)
+        pick = (hand >> (4 * (acts[ply] % np.maximum(nh, 1)))) & 15
+        a = np.where(play_legal[ply] & (nh > 0), pick, acts[ply]).astype(np.uint8)
+        over = ((states["nh"][:, 0] | states["nh"][:, 1]) == 0) | (states["step"] == 8)   # a terminal state's clone keeps its limit (scopa_state_clone)
+        states["step"][(clone_at == ply) & ~over] |= sl.STEP_CLONED
+        ctx.step_batch_host(states, a)
+        for i in range(2048):
+            if clone_at[i] == ply:
+                ref[i] = ref[i].clone()
+            ref[i].step(int(a[i]))
+            sn = unpack_state(states[i])
+            sn["step"] &= sl.STEP_COUNT_MASK
+            assert sn == ref[i].snapshot(), (i, ply)
+    steps = states["step"] & sl.STEP_COUNT_MASK
+    cloned = (states["step"] & sl.STEP_CLONED) != 0
+    empty = (states["nh"][:, 0] | states["nh"][:, 1]) == 0
+    assert np.all(steps[~cloned] <= 8) and np.all(empty | (steps == np.where(cloned, 16, 8)))   # the terminal rule, on all 65 536
+    assert (steps > 8).sum() > 10000
+
+
 @pytest.mark.parametrize("seed", [42, 0, 1, 7, 123])
 def test_tree_build_matches_reference(ctx, sl, golden, seed):
     g = golden.npz(f"tree_seed{seed}.npz")

@@ -64,6 +64,33 @@ def test_playouts_with_illegal_actions(oracle, golden):
         assert s.rewards() == c["rewards"]
 
 
+def test_cloned_playouts_play_to_step_16(oracle, golden):
+    """MiniScopaState.clone() builds an env whose max_steps is 16 (openspiel_mini_scopa.py:108): a clone that absorbs illegal no-op
+    actions plays past step 8.  240 reference playouts that clone at random plies (tests/golden/playouts_cloned.json)."""
+    cases = golden.json("playouts_cloned.json")
+    assert len(cases) >= 200 and sum(len(c["actions"]) > 8 for c in cases) >= 100
+    for c in cases:
+        s = oracle.State(seed=c["seed"])
+        for a, cb, tr in zip(c["actions"], c["clone_before"], c["trail"]):
+            if cb:
+                s = s.clone()
+            assert not s.is_terminal()
+            s.step(a)
+            sn = s.snapshot()
+            for k in ("hands", "table", "ncap", "scopas", "step"):
+                assert sn[k] == tr[k], (c["seed"], c["actions"], k)
+            assert s.max_steps == tr["max_steps"] == (16 if tr["cloned"] else 8)
+            assert s.is_terminal() == tr["term"] and s.current_player() == tr["cur"]
+            assert s.legal(0) == tr["legal0"] and s.legal(1) == tr["legal1"]
+            assert s.infoset_string(0) == tr["info0"] and s.infoset_string(1) == tr["info1"]
+            assert s.rewards() == tr["rewards"]
+        assert s.is_terminal() and s.rewards() == c["rewards"]
+        k, tc = s.clone(), c["terminal_clone"]      # a terminal state's clone stays terminal; a further action is a dead step
+        k.step(tc["action"])
+        sn = k.snapshot()
+        assert all(sn[x] == tc[x] for x in sn) and k.is_terminal() and k.legal(0) == tc["legal0"] == [] and k.rewards() == tc["rewards"]
+
+
 def test_vanilla_cfr_bit_exact(oracle, golden):
     g = golden.npz("vanilla_cfr.npz")
     t = oracle.Tree(seed=42)
