@@ -419,7 +419,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true", help="use the N>1 code path (process group, all-reduce) even with one rank")
     ap.add_argument("--share-gpu", action="store_true",
                     help="rehearsal on a box with fewer GPUs than ranks: all ranks use device 0, the process group is gloo (RCCL refuses two ranks on one device)")
+    ap.add_argument("--no-subrecords", action="store_true", help="N = 1 mccfr run: leave out the many_deals / sdcfr_large_batch / state_engines / evaluator sub-records (benchmarks/subrecords.py)")
     args = ap.parse_args()
+    # the host driver only supports dmabuf IPC: ranks started by an external launcher (torchrun, the driver) must get this too, before any HIP call
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
     if args.steps is None:
         args.steps = 2000 if args.workload == "mccfr" else 30
@@ -729,6 +732,13 @@ def main():
                 out["sdcfr"] = run_sdcfr(sub, emit=False)
             except Exception as e:
                 out["sdcfr"] = {"error": repr(e)}
+        if world == 1 and not use_dist and not args.no_subrecords:
+            # the hot path's other kernels under the same clock: a few launches each, each with its own roofline block
+            try:
+                from benchmarks import subrecords
+                out.update(subrecords.all_records(local_rank))
+            except Exception as e:
+                out["subrecords_error"] = repr(e)
         if saved_stdout is not None:
             sys.stdout.flush()
             os.dup2(saved_stdout, 1)

@@ -9,6 +9,34 @@ import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
+def measure_kernels(ctx, pol, n, stream=None, device=0):
+    """The eight k_eval_tabular_step launches of n episodes on context `ctx` (a deal must be set; pol: device float64 [n_infosets][4] average policy),
+    per sampling form; stream = the torch stream the context launches on (HIP events on it) or None (host clock between synchronisations)."""
+    import torch
+    dev = f"cuda:{device}"
+    states = torch.zeros((n, 4), dtype=torch.int32, device=dev); idx = torch.zeros(n, dtype=torch.int32, device=dev)
+    seat = (torch.arange(n, device=dev) >= n / 2).to(torch.int32)
+    by_form = {}
+    for form in ("float64 divisions per visit", "integer thresholds per infoset (scopa_eval_tabular_prepare)"):
+        ctx.eval_init_states(states.data_ptr(), n); idx.zero_()
+        torch.cuda.synchronize(); ctx.synchronize()
+        if form.startswith("integer"):
+            ctx.eval_tabular_prepare(pol.data_ptr())
+        times = []
+        for ply in range(8):
+            torch.cuda.synchronize(); ctx.synchronize()
+            call = lambda: ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0 if form.startswith("integer") else pol.data_ptr(), seat.data_ptr(), 16)
+            if stream is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(stream); call(); e1.record(stream); e1.synchronize()
+                times.append(1e-3 * e0.elapsed_time(e1))
+            else:
+                t0 = time.perf_counter(); call(); ctx.synchronize(); times.append(time.perf_counter() - t0)
+        by_form[form] = {"seconds_8_launches": sum(times), "episodes_per_s": n / sum(times), "achieved_GBps": 8 * n * 44 / sum(times) / 1e9,
+                         "frac_of_hbm_peak": 8 * n * 44 / sum(times) / 1e9 / 8000.0, "seconds_per_ply": times}
+    return by_form, states
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--episodes", type=int, default=1 << 24)
@@ -27,21 +55,8 @@ def main():
     ctx = tr._engine.ctx
     n = a.episodes
     pol = torch.as_tensor(np.ascontiguousarray(ctx.exploitability(return_policy=True)["policy"], np.float64), device="cuda:0")
-    states = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0"); idx = torch.zeros(n, dtype=torch.int32, device="cuda:0")
-    seat = torch.as_tensor(np.array([0 if e < n / 2 else 1 for e in range(n)], np.int32), device="cuda:0")
-    by_form = {}
-    for form in ("float64 divisions per visit", "integer thresholds per infoset (scopa_eval_tabular_prepare)"):
-        ctx.eval_init_states(states.data_ptr(), n); idx.zero_()
-        torch.cuda.synchronize(); ctx.synchronize()
-        if form.startswith("integer"):
-            ctx.eval_tabular_prepare(pol.data_ptr())
-        times = []
-        for ply in range(8):
-            torch.cuda.synchronize(); ctx.synchronize(); t0 = time.perf_counter()
-            ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0 if form.startswith("integer") else pol.data_ptr(), seat.data_ptr(), 16)
-            ctx.synchronize(); times.append(time.perf_counter() - t0)
-        by_form[form] = {"seconds_8_launches": sum(times), "episodes_per_s": n / sum(times), "achieved_GBps": 8 * n * 44 / sum(times) / 1e9,
-                         "frac_of_hbm_peak": 8 * n * 44 / sum(times) / 1e9 / 8000.0, "seconds_per_ply": times}
+    by_form, _ = measure_kernels(ctx, pol, n)
+    times = by_form["integer thresholds per infoset (scopa_eval_tabular_prepare)"]["seconds_per_ply"]
     k = sum(times)                                     # the form evaluate_agent_device uses (the last one timed)
     print(json.dumps({"kernel": "k_eval_tabular_step", "episodes": n, "policy": f"average policy after {a.cfr_iterations} vanilla-CFR iterations", "reward_vs_random": reward,
                       "reward_std_error": stats["reward_std_error"], "scopas_trained_vs_random": [stats["trained_avg"], stats["opponent_avg"]],

@@ -19,22 +19,8 @@ def main():
     ap.add_argument("--iters", type=int, default=5)
     ap.add_argument("--reps", type=int, default=3)
     a = ap.parse_args()
-    from scopa_amd import _lib
-    ctx = _lib.Context(0)
-    m = _lib.MultiDeal(ctx, a.deals)
-    m.deal_py_seeds(np.arange(a.deals))
-    t0 = time.perf_counter(); m.build(); t_build = time.perf_counter() - t0
-    m.cfr_exact_iterate_lanes(1)
-    best = 1e30
-    for _ in range(a.reps):
-        t0 = time.perf_counter(); m.cfr_exact_iterate_lanes(a.iters); best = min(best, time.perf_counter() - t0)
-    e = m.exploitability()
-    print(json.dumps({"workload": "vanilla CFR, %d deals x %d iterations, one deal per lane" % (a.deals, a.iters), "deals": a.deals,
-                      "iterations": a.iters, "seconds": best, "deal_iterations_per_s": a.deals * a.iters / best,
-                      "visits_per_s": a.deals * a.iters * 3306 / best, "row_image_resident_GB": a.deals * 1653 * 64 / 1e9,
-                      "tree_build_s": t_build, "algorithmic_bytes_per_deal_iteration": ALG_BYTES,
-                      "algorithmic_GBps": a.deals * a.iters * ALG_BYTES / best / 1e9, "mean_exploitability": float(e[:, 0].mean())}))
-    m.close()
+    from benchmarks.subrecords import many_deals          # the same measurement bench.py's `many_deals` sub-record reports (HIP events on the kernel's stream)
+    print(json.dumps(many_deals(0, a.deals, a.iters, a.reps)))
 
 
 if __name__ == "__main__":

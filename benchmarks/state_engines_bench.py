@@ -19,10 +19,16 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 HBM_PEAK_GBPS = 8000.0
 
 
-def timed(ctx, torch, fn):
-    """one launch on the context's stream, bracketed by synchronisations (launches here take 0.3-3 ms; the bracket costs ~10 us)"""
+def timed(ctx, torch, fn, stream=None):
+    """one launch on the context's stream.  stream (a torch stream the context was created on): HIP events recorded on that stream around the
+    launch -- the kernel's own duration; without it the host clock between synchronisations (launches here take 0.1-3 ms; the bracket costs ~10 us)"""
     import time
     torch.cuda.synchronize(); ctx.synchronize()
+    if stream is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream); fn(); e1.record(stream)
+        e1.synchronize()
+        return 1e-3 * e0.elapsed_time(e1)
     t0 = time.perf_counter(); fn(); ctx.synchronize()
     return time.perf_counter() - t0
 
@@ -40,19 +46,16 @@ def report(name, n, bytes_step, times, extra):
             "seconds_per_ply": times, **extra}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--mini", type=int, default=1 << 26)
-    ap.add_argument("--team", type=int, default=1 << 25)
-    ap.add_argument("--full", type=int, default=1 << 24)
-    ap.add_argument("--pool", type=int, default=4096)
-    a = ap.parse_args()
+def measure(ctx, n_mini=1 << 26, n_team=1 << 25, n_full=1 << 24, n_pool=4096, stream=None, device=0):
+    """The three engines on context `ctx`; stream: the torch stream the context launches on (event timing), or None (host clock)."""
+    import types
     import torch
     from scopa_amd import _lib
-    ctx = _lib.Context(0)
-    dev = torch.device("cuda:0")
+    a = types.SimpleNamespace(mini=n_mini, team=n_team, full=n_full, pool=n_pool)
+    dev = torch.device(f"cuda:{device}")
     g = torch.Generator(device=dev); g.manual_seed(0)
-    out = {"hbm_peak_GBps": HBM_PEAK_GBPS, "timing": "per launch; host clock between stream synchronisations"}
+    out = {"hbm_peak_GBps": HBM_PEAK_GBPS,
+           "timing": "per launch; " + ("HIP events on the kernels' stream" if stream is not None else "host clock between stream synchronisations")}
 
     def rnd_k(nh):       # uniform index below nh (at least 1)
         return (torch.rand(nh.numel(), device=dev, generator=g) * nh.clamp(min=1)).to(torch.int32).clamp(max=3).minimum(nh.clamp(min=1) - 1)
@@ -73,7 +76,7 @@ def main():
             k = rnd_k(st[:, 8 + mover].to(torch.int32))
             act = ((hand >> (4 * k)) & 15).to(torch.uint8).contiguous()
             del hand, k
-            times.append(timed(ctx, torch, lambda: ctx.step_batch(st.data_ptr(), act.data_ptr(), a.mini)))
+            times.append(timed(ctx, torch, lambda: ctx.step_batch(st.data_ptr(), act.data_ptr(), a.mini), stream))
         h = st[:1 << 20].cpu().numpy().view(_lib.STATE_DTYPE).reshape(-1)
         assert (h["step"] == 8).all() and (h["nh"] == 0).all() and ((h["ncap"].sum(axis=1) + h["nt"]) == 8).all()
         out["mini"] = report("k_step_batch", a.mini, 33, times, {})
@@ -94,7 +97,7 @@ def main():
             k = rnd_k(st[:, 28 + seat].to(torch.int32))
             act = ((hand >> (4 * k)) & 15).to(torch.uint8).contiguous()
             del hand, k
-            times.append(timed(ctx, torch, lambda: ctx.team_step_batch(st.data_ptr(), act.data_ptr(), a.team)))
+            times.append(timed(ctx, torch, lambda: ctx.team_step_batch(st.data_ptr(), act.data_ptr(), a.team), stream))
         h = st[:1 << 20].cpu().numpy().view(_lib.TEAM_STATE_DTYPE).reshape(-1)
         assert (h["step"] == 16).all() and (h["nh"] == 0).all() and (h["flags"] & 1).all()
         out["team"] = report("k_team_step_batch", a.team, 81, times, {})
@@ -103,8 +106,9 @@ def main():
 
     # ---- FullScopa: 40 cards, 3-card hands re-dealt six times, 36 plies ---------------------------------------------------
     if a.full:
-        pool = np.zeros(a.pool, _lib.FULL_STATE_DTYPE)
-        decks = np.zeros((a.pool, 40), np.uint8)
+        fpool = min(a.pool, 1024)                                      # a FullScopa deal costs 0.6 ms on the host
+        pool = np.zeros(fpool, _lib.FULL_STATE_DTYPE)
+        decks = np.zeros((fpool, 40), np.uint8)
         for i in range(pool.size):
             decks[i] = _lib.full_deal_py_seed(i)
             pool[i] = _lib.FullState(deck=decks[i], game=i).s[0]
@@ -121,12 +125,29 @@ def main():
             k = rnd_k(nh)
             act = torch.where(nh > 0, (hand >> (6 * k)) & 63, torch.zeros_like(hand)).to(torch.uint8).contiguous()
             del hand, k, nh
-            times.append(timed(ctx, torch, lambda: ctx.full_step_batch(st.data_ptr(), act.data_ptr(), d_decks.data_ptr(), a.full)))
+            times.append(timed(ctx, torch, lambda: ctx.full_step_batch(st.data_ptr(), act.data_ptr(), d_decks.data_ptr(), a.full), stream))
             plies += 1
         h = st[:1 << 20].cpu().numpy().view(_lib.FULL_STATE_DTYPE).reshape(-1)
         assert (h["terminal"] == 1).all() and (h["flags"] == 0).all()
         out["full"] = report("k_full_step_batch", a.full, 129, times, {"game_length_plies": plies})
-    print(json.dumps(out))
+        del st, act
+        torch.cuda.empty_cache()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--mini", type=int, default=1 << 26)
+    ap.add_argument("--team", type=int, default=1 << 25)
+    ap.add_argument("--full", type=int, default=1 << 24)
+    ap.add_argument("--pool", type=int, default=4096)
+    ap.add_argument("--host-clock", action="store_true", help="time launches with the host clock between synchronisations instead of HIP events")
+    a = ap.parse_args()
+    import torch
+    from scopa_amd import _lib
+    stream = None if a.host_clock else torch.cuda.Stream()
+    ctx = _lib.Context(0, stream=stream.cuda_stream if stream is not None else None)
+    print(json.dumps(measure(ctx, a.mini, a.team, a.full, a.pool, stream)))
 
 
 if __name__ == "__main__":

@@ -205,6 +205,9 @@ int32_t scopa_sdcfr_visits(scopa_ctx *ctx, uint64_t *decision_visits);
  * d_image[2][SCOPA_SDCFR_IMAGE_FLOATS]: per player the net as scopa_sdcfr_pack_weights lays it out (the operand layout of
  * v_mfma_f32_16x16x4_f32; the kernel copies it to LDS as it is).  d_uniforms (optional, tests): [batch][8][24] float64 draws
  * indexed (traversal, ply, slot).  d_mem_feat must be 8-byte, d_mem_regret / d_mem_mask 16-byte aligned.
+ * d_mem_mask may be NULL (here and in scopa_sdcfr_backward): a traverser node's legal actions are the cards of the mover's hand
+ * (openspiel_mini_scopa.py:36-45) and features[0..16) are that hand's one-hot (deep_cfr.py:213-275), so the mask row equals the first
+ * sixteen floats of the feature row and need not be written a second time -- a memory row is then 200 bytes of HBM instead of 264.
  * Samples the same actions as the ply-by-ply path (same Philox keying); float32 sums run in a different order. */
 #define SCOPA_SDCFR_IMAGE_FLOATS 13520
 int32_t scopa_sdcfr_image_floats(void);
@@ -231,7 +234,8 @@ int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t 
  * forward 34-128-64-16, MSE(pred * mask, target * mask) over n_rows x 16, backward, clip_grad_norm_(1.0), Adam(lr, betas 0.9 / 0.999, eps 1e-8).
  * OPT-IN (the default trains with PyTorch-ROCm): DeepCFR(train_backend="hip").  d_w1 .. d_b3 are the net's own tensors (torch layout W[out][in]),
  * updated in place; d_state = [2][13776] float (exp_avg, exp_avg_sq in net.parameters() order), zero before the first step; step = 1, 2, ...;
- * the step's loss is ADDED to d_loss[0].  n_rows: a multiple of 16.  Two launches (k_sdcfr_train_grad, k_sdcfr_train_adam), no host synchronisation. */
+ * the step's loss is ADDED to d_loss[0].  n_rows: a multiple of 16.  d_mask NULL = every row's mask is its features[0..16) (rows written by the
+ * traversal calls with d_mem_mask NULL).  Two launches (k_sdcfr_train_grad, k_sdcfr_train_adam), no host synchronisation. */
 int32_t scopa_sdcfr_train_params(void);   /* 13 776 */
 /* n_steps consecutive steps in one call: step e trains on d_rows[e * n_rows .. (e + 1) * n_rows) with step number first_step + e (the epochs of one train() call) */
 int32_t scopa_sdcfr_train_steps(scopa_ctx *ctx, const int64_t *d_rows, int32_t n_rows, int32_t n_steps, const float *d_feat, const float *d_regret, const float *d_mask,

@@ -24,29 +24,78 @@ ROWS_PER_TRAVERSAL = 41  # traverser-node visits of one traversal (1 + 4 + 12 + 
 
 
 class DeviceMemory:
-    """FIFO advantage memory (the reference's deque(maxlen=100000), deep_cfr.py:52) as three device tensors."""
+    """FIFO advantage memory (the reference's deque(maxlen=100000), deep_cfr.py:52) as device tensors: features [capacity][34] and normalised
+    regrets [capacity][16].  MASKS are not stored for the rows the traversal kernels write: at a traverser node the legal actions are the cards
+    of the mover's hand (openspiel_mini_scopa.py:36-45) and the first sixteen features are that hand's one-hot (deep_cfr.py:213-275), so such a
+    row's mask IS `feat[row, :16]` -- `mask` hands out that strided view, the kernels skip the 64-byte mask stream (a row is 200 bytes of HBM, not
+    264) and the training gather reads one array less.  `add_experience` takes a caller-supplied mask that need not equal the features: those
+    rows keep a real mask in a side array chosen by a per-row flag (allocated on first use; a traversal overwriting such a row clears the flag)."""
 
     def __init__(self, capacity, input_dim, device):
         self.capacity = capacity
         self.feat = torch.zeros((capacity, input_dim), dtype=torch.float32, device=device)
         self.regret = torch.zeros((capacity, 16), dtype=torch.float32, device=device)
-        self.mask = torch.zeros((capacity, 16), dtype=torch.float32, device=device)
+        self._side_mask = None   # [capacity][16]: masks of rows appended through append() / add_experience
+        self._explicit = None    # [capacity] bool: the row's mask lives in _side_mask
         self.total = 0  # rows ever appended
 
     def __len__(self):
         return min(self.total, self.capacity)
 
     @property
+    def row_bytes(self):
+        """HBM bytes a traversal kernel writes per memory row: features and regrets (the mask is a view of the features)."""
+        return 4 * (self.feat.shape[1] + 16)
+
+    @property
+    def mask(self):
+        """[capacity][16] masks: a strided VIEW of the feature array while every row was written by a traversal kernel; with rows appended through
+        append() in the ring, a tensor assembled from that view and the side array."""
+        view = self.feat[:, :16]
+        if self._explicit is None:
+            return view
+        return torch.where(self._explicit.unsqueeze(1), self._side_mask, view)
+
+    @property
+    def mask_ptr(self):
+        """What the library's training step takes as d_mask: 0 (mask = features[0..16), scopa_sdcfr.hip sd_mask_note) unless explicit masks exist."""
+        if self._explicit is None:
+            return 0, None
+        m = self.mask.contiguous()
+        return m.data_ptr(), m       # (the caller keeps `m` alive until its launches are queued on the same stream)
+
+    def gather(self, rows):
+        """(features, regrets, masks) of the ring rows `rows` -- the training batch (deep_cfr.py:88-97)."""
+        x = self.feat[rows]
+        m = x[..., :16]
+        if self._explicit is not None:
+            m = torch.where(self._explicit[rows].unsqueeze(-1), self._side_mask[rows], m)
+        return x, self.regret[rows], m
+
+    @property
     def write_base(self):
         return self.total % self.capacity
 
     def advance(self, rows):
+        """`rows` ring rows from write_base on have just been written by a traversal kernel (on the current stream)."""
+        if self._explicit is not None and rows:
+            b = self.write_base
+            self._explicit[b:b + rows] = False
+            if b + rows > self.capacity:
+                self._explicit[:b + rows - self.capacity] = False
         self.total += rows
 
+    def put(self, rows, feat, regret, mask):
+        """Rows with masks of their own at ring positions `rows` (a slice or index tensor); `total` is the caller's to set."""
+        if self._explicit is None:
+            self._side_mask = torch.zeros((self.capacity, 16), dtype=torch.float32, device=self.feat.device)
+            self._explicit = torch.zeros(self.capacity, dtype=torch.bool, device=self.feat.device)
+        self.feat[rows], self.regret[rows], self._side_mask[rows] = feat, regret, mask
+        self._explicit[rows] = True
+
     def append(self, feat, regret, mask):
-        """One row at the deque's append position (the ring slot the traversal kernels would write next)."""
-        r = self.write_base
-        self.feat[r], self.regret[r], self.mask[r] = feat, regret, mask
+        """One row at the deque's append position (the ring slot the traversal kernels would write next), with its own mask."""
+        self.put(self.write_base, feat, regret, mask)
         self.total += 1
 
     def logical_to_physical(self, idx):
@@ -55,8 +104,7 @@ class DeviceMemory:
         return (idx + start) % self.capacity
 
     def rows(self, idx):
-        r = self.logical_to_physical(idx)
-        return self.feat[r], self.regret[r], self.mask[r]
+        return self.gather(self.logical_to_physical(idx))
 
     def __getitem__(self, i):
         f, r, m = self.rows(torch.tensor([i % max(len(self), 1)], device=self.feat.device))
@@ -229,7 +277,8 @@ class AdvantageNetwork:
         loss.zero_()
         lr = float(self.optimizer.param_groups[0]["lr"])
         ptrs = tuple(p.data_ptr() for p in params)
-        self._ctx.sdcfr_train_steps(rows_all.data_ptr(), batch_size, epochs, self.buffer.feat.data_ptr(), self.buffer.regret.data_ptr(), self.buffer.mask.data_ptr(),
+        mask_ptr, _keep = self.buffer.mask_ptr
+        self._ctx.sdcfr_train_steps(rows_all.data_ptr(), batch_size, epochs, self.buffer.feat.data_ptr(), self.buffer.regret.data_ptr(), mask_ptr,
                                     self.buffer.capacity, ptrs, state.data_ptr(), self._hip_step + 1, lr, loss.data_ptr())
         self._hip_step += epochs
         return loss[0] / epochs if defer else float(loss.item()) / epochs
@@ -248,7 +297,7 @@ class AdvantageNetwork:
 
     def _step(self, rows):
         """One optimiser step on the ring rows `rows` (deep_cfr.py:99-112); returns the loss tensor."""
-        states, target_adv, masks = self.buffer.feat[rows], self.buffer.regret[rows], self.buffer.mask[rows]
+        states, target_adv, masks = self.buffer.gather(rows)
         self.optimizer.zero_grad(set_to_none=True)   # fresh gradient tensors each step: no zero-fill and no accumulate-add kernels (9 of ~45 per step)
         pred_adv = self.net(states)
         loss = self.criterion(pred_adv * masks, target_adv * masks)
@@ -280,7 +329,7 @@ class AdvantageNetwork:
             self._lean_setup()                                               # (first use, or autograd's step has replaced the .grad tensors since)
         flat, (w1, b1, w2, b2, w3, b3) = self._lean[0], self._lean[1]
         with torch.no_grad():
-            x, t, m = self.buffer.feat[rows], self.buffer.regret[rows], self.buffer.mask[rows]
+            x, t, m = self.buffer.gather(rows)
             h1 = torch._addmm_activation(b1, x, w1.t())                   # relu(x W1^T + b1), one kernel
             h2 = torch._addmm_activation(b2, h1, w2.t())
             y = torch.addmm(b3, h2, w3.t())
@@ -548,7 +597,7 @@ class DeepCFR:
             if timed is not None:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record(self._stream)
-            ctx.sdcfr_traverse_fused(player, batch, w.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), mem.mask.data_ptr(),
+            ctx.sdcfr_traverse_fused(player, batch, w.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), 0,   # no mask stream: DeviceMemory.mask
                                      mem.capacity, mem.write_base, vals.data_ptr(), u.data_ptr() if u is not None else 0,
                                      self._iteration, self.rank * batch)
             if timed is not None:
@@ -593,7 +642,7 @@ class DeepCFR:
                 nidx, pol, feats, mask = saved[ply]
                 out = torch.empty(nidx.numel(), dtype=torch.float32, device=dev)
                 ctx.sdcfr_backward(ply, player, nidx.numel(), nidx.data_ptr(), pol.data_ptr(), val.data_ptr(), out.data_ptr(),
-                                   feats.data_ptr(), mask.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), mem.mask.data_ptr(),
+                                   feats.data_ptr(), mask.data_ptr(), mem.feat.data_ptr(), mem.regret.data_ptr(), 0,
                                    mem.capacity, mem.write_base)
                 val = out
             mem.advance(batch * ROWS_PER_TRAVERSAL)

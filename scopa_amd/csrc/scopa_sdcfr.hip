@@ -156,7 +156,8 @@ k_sdcfr_backward(const scopa_state *__restrict__ g_states, int ply, int traverse
     }
     long long row = (write_base + b * 41 + rank) % capacity;
     for (int c = 0; c < 34; c++) mem_feat[row * 34 + c] = feats[i * 34 + c];
-    for (int c = 0; c < 16; c++) { mem_regret[row * 16 + c] = reg[c]; mem_mask[row * 16 + c] = mask[i * 16 + c]; }
+    for (int c = 0; c < 16; c++) mem_regret[row * 16 + c] = reg[c];
+    if (mem_mask) for (int c = 0; c < 16; c++) mem_mask[row * 16 + c] = mask[i * 16 + c];   // no mask array: the row's mask is features[0..16) (sd_mask_note)
 }
 
 // ---- batched play vs a uniform-random opponent: states advance with the same device step as everything else -------------
@@ -258,7 +259,7 @@ int32_t scopa_sdcfr_backward(scopa_ctx *ctx, int32_t ply, int32_t traverser, int
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_backward: no deal set");
     const bool trav_ply = (ply & 1) == traverser;
     if (trav_ply && n)
-        SC_REQUIRE(ctx, d_feats && d_mask && d_mem_feat && d_mem_regret && d_mem_mask && capacity >= 41 && write_base >= 0, SCOPA_EINVAL,
+        SC_REQUIRE(ctx, d_feats && d_mask && d_mem_feat && d_mem_regret && capacity >= 41 && write_base >= 0, SCOPA_EINVAL,
                    "scopa_sdcfr_backward: memory buffers required at a traverser ply");
     const int width = frontier_width(traverser, ply);
     SC_REQUIRE(ctx, n % width == 0, SCOPA_EINVAL, "scopa_sdcfr_backward: n is not a multiple of the ply's frontier width");
@@ -703,7 +704,7 @@ k_sdcfr_traverse(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g
                                 mf[ch] = make_float2((float)((xbits >> (2 * ch)) & 1u), (float)((xbits >> (2 * ch + 1)) & 1u));
                             }
                             if (q == 0) mf[16] = make_float2(1.0f, 0.0f);  // float(player == current_player), unused feature
-                            reinterpret_cast<float4 *>(mem_mask + (size_t)row * 16)[q] =
+                            if (mem_mask) reinterpret_cast<float4 *>(mem_mask + (size_t)row * 16)[q] =
                                 make_float4((float)((xbits >> (4 * q)) & 1u), (float)((xbits >> (4 * q + 1)) & 1u), (float)((xbits >> (4 * q + 2)) & 1u), (float)((xbits >> (4 * q + 3)) & 1u));
                         }
                     }
@@ -1157,6 +1158,7 @@ k_sdcfr_walk(const uint2 *__restrict__ g_ninfo, const int8_t *__restrict__ g_pay
                 if (i < 8) *reinterpret_cast<SdF4A8 *>(dst) = SdF4A8{(float)(hb & 1u), (float)((hb >> 1) & 1u), (float)((hb >> 2) & 1u), (float)((hb >> 3) & 1u)};
                 else *reinterpret_cast<float2 *>(dst) = make_float2(1.0f, 0.0f);   // [32] = float(player == current_player), [33] unused
             }
+            if (mem_mask != nullptr)                                        // no mask array (the default ring): a row's mask IS features[0..16) -- sd_mask_note
             for (int e = lane; e < n_live * 41 * 4; e += 64) {              // masks: 4 sixteen-byte pieces per 64-byte row
                 const int rr = e >> 2, i = e & 3;
                 const uint32_t hb = xbv[rr] >> (4 * i);
@@ -1291,7 +1293,10 @@ int32_t scopa_sdcfr_tuning(scopa_ctx *ctx, int32_t traversals_per_task, int32_t 
 int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t batch, const float *d_image, float *d_mem_feat,
                                    float *d_mem_regret, float *d_mem_mask, int64_t capacity, int64_t write_base,
                                    float *d_root_values, const double *d_uniforms, uint32_t iteration, uint32_t b0) {
-    if (!ctx || traverser < 0 || traverser > 1 || batch < 0 || (batch && (!d_image || !d_mem_feat || !d_mem_regret || !d_mem_mask || !d_root_values)))
+    // sd_mask_note -- d_mem_mask may be NULL: at a traverser node the legal actions are the cards of the mover's hand (openspiel_mini_scopa.py:36-45), and
+    // the first sixteen features are that hand's one-hot (deep_cfr.py:213-275), so a row this call writes has mask == features[0..16) and the 64-byte mask
+    // stream is redundant: the caller keeps masks as a strided view of the feature array (DeviceMemory.mask) and the row shrinks from 264 to 200 bytes.
+    if (!ctx || traverser < 0 || traverser > 1 || batch < 0 || (batch && (!d_image || !d_mem_feat || !d_mem_regret || !d_root_values)))
         return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_sdcfr_traverse_fused: no deal set");
     SC_REQUIRE(ctx, capacity >= 41 && (int64_t)batch * 41 <= capacity, SCOPA_EINVAL, "scopa_sdcfr_traverse_fused: memory ring too small for the batch");

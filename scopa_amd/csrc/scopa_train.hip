@@ -59,7 +59,7 @@ k_sdcfr_train_grad(const int64_t *__restrict__ g_rows, int n_rows, long long cap
         if (tid < 16) { const long long r = g_rows[tile * 16 + tid]; s_row[tid] = r < 0 ? 0 : r >= capacity ? capacity - 1 : r; }   // (a row index outside the ring is clamped, never dereferenced)
         __syncthreads();
         for (int e = tid; e < 16 * kIn; e += 256) { const int r = e / kIn, c = e - r * kIn; s_x[r * kSX + c] = g_feat[(size_t)s_row[r] * kIn + c]; }
-        { const int r = tid >> 4, c = tid & 15; s_t[r * kSD + c] = g_regret[(size_t)s_row[r] * kOut + c]; s_m[r * kSD + c] = g_mask[(size_t)s_row[r] * kOut + c]; }
+        { const int r = tid >> 4, c = tid & 15; s_t[r * kSD + c] = g_regret[(size_t)s_row[r] * kOut + c]; s_m[r * kSD + c] = g_mask ? g_mask[(size_t)s_row[r] * kOut + c] : g_feat[(size_t)s_row[r] * kIn + c]; }   // no mask array: mask = features[0..16) (scopa_sdcfr.hip sd_mask_note)
         __syncthreads();
         {   // ---- layer 1: h1[unit][row] = relu(W1 x + b1); wavefront w: unit tiles 2 w, 2 w + 1
             v4f acc[2];
@@ -248,7 +248,7 @@ int32_t scopa_sdcfr_train_params(void) { return kParams; }
 int32_t scopa_sdcfr_train_steps(scopa_ctx *ctx, const int64_t *d_rows, int32_t n_rows, int32_t n_steps, const float *d_feat, const float *d_regret, const float *d_mask,
                                 int64_t capacity, float *d_w1, float *d_b1, float *d_w2, float *d_b2, float *d_w3, float *d_b3, float *d_state, int32_t first_step, float lr,
                                 float *d_loss) {
-    if (!ctx || !d_rows || !d_feat || !d_regret || !d_mask || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_state || !d_loss) return SCOPA_EINVAL;
+    if (!ctx || !d_rows || !d_feat || !d_regret || !d_w1 || !d_b1 || !d_w2 || !d_b2 || !d_w3 || !d_b3 || !d_state || !d_loss) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, n_rows >= 16 && n_rows % 16 == 0 && n_rows <= (1 << 20), SCOPA_EINVAL, "scopa_sdcfr_train_steps: the batch must be a multiple of 16 rows (16 .. 2^20)");
     SC_REQUIRE(ctx, capacity >= 1 && first_step >= 1 && n_steps >= 0 && n_steps <= 4096 && lr > 0.0f, SCOPA_EINVAL,
                "scopa_sdcfr_train_steps: capacity, first_step (1-based) and lr must be positive, n_steps in 0 .. 4096");

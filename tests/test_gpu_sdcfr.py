@@ -446,7 +446,7 @@ def test_hip_training_step_rejects_bad_arguments_and_trains(ctx):
     rows = torch.zeros(64, dtype=torch.long, device="cuda:0")
     state, loss = torch.zeros(2 * 13776, device="cuda:0"), torch.zeros(1, device="cuda:0")
     c = d._engine.ctx
-    args = lambda n, step, p=ptrs: (rows.data_ptr(), n, 1, a.buffer.feat.data_ptr(), a.buffer.regret.data_ptr(), a.buffer.mask.data_ptr(), a.buffer.capacity, p, state.data_ptr(), step, 5e-4, loss.data_ptr())
+    args = lambda n, step, p=ptrs: (rows.data_ptr(), n, 1, a.buffer.feat.data_ptr(), a.buffer.regret.data_ptr(), a.buffer.mask_ptr[0], a.buffer.capacity, p, state.data_ptr(), step, 5e-4, loss.data_ptr())
     for bad in (args(20, 1), args(0, 1), args(32, 0), args(32, 1, (ptrs[0] + 4,) + ptrs[1:])):
         with pytest.raises(_lib.ScopaError):
             c.sdcfr_train_steps(*bad)

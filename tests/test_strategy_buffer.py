@@ -50,9 +50,9 @@ def test_lean_optimiser_step_equals_autograd_on_the_cpu():
     b = AdvantageNetwork(34, 16, device="cpu", memory_size=256)
     b.net.load_state_dict(copy.deepcopy(a.net.state_dict()))
     for net in (a, b):
-        net.buffer.feat[:200] = (torch.rand(200, 34, generator=torch.Generator().manual_seed(1)) > 0.7).float()
-        net.buffer.regret[:200] = torch.randn(200, 16, generator=torch.Generator().manual_seed(2)) * 0.5
-        net.buffer.mask[:200] = (torch.rand(200, 16, generator=torch.Generator().manual_seed(4)) > 0.6).float()
+        net.buffer.put(slice(0, 200), (torch.rand(200, 34, generator=torch.Generator().manual_seed(1)) > 0.7).float(),
+                       torch.randn(200, 16, generator=torch.Generator().manual_seed(2)) * 0.5,
+                       (torch.rand(200, 16, generator=torch.Generator().manual_seed(4)) > 0.6).float())   # masks of their own (not features[:16]): the side array
         net.buffer.total = 200
     rows = torch.arange(128)
     for _ in range(3):
@@ -60,3 +60,39 @@ def test_lean_optimiser_step_equals_autograd_on_the_cpu():
         assert float(la.detach()) == float(lb)
     for (k, x), y in zip(a.net.state_dict().items(), b.net.state_dict().values()):
         assert torch.equal(x, y), k
+
+
+def test_device_memory_masks_are_a_view_of_the_features_unless_supplied():
+    """DeviceMemory (the reference's deque of (features, regrets, mask) rows, deep_cfr.py:52,70-75,88): rows written by the traversal kernels carry no
+    mask array -- their mask is features[:16] (the mover's hand) and `mask` is a strided view; rows appended through add_experience keep the mask the
+    caller gave, whatever it is; a traversal overwriting such a row makes it a kernel row again; the ring wraps like the deque."""
+    import torch
+    from scopa_amd.algorithms.deep_cfr.deep_cfr import AdvantageNetwork
+    a = AdvantageNetwork(34, 16, device="cpu", memory_size=8)
+    mem = a.buffer
+    assert mem.row_bytes == 200 and mem.mask.data_ptr() == mem.feat.data_ptr() and mem.mask.shape == (8, 16) and mem.mask_ptr[0] == 0
+    g = torch.Generator().manual_seed(0)
+    kernel_rows = (torch.rand(5, 34, generator=g) > 0.5).float()
+    mem.feat[:5], mem.regret[:5] = kernel_rows, torch.randn(5, 16, generator=g)      # what a traversal launch leaves: features and regrets only
+    mem.advance(5)
+    f, r, m = mem.rows(torch.arange(5))
+    assert torch.equal(m, kernel_rows[:, :16]) and torch.equal(f, kernel_rows)
+    odd_mask = np.zeros(16, np.float32); odd_mask[[1, 2, 15]] = 1                     # not the features' first sixteen
+    feats = np.ones(34, np.float32)
+    for k in range(2):
+        a.add_experience(feats * (k + 1), np.arange(16, dtype=np.float32) - 3.0, odd_mask)
+    assert len(mem) == 7 and mem.mask.data_ptr() != mem.feat.data_ptr()
+    f6, r6, m6 = mem[6]
+    assert np.array_equal(m6, odd_mask) and np.array_equal(f6, 2 * feats) and abs(np.abs(r6).max() - 1.0) < 1e-6     # divided by max|adv| + 1e-8 (:73-74)
+    assert np.array_equal(mem[2][2], kernel_rows[2, :16].numpy())                                                     # kernel rows unchanged beside it
+    x, t, m = mem.gather(torch.tensor([[0, 5], [6, 4]]))                                                              # [epochs][batch] index batches
+    assert m.shape == (2, 2, 16) and torch.equal(m[0, 1], torch.from_numpy(odd_mask)) and torch.equal(m[1, 1], kernel_rows[4, :16])
+    a.add_experience(feats * 3, np.ones(16, np.float32), odd_mask)                    # row 7: the ring is full
+    a.add_experience(feats * 4, np.ones(16, np.float32), odd_mask)                    # wraps: physical row 0, the deque drops its oldest
+    assert len(mem) == 8 and mem.total == 9 and np.array_equal(mem[7][0], 4 * feats) and np.array_equal(mem[0][0], kernel_rows[1].numpy())
+    # a traversal launch now writes 3 rows at the write position (physical rows 1, 2, 3): they are kernel rows again
+    mem.feat[1:4] = kernel_rows[:3]
+    mem.advance(3)
+    assert not bool(mem._explicit[1:4].any()) and bool(mem._explicit[0]) and torch.equal(mem.mask[1:4], kernel_rows[:3, :16])
+    ptr, keep = mem.mask_ptr
+    assert ptr != 0 and keep.is_contiguous() and torch.equal(keep[0], torch.from_numpy(odd_mask))

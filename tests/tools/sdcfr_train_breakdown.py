@@ -62,7 +62,7 @@ with torch.cuda.stream(d2._stream):
         for rep in range(10):
             for e in range(E):
                 a._hip_step += 1
-                a._ctx.sdcfr_train_step(rows_all[e].data_ptr(), bs, a.buffer.feat.data_ptr(), a.buffer.regret.data_ptr(), a.buffer.mask.data_ptr(), a.buffer.capacity, ptrs, state.data_ptr(), a._hip_step, 5e-4, loss.data_ptr())
+                a._ctx.sdcfr_train_step(rows_all[e].data_ptr(), bs, a.buffer.feat.data_ptr(), a.buffer.regret.data_ptr(), a.buffer.mask_ptr[0], a.buffer.capacity, ptrs, state.data_ptr(), a._hip_step, 5e-4, loss.data_ptr())
         e1.record(d2._stream); e1.synchronize()
         print(f"hip backend: optimiser step on {bs} rows {1e3 * e0.elapsed_time(e1) / (10 * E):.1f} us (events around {10 * E} steps)")
 print(f"hip backend: train({E} epochs) {1e6 * t_train:.0f} us")
