@@ -315,10 +315,11 @@ def run_sdcfr(args, emit=True):
         flop_visit = 2.0 * (34 * 128 + 128 * 64 + 64 * 16)               # one MLP forward (27 136 FLOP) ...
         fwd_launch = (81 + 58) / 2.0 * batch                             # ... per visit that needs one: the 24 single-action opponent nodes of plies 6/7 are forced, the kernel skips them
         alg_b = 412.0
-        rows_b = 41 * 264.0 * batch                                      # the memory rows a launch must write (41 rows x (34 + 16 + 16) float32 per traversal)
+        row_bytes = d.advantage_nets[0].buffer.row_bytes                 # 200: 34 feature + 16 regret floats (the mask is a view of the features, DeviceMemory)
+        rows_b = 41.0 * row_bytes * batch                                # the memory rows a launch must write
         pv_s = 1e-3 * sum(pv_ms) / max(len(pv_ms), 1) if pv_ms else (kern_s if per_visit_default else None)
         bounds = {"hbm-memory-rows": {"achieved": rows_b / kern_s / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                                      "how": "41 x 264 B of memory rows per traversal x traversals per launch / traversal time (policy launch + walk launch): what the "
+                                      "how": f"41 x {row_bytes} B of memory rows per traversal (34 feature + 16 regret floats; the mask is features[:16], not stored) x traversals per launch / traversal time (policy launch + walk launch): what the "
                                              "launch must write whatever the algorithm; nets, policy table, node table and frontier are LDS-resident"},
                   }
         if per_visit_default:
@@ -363,7 +364,7 @@ def run_sdcfr(args, emit=True):
                                                         "rows do, so the ratio can exceed 1; the bound that applies is bounds.hbm-memory-rows, the traffic measured is `traffic`"},
                             "note": "time from events recorded on the kernels' stream around each player's traversal (both launches of the default form).  Default form: the "
                                     "advantage nets are frozen during a launch and a node's features depend on the tree node alone, so the deal's 1 653 decision nodes are "
-                                    "evaluated once (MFMA tiles, k_sdcfr_policy) and the traversals walk the 26 KB policy table in LDS; HBM sees the 41 x 264 B memory rows per "
+                                    "evaluated once (MFMA tiles, k_sdcfr_policy) and the traversals walk the 26 KB policy table in LDS; HBM sees the 41 x 200 B memory rows per "
                                     "traversal, which is what bounds it.  Forward-per-visit form (bounds.mfma-f32): both nets as MFMA operand images in LDS, activations in "
                                     "registers; SQ counter passes: profiles/r03_pmc_sq_sdcfr_walk_b*.json (default form), profiles/r03_pmc_sq_sdcfr_traverse_b*.json"},
                "decision_visits": visits, "world": roster}
