@@ -47,6 +47,8 @@ struct scopa_ctx {
     double *d_scratch = nullptr;  // root values / uniforms staging
     double *d_sigcdf = nullptr;   // [kDecision][6] sigma | threshold rows of the frozen regret table (48 bytes: the layout the traversal keeps in LDS)
     bool sigcdf_valid = false;    // false whenever d_regret changed outside k_mccfr_apply
+    bool mccfr_all_seen = false;  // every infoset of the deal has a first-visit mark in d_visit: traversal launches stop tracking first visits (scopa_mccfr.hip); false after scopa_tables_reset
+    uint32_t mccfr_seen_wait = 0; // traversal launches since the marks were last counted
     double *d_groups = nullptr;   // [kDeltaGroups group tables][5][kGroupRows] float64: where traversal launches add their deltas (scopa_mccfr.hip); all-zero between launches' applies
     unsigned long long *d_clock = nullptr;   // [2048 sampled launches][512 workgroups][4] phase stamps on the 100 MHz device clock (allocated by scopa_prof_enable)
     uint16_t clock_grid[2048] = {0};         // workgroups of each sampled launch
@@ -77,7 +79,7 @@ struct scopa_ctx {
     double prof_ms = 0.0;
 
     // exact vanilla CFR, scheduled form (scopa_cfr.hip): EXIT events of the deal's tree levelled under the per-infoset visit order
-    uint32_t *d_lane_tab = nullptr;   // [9][64] uint4: what a lane's node slots are made of, for the traversal kernels (scopa_mccfr.hip: LaneSlots), built at first use
+    uint32_t *d_lane_tab = nullptr;   // [15][64] uint4: what a lane's node slots are made of, for the traversal kernels (scopa_mccfr.hip: LaneSlots), built at first use
     uint16_t *d_sched = nullptr;   // events (uint32 each) | step offsets | [kDecision][8] path cells (layout: scopa_cfr.hip)
     int sched_steps = 0;
     bool sched_valid = false;      // false after scopa_set_deal
@@ -87,7 +89,7 @@ struct scopa_ctx {
 
     // graph mode of scopa_mccfr_iterate (scopa_mccfr.hip): captured (traverse, apply) x k chains by (batch, k); the iteration number
     // the captured launches use lives in d_meta[2]
-    struct GraphEntry { uint32_t batch, k; void *exec; };
+    struct GraphEntry { uint32_t batch, k, track; void *exec; };
     std::vector<GraphEntry> mccfr_graphs;
     bool mccfr_graph_mode = false;
 

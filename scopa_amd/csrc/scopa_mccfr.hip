@@ -130,16 +130,15 @@ k_mccfr_prepare(const uint64_t *__restrict__ g_key, const double *__restrict__ g
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Per-wavefront scratch in LDS: the records of one traversal pair (2 tasks) + what the update step needs.
+constexpr int kIdentSlot = 166;   // ws.npk[kIdentSlot]: the IDENTITY record (infoset = the all-ones row behind the table, action 0): what an update lane reads
+                                  // for the plies at or below its own node -- the factor 1.0 comes out of the same loads as the real factors, no select
 struct WaveScratch {
-    uint32_t npk[166];       // one record per node of plies 0..5 (2 + 6 + 10 + 25 + 40 nodes, then ply 5's 60 + 20 from slot 86): idx | infoset << 10
+    uint32_t npk[168];       // one record per node of plies 0..5 (2 + 6 + 10 + 25 + 40 nodes, then ply 5's 60 + 20 from slot 86): idx | infoset << 10
                              // | sampled action << 21.  The leaf stage reads ply 5's; the update step rebuilds a traverser node's reach and
-                             // sampling probability from its ancestors' records
-    int8_t p6[2 * 60];       // resolved leaf payoffs x2 (traverser's sign) per task
-    // the pair's random draws, 31-bit integers, indexed by node (base(ntl) + j, base = 0, 1, 6, 26); only the ones consumed are kept
-    uint32_t kx0[86];        // traverser 0: opponent nodes of plies 1,3,5   (slot 0 unused)
-    uint32_t ky0[26];        // traverser 0: traverser nodes of plies 0,2,4
-    uint32_t kx1[26];        // traverser 1: opponent nodes of plies 0,2,4
-    uint32_t ky1[26];        // traverser 1: traverser nodes of plies 1,3,5
+                             // sampling probability from its ancestors' records.  [166] = the identity record, [167] unused
+    int8_t p6[128];          // resolved leaf payoffs x2 (traverser's sign) per task, 2 x 60 (+ 8 unused)
+    uint32_t kdraw[64][4];   // the pair's random draws: lane l's Philox block as it came out of draw_pairs (31-bit integers) -- ONE 16-byte store per lane;
+                             // which word a node consumes is the lane table's business (kword)
 };
 static_assert(sizeof(WaveScratch) % 16 == 0, "WaveScratch must keep 16-byte alignment");
 
@@ -152,39 +151,40 @@ __device__ __forceinline__ void wave_lds_sync() {
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 }
 
+// LDS addresses as 32-bit integers: what the lane table below holds (a generic pointer laundered through a register would
+// come back as a flat pointer).
+__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p; }
+__device__ __forceinline__ uint32_t lds_read_u32(uint32_t a) { return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a; }
+__device__ __forceinline__ int lds_read_i8(uint32_t a) { return *(__attribute__((address_space(3))) const int8_t *)(uintptr_t)a; }
+__device__ __forceinline__ double lds_read_f64(uint32_t a) { return *(__attribute__((address_space(3))) const double *)(uintptr_t)a; }
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));   // a plain vector: HIP's uint4 class has no copy across address spaces
+__device__ __forceinline__ uint4 lds_read_u4(uint32_t a) {
+    const u32x4 v = *(__attribute__((address_space(3))) const u32x4 *)(uintptr_t)a;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+__device__ __forceinline__ void lds_write_u4(uint32_t a, uint32_t x, uint32_t y, uint32_t z, uint32_t w) {
+    *(__attribute__((address_space(3))) u32x4 *)(uintptr_t)a = u32x4{x, y, z, w};
+}
+
 // All random draws of one traversal pair in ONE dense pass: 44 + 14 Philox blocks on 58 lanes (20 64-bit multiplies per wavefront;
 // the first form drew one block per ply round at 3-60 % lane use, the second 112 blocks of which half the words went unused).
-// Lane < 44: traverser 0's block `lane`; lanes 44..57: traverser 1's block `lane - 44`.  Block p of a traverser covers ntl = 0 (p = 0),
-// 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair j0 = 2 * (p - first block of the level), j0 + 1; its words are
-// x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the traverser node below it.
-// Philox counter = (p, global traversal id, iteration, traverser), key = seed.
-constexpr int kStaticLds = 64 + 9216;   // k_mccfr_traverse: s_vis, s_one, s_next, s_slice (+ alignment) and the staged lane table, beside the dynamic LDS
-constexpr int kStaticLdsMulti = 64;     // k_mccfr_multi: s_vis, s_one
+// Lane < 44: traverser 0's block `lane`; lanes 44..57: traverser 1's block `lane - 44` (lanes 58..63 compute a block nobody reads: cheaper
+// than masking them).  Block p of a traverser covers ntl = 0 (p = 0), 1 (p = 1..3), 2 (p = 4..13), 3 (p = 14..43) and the node pair
+// j0 = 2 * (p - first block of the level), j0 + 1; its words are x(j0) | y(j0) | x(j0 + 1) | y(j0 + 1), x for the opponent node, y for the
+// traverser node below it.  Philox counter = (p, global traversal id, iteration, traverser), key = seed.
+constexpr int kLaneSlotVecs = 15;                         // the lane table: [15][64] uint4 (below)
+constexpr int kStaticLds = 64 + kLaneSlotVecs * 1024;     // k_mccfr_traverse / k_mccfr_multi: s_vis, s_next, s_slice (+ alignment) and the staged lane table, beside the dynamic LDS
+constexpr int kStaticLdsMulti = kStaticLds;
 
 template <int NP>
-__device__ __forceinline__ void draw_pairs(WaveScratch *ws, int lane, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
-    if (lane < 58) {
-        const int trav = lane < 44 ? 0 : 1, p = trav ? lane - 44 : lane;
-        const int ntl = p == 0 ? 0 : p < 4 ? 1 : p < 14 ? 2 : 3;
-        const int j0 = 2 * (p - (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 4 : 14));
-        const int node = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j0;            // index into the kx / ky arrays
-        const bool two = j0 + 1 < (ntl == 0 ? 1 : ntl == 1 ? 5 : ntl == 2 ? 20 : 60);      // the level has an odd node count at ntl 0, 1
-        philox_out x[NP];
+__device__ __forceinline__ void draw_pairs(uint32_t wsb, int lane, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo, uint32_t seed_hi) {
+    const int trav = lane < 44 ? 0 : 1, p = trav ? lane - 44 : lane;
+    philox_out x[NP];
 #pragma unroll
-        for (int i = 0; i < NP; i++) x[i] = philox4x32_10((uint32_t)p, b[i], iteration, (uint32_t)trav, seed_lo, seed_hi);   // independent chains
+    for (int i = 0; i < NP; i++) x[i] = philox4x32_10((uint32_t)p, b[i], iteration, (uint32_t)trav, seed_lo, seed_hi);   // independent chains
 #pragma unroll
-        for (int i = 0; i < NP; i++) {
-            WaveScratch &w = ws[i];
-            if (trav == 0) {
-                w.kx0[node] = x[i].x0 >> 1;
-                if (two) w.kx0[node + 1] = x[i].x2 >> 1;
-                if (ntl < 3) { w.ky0[node] = x[i].x1 >> 1; if (two) w.ky0[node + 1] = x[i].x3 >> 1; }
-            } else {
-                w.kx1[node] = x[i].x0 >> 1; w.ky1[node] = x[i].x1 >> 1;
-                if (two) { w.kx1[node + 1] = x[i].x2 >> 1; w.ky1[node + 1] = x[i].x3 >> 1; }
-            }
-        }
-    }
+    for (int i = 0; i < NP; i++)
+        lds_write_u4(wsb + (uint32_t)(i * sizeof(WaveScratch) + offsetof(WaveScratch, kdraw)) + 16u * (uint32_t)lane, x[i].x0 >> 1, x[i].x1 >> 1, x[i].x2 >> 1, x[i].x3 >> 1);
     wave_lds_sync();
 }
 
@@ -202,56 +202,29 @@ __host__ __device__ constexpr int npk_offset(int d) { return d == 0 ? 0 : d == 1
 __host__ __device__ constexpr int npk_slot(int trav, int d, int j) { return npk_offset(d) + (trav ? task_nodes(0, d) : 0) + j; }
 static_assert(npk_offset(1) == task_nodes(0, 0) + task_nodes(1, 0) && npk_offset(2) == npk_offset(1) + task_nodes(0, 1) + task_nodes(1, 1) &&
               npk_offset(3) == npk_offset(2) + task_nodes(0, 2) + task_nodes(1, 2) && npk_offset(4) == npk_offset(3) + task_nodes(0, 3) + task_nodes(1, 3) &&
-              npk_offset(4) + task_nodes(0, 4) + task_nodes(1, 4) <= npk_offset(5) && npk_offset(5) + task_nodes(0, 5) + task_nodes(1, 5) == 166,
+              npk_offset(4) + task_nodes(0, 4) + task_nodes(1, 4) <= npk_offset(5) && npk_offset(5) + task_nodes(0, 5) + task_nodes(1, 5) == kIdentSlot,
               "record slots of plies 0..5 tile WaveScratch::npk");
 
-// The update step's static knowledge, one row of 6 uint16 per update lane x (0..51: traverser x / 26, level m, node j): for every ply
-// q above the node the ws.npk slot of its ancestor there (low byte) and the action that leads from that ancestor towards the node if
-// it is FORCED by a re-expansion (high byte = action + 1; 0 = the ancestor's sampled action), 0xFFFF for q >= the node's ply;
-// entry 5 = the node's own slot.  Part of the lane table.
-constexpr int kAncRow = 6;
-struct AncRegs { uint32_t w[3]; };   // an update lane's row
-__device__ __forceinline__ void anc_build(int x, uint16_t *__restrict__ row) {
-    const int trav = x < kUpd ? 0 : 1, xx = trav ? x - kUpd : x;
-    const int m = xx == 0 ? 0 : xx < 6 ? 1 : 2;
-    int j = xx - (m == 0 ? 0 : m == 1 ? 1 : 6);
-    const int d = 2 * m + trav;
-    row[5] = (uint16_t)npk_slot(trav, d, j);
-    for (int q = 0; q < 5; q++) row[q] = 0xFFFFu;
-    for (int c = d; c > 0; c--) {                       // climb: node j of ply c -> its parent at ply c - 1
-        const int pd = c - 1, pn = 4 - (pd >> 1);
-        int forced = 0;
-        if ((pd & 1) == trav) { const int pj = j / (pn + 1), br = j - pj * (pn + 1); forced = br; j = pj; }   // br = 0: the sampled child
-        row[pd] = (uint16_t)(npk_slot(trav, pd, j) | (forced << 8));
-    }
-}
-
-// LDS addresses as 32-bit integers: what the lane-static tables below hold (a generic pointer laundered through a register would
-// come back as a flat pointer).
-__device__ __forceinline__ uint32_t lds_addr(const void *p) { return (uint32_t)(uintptr_t)(__attribute__((address_space(3))) const void *)p; }
-__device__ __forceinline__ uint32_t lds_read_u32(uint32_t a) { return *(__attribute__((address_space(3))) const uint32_t *)(uintptr_t)a; }
-
-// Everything about a lane's node SLOT that does not depend on the pair being walked -- which lane holds the parent, whether the action
-// towards the node is forced by a re-expansion, where its draw word lies, the update lane's
-// ancestor row -- is the same for every wavefront of every launch: k_lane_table computes it ONCE per context into a 9 KB table and a
-// wavefront loads its 36 words per lane under the prologue's other loads.  (Derived in the kernel it was ~300 VALU instructions per
-// wavefront before the first pair -- as much as a whole pair costs -- and, left to the compiler, 33 instead of 17 per ply and slot
-// inside the pair loop plus enough SGPR masks to spill the Philox round keys.)
-// Slot D = ply D's node of this lane (lane t < c0 is node t of traverser 0's recursion tree, the next c1 lanes are traverser 1's);
-// slot 6 = ply 5's second round (80 nodes); leaf slots q = 0, 1 = leaves lane, lane + 64 of the 120.
-struct LaneSlots {
-    uint32_t plane4[7];   // ds_bpermute address: 4 x the lane that holds the parent's record
-    uint32_t amask[7];    // action towards this node = (parent's sampled action & amask) | aforce
-    uint32_t aforce[7];
-    uint32_t kword[7];    // LDS address of the slot's draw word in the wave's scratch (table: offset within WaveScratch)
-    uint32_t leaf_rec[2], leaf_amask[2], leaf_aforce[2];   // the same for a leaf: LDS address of its ply-5 ancestor's record
-};
-// table layout: word w of lane l at [w / 4][l] . (w % 4), i.e. 9 x 64 uint4 -- a wavefront reads 9 coalesced 1 KB lines
-constexpr int kLaneWords = 36, kLaneVecs = kLaneWords / 4;
-constexpr int kLwPlane = 0, kLwAmask = 6, kLwAforce = 12, kLwKword = 18, kLwLeafRec = 25, kLwLeafAmask = 27, kLwLeafAforce = 29, kLwAnc = 31;   // 34, 35 unused
+// THE LANE TABLE.  Everything about a lane's node SLOT that does not depend on the pair being walked -- which lane holds the parent, whether the
+// action towards the node is forced by a re-expansion, where its draw word lies, which records an update lane's ancestors left -- is the same for
+// every wavefront of every launch: k_lane_table computes it ONCE per context into a 15 KB table, a workgroup stages it into LDS with its prologue,
+// and a stage READS ITS SLOT'S 16 BYTES WHEN IT RUNS (one ds_read_b128 per ply round).  History: derived in the kernel it was ~300 VALU instructions
+// per wavefront before the first pair; round 2's table was unpacked into 38 registers per lane once per wavefront (round 3: 156 VALU + 66 SALU
+// instructions behind the prologue's barrier, 17 scalar registers spilled) -- at the headline batch a wavefront walks ONE pair, so "once per wavefront"
+// was once per pair, and the update step still decoded its ancestor row with ~45 instructions per pair.  Offsets are relative to the wave's scratch.
+//   vec S = 0..6   ply D = S (S = 6: ply 5's second round, 80 nodes): { 4 x parent lane (ds_bpermute address), amask, aforce, draw word offset }
+//                  action towards this node = (parent's sampled action & amask) | aforce; lanes without a node read lane 0 / word 0 and are masked off
+//   vec 7, 8       leaves lane, lane + 64 of the 120: { offset of the ply-5 ancestor's record, amask, aforce, - }
+//   vec 9..14      the update lane x (0..51: traverser x / 26, level m, node j):
+//                  9: record offsets of the ancestors at plies 0..3 | 10: ply 4's, the node's own record, its action count nX, - | 11: p6 offsets of the
+//                  leaf values of actions 0..3 (beyond nX: the last one's) | 12: am24 of plies 0..3 | 13: am24 of ply 4, af8 of plies 0..2 | 14: af8 of plies 3, 4
+//                  factor towards the node at ply q = sigma[record's infoset][((record >> 18) & am24) | af8 : 8 x the action]; plies at or below the node's
+//                  own read the identity record (infoset = the all-ones row, action 0): factor 1.0
+constexpr int kLvLeaf = 7, kLvUpd = 9;
+struct LaneTabRow { uint4 v[kLaneSlotVecs]; };
 
 template <int D, int ROUND>
-__device__ __forceinline__ void lane_slot_build(uint32_t *w, int lane) {
+__device__ __forceinline__ void lane_slot_build(LaneTabRow &row, int lane) {
     constexpr int S = D + ROUND;
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
     const int t = lane + 64 * ROUND;
@@ -268,19 +241,60 @@ __device__ __forceinline__ void lane_slot_build(uint32_t *w, int lane) {
         if (p_trav) { pj = j / (pn + 1); br = j - pj * (pn + 1); }
         if (valid) plane4 = 4u * (uint32_t)((trav ? task_nodes(0, pd) : 0) + pj);
         if (valid && p_trav && br > 0) { amask = 0u; aforce = (uint32_t)(br - 1); }
-        w[kLwPlane + S - 1] = plane4; w[kLwAmask + S - 1] = amask; w[kLwAforce + S - 1] = aforce;
     }
-    // this node's draw: slot (ntl, j) of its traverser, prepared by draw_pairs()
-    const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 6 : 26) + j;
-    const uint32_t koff = trav == 0 ? (is_trav ? offsetof(WaveScratch, ky0) : offsetof(WaveScratch, kx0))
-                                    : (is_trav ? offsetof(WaveScratch, ky1) : offsetof(WaveScratch, kx1));
-    w[kLwKword + S] = koff + 4u * (uint32_t)blk;
+    // this node's draw: word (j & 1) * 2 + (traverser node ? 1 : 0) of block first(ntl) + j / 2 of its traverser, i.e. of lane (traverser ? 44 : 0) + block
+    const int blk = (ntl == 0 ? 0 : ntl == 1 ? 1 : ntl == 2 ? 4 : 14) + (j >> 1);
+    const uint32_t kword = valid ? (uint32_t)(offsetof(WaveScratch, kdraw) + 16 * ((trav ? 44 : 0) + blk) + 4 * ((j & 1) * 2 + (is_trav ? 1 : 0)))
+                                 : (uint32_t)offsetof(WaveScratch, kdraw);
+    row.v[S] = make_uint4(plane4, amask, aforce, kword);
 }
+
+// the update lane x's row (vecs 9..14)
+__device__ __forceinline__ void upd_build(LaneTabRow &row, int x) {
+    const uint32_t ident = (uint32_t)(offsetof(WaveScratch, npk) + 4 * kIdentSlot);
+    uint32_t rec[5] = {ident, ident, ident, ident, ident}, am[5] = {24u, 24u, 24u, 24u, 24u}, af[5] = {0u, 0u, 0u, 0u, 0u};
+    uint32_t own = ident, nX = 1u, p6o[4] = {(uint32_t)offsetof(WaveScratch, p6), (uint32_t)offsetof(WaveScratch, p6), (uint32_t)offsetof(WaveScratch, p6), (uint32_t)offsetof(WaveScratch, p6)};
+    if (x < 2 * kUpd) {
+        const int trav = x < kUpd ? 0 : 1, xx = trav ? x - kUpd : x;
+        const int m = xx == 0 ? 0 : xx < 6 ? 1 : 2;
+        int j = xx - (m == 0 ? 0 : m == 1 ? 1 : 6);
+        const int d = 2 * m + trav;
+        nX = (uint32_t)(4 - m);
+        const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i + 1, 0, ...) = base + (i + 1) * stride
+        const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
+        for (int c = 0; c < 4; c++) p6o[c] = (uint32_t)(offsetof(WaveScratch, p6) + trav * 60 + base + ((c < (int)nX ? c : (int)nX - 1) + 1) * stride);
+        own = (uint32_t)(offsetof(WaveScratch, npk) + 4 * npk_slot(trav, d, j));
+        for (int c = d; c > 0; c--) {                       // climb: node j of ply c -> its parent at ply c - 1
+            const int pd = c - 1, pn = 4 - (pd >> 1);
+            int forced = 0;
+            if ((pd & 1) == trav) { const int pj = j / (pn + 1), br = j - pj * (pn + 1); forced = br; j = pj; }   // br = 0: the sampled child
+            rec[pd] = (uint32_t)(offsetof(WaveScratch, npk) + 4 * npk_slot(trav, pd, j));
+            if (forced) { am[pd] = 0u; af[pd] = 8u * (uint32_t)(forced - 1); }
+        }
+    }
+    row.v[kLvUpd + 0] = make_uint4(rec[0], rec[1], rec[2], rec[3]);
+    row.v[kLvUpd + 1] = make_uint4(rec[4], own, nX, 0u);
+    row.v[kLvUpd + 2] = make_uint4(p6o[0], p6o[1], p6o[2], p6o[3]);
+    row.v[kLvUpd + 3] = make_uint4(am[0], am[1], am[2], am[3]);
+    row.v[kLvUpd + 4] = make_uint4(am[4], af[0], af[1], af[2]);
+    row.v[kLvUpd + 5] = make_uint4(af[3], af[4], 0u, 0u);
+}
+
+// what the walk needs beside the pair: LDS base addresses (32-bit) and the tree maps
+struct WalkEnv {
+    uint32_t wsb;          // this wavefront's scratch (the first of its one or two WaveScratch)
+    uint32_t tab;          // the staged lane table + 16 x lane: vec S of this lane at tab + 1024 S
+    const uint16_t *s_inf;
+    const int8_t *s_pay;
+    const double *s_sigcdf;
+    double *s_dR;
+    uint8_t *s_seen;       // first-visit tracking (the dict views' insertion of keys): nullptr once every infoset of the deal has been seen
+    unsigned int *s_cnt;
+};
 
 // One ply of NP traversal pairs (one or two: the pairs' dependent chains -- parent record, infoset, thresholds -- interleave).
 template <int D, int NP>
-__device__ __forceinline__ void ply_step(WaveScratch *ws, int lane, const uint16_t *__restrict__ s_inf, const double *__restrict__ s_sigcdf,
-                                         uint8_t *__restrict__ s_seen, unsigned int *__restrict__ s_cnt, NodeRegs (&st)[NP], const LaneSlots &ls) {
+__device__ __forceinline__ void ply_step(const WalkEnv &e, int lane, NodeRegs (&st)[NP]) {
     constexpr int n = 4 - (D >> 1);
     constexpr int c0 = task_nodes(0, D), c1 = task_nodes(1, D);
     constexpr int NR = c0 + c1 > 64 ? 2 : 1;   // ply 5: 80 nodes, two rounds
@@ -291,24 +305,26 @@ __device__ __forceinline__ void ply_step(WaveScratch *ws, int lane, const uint16
         uint32_t k, thr0, thr1, thr2;
     };
     Pre g[NP][NR];
+    uint4 sl[NR];
+#pragma unroll
+    for (int r = 0; r < NR; r++) sl[r] = lds_read_u4(e.tab + 1024u * (uint32_t)(D + r));
 #pragma unroll
     for (int i = 0; i < NP; i++)
 #pragma unroll
         for (int r = 0; r < NR; r++) {
-            const int S = D + r;
             Pre &q = g[i][r];
             q.idx = 0;
             if constexpr (D > 0) {  // the parent's hand-down: executed by ALL lanes (a cross-lane read wants its source lane enabled)
                 constexpr int pn = 4 - ((D > 0 ? D - 1 : 0) >> 1);
-                const uint32_t ppk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)ls.plane4[S], (int)st[i].pk);
-                const uint32_t act = ((ppk >> 21) & ls.amask[S]) | ls.aforce[S];
+                const uint32_t ppk = (uint32_t)__builtin_amdgcn_ds_bpermute((int)sl[r].x, (int)st[i].pk);
+                const uint32_t act = ((ppk >> 21) & sl[r].y) | sl[r].z;
                 q.idx = (int)((ppk & 1023u) * pn + act);
             }
-            q.In = s_inf[level_offset(D) + q.idx];
-            q.k = lds_read_u32(ls.kword[S] + (uint32_t)(i * sizeof(WaveScratch)));
+            q.In = e.s_inf[level_offset(D) + q.idx];
+            q.k = lds_read_u32(e.wsb + sl[r].w + (uint32_t)(i * sizeof(WaveScratch)));
             // only the first n-1 thresholds can count (those from n-1 on are >= 2^31 > k): one LDS read at the n = 2 plies, where
             // most nodes are, instead of three
-            const uint32_t *thr = reinterpret_cast<const uint32_t *>(s_sigcdf + q.In * kRow + 4);
+            const uint32_t *thr = reinterpret_cast<const uint32_t *>(e.s_sigcdf + q.In * kRow + 4);
             q.thr0 = thr[0];
             q.thr1 = n > 2 ? thr[1] : 0xFFFFFFFFu;
             q.thr2 = n > 3 ? thr[2] : 0xFFFFFFFFu;
@@ -321,10 +337,10 @@ __device__ __forceinline__ void ply_step(WaveScratch *ws, int lane, const uint16
             const int t = 64 * r + lane;
             if (t < c0 + c1) {
                 const int a = (q.thr0 <= q.k) + (q.thr1 <= q.k) + (q.thr2 <= q.k);
-                if ((D & 1) == (t < c0 ? 0 : 1)) atomicAdd(&s_cnt[q.In], 1u);   // strategy_sum += sigma per traverser visit (mc_cfr.py:84); also marks the infoset seen
-                else s_seen[q.In] = 1;                                          // benign race: every writer stores 1
+                if ((D & 1) == (t < c0 ? 0 : 1)) atomicAdd(&e.s_cnt[q.In], 1u);   // strategy_sum += sigma per traverser visit (mc_cfr.py:84); also marks the infoset seen
+                else if (e.s_seen) e.s_seen[q.In] = 1;                          // benign race: every writer stores 1
                 const uint32_t pk = (uint32_t)q.idx | ((uint32_t)q.In << 10) | ((uint32_t)a << 21);
-                ws[i].npk[npk_offset(D) + t] = pk;    // the update step walks these records; the leaf stage reads ply 5's
+                *(__attribute__((address_space(3))) uint32_t *)(uintptr_t)(e.wsb + (uint32_t)(i * sizeof(WaveScratch) + offsetof(WaveScratch, npk) + 4 * npk_offset(D)) + 4u * (uint32_t)t) = pk;
                 if constexpr (D < 5) st[i].pk = pk;
             }
         }
@@ -346,47 +362,47 @@ __device__ unsigned long long g_wave_phases[4 * 16];   // workgroup 0, per wavef
 // load on the CU (tests/tools/walk_stamps.py): with 16 wavefronts per CU neither the LDS array nor the SIMDs were more than 70 % busy.
 // A wavefront that has two or more pairs to walk therefore takes them two at a time: every stage gathers for both, then stores for both.
 template <int NP>
-__device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint16_t *__restrict__ s_inf, const int8_t *__restrict__ s_pay,
-                                           const double *__restrict__ s_sigcdf, double *__restrict__ s_dR, uint8_t *__restrict__ s_seen,
-                                           unsigned int *__restrict__ s_cnt, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo,
-                                           uint32_t seed_hi, unsigned int &my_pairs, const AncRegs &anc, const LaneSlots &ls,
-                                           const double *__restrict__ s_one) {
+__device__ __forceinline__ void walk_pairs(const WalkEnv &e, int lane, const uint32_t (&b)[NP], uint32_t iteration, uint32_t seed_lo,
+                                           uint32_t seed_hi, unsigned int &my_pairs) {
 #ifdef SCOPA_WALK_STAMPS
     const unsigned long long w_start_ = wall_clock64();
     unsigned long long t_prev_ = clock64();
 #endif
-    draw_pairs<NP>(ws, lane, b, iteration, seed_lo, seed_hi);
+    draw_pairs<NP>(e.wsb, lane, b, iteration, seed_lo, seed_hi);
     WALK_STAMP(0);
     // plies 0..5: one lane per unique node of a pair's two recursion trees (ply constants are compile-time); a ply's nodes
     // stay in their lanes' registers for the next ply to fetch
     NodeRegs st[NP];
 #pragma unroll
     for (int i = 0; i < NP; i++) st[i].pk = 0u;
-    ply_step<0, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(1);
-    ply_step<1, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(2);
-    ply_step<2, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(3);
-    ply_step<3, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(4);
-    ply_step<4, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(5);
-    ply_step<5, NP>(ws, lane, s_inf, s_sigcdf, s_seen, s_cnt, st, ls); WALK_STAMP(6);
+    ply_step<0, NP>(e, lane, st); WALK_STAMP(1);
+    ply_step<1, NP>(e, lane, st); WALK_STAMP(2);
+    ply_step<2, NP>(e, lane, st); WALK_STAMP(3);
+    ply_step<3, NP>(e, lane, st); WALK_STAMP(4);
+    ply_step<4, NP>(e, lane, st); WALK_STAMP(5);
+    ply_step<5, NP>(e, lane, st); WALK_STAMP(6);
     my_pairs += NP;   // wave-uniform; the recursion tree has one shape: kPairDecisionVisits + kPairTerminalVisits per pair
     // plies 6-7 (one legal action each): leaf payoffs, seen flags, visit counts.  120 leaves on 64 lanes: all of a lane's items are
     // loaded before any is used (two dependent LDS round trips for the stage)
     {
+        uint4 lf[2];
+#pragma unroll
+        for (int q = 0; q < 2; q++) lf[q] = lds_read_u4(e.tab + 1024u * (uint32_t)(kLvLeaf + q));
         uint32_t ppk[NP][2];
 #pragma unroll
         for (int i = 0; i < NP; i++)
 #pragma unroll
-            for (int q = 0; q < 2; q++) ppk[i][q] = lds_read_u32(ls.leaf_rec[q] + (uint32_t)(i * sizeof(WaveScratch)));
+            for (int q = 0; q < 2; q++) ppk[i][q] = lds_read_u32(e.wsb + lf[q].x + (uint32_t)(i * sizeof(WaveScratch)));
         int I6[NP][2], I7[NP][2], pay[NP][2];
 #pragma unroll
         for (int i = 0; i < NP; i++)
 #pragma unroll
             for (int q = 0; q < 2; q++) {
-                const uint32_t act = ((ppk[i][q] >> 21) & ls.leaf_amask[q]) | ls.leaf_aforce[q];
+                const uint32_t act = ((ppk[i][q] >> 21) & lf[q].y) | lf[q].z;
                 const int idx6 = (int)((ppk[i][q] & 1023u) * 2 + act);   // = index of the ply-7 node and of the leaf as well
-                I6[i][q] = s_inf[level_offset(6) + idx6];
-                I7[i][q] = s_inf[level_offset(7) + idx6];
-                pay[i][q] = s_pay[idx6];
+                I6[i][q] = e.s_inf[level_offset(6) + idx6];
+                I7[i][q] = e.s_inf[level_offset(7) + idx6];
+                pay[i][q] = e.s_pay[idx6];
             }
 #pragma unroll
         for (int i = 0; i < NP; i++)
@@ -395,9 +411,10 @@ __device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint
                 const int t = lane + 64 * q;
                 if (t < 2 * 60) {
                     const int trv = t < 60 ? 0 : 1;
-                    s_seen[trv == 0 ? I7[i][q] : I6[i][q]] = 1;            // the opponent's node of the two (the traverser's is marked by its count)
-                    atomicAdd(&s_cnt[trv == 0 ? I6[i][q] : I7[i][q]], 1u); // the traverser's single-action node: strategy_sum += [1.0]
-                    ws[i].p6[t] = (int8_t)(trv == 0 ? pay[i][q] : -pay[i][q]);
+                    if (e.s_seen) e.s_seen[trv == 0 ? I7[i][q] : I6[i][q]] = 1;  // the opponent's node of the two (the traverser's is marked by its count)
+                    atomicAdd(&e.s_cnt[trv == 0 ? I6[i][q] : I7[i][q]], 1u);     // the traverser's single-action node: strategy_sum += [1.0]
+                    *(__attribute__((address_space(3))) int8_t *)(uintptr_t)(e.wsb + (uint32_t)(i * sizeof(WaveScratch) + offsetof(WaveScratch, p6)) + (uint32_t)t) =
+                        (int8_t)(trv == 0 ? pay[i][q] : -pay[i][q]);
                 }
             }
     }
@@ -406,46 +423,43 @@ __device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint
     // update: one lane per traverser node with > 1 action (mc_cfr.py:79-84).  The node's opponent reach and own sampling probability
     // are rebuilt here from its ancestors' records -- the product, root first, of sigma[ancestor infoset][action towards the node] over
     // the opponent's / the traverser's plies above it: the same factors in the same order as the reference's top-down updates
-    // (:58-65, :75-76).  Everything is loaded before anything is used.
+    // (:58-65, :75-76).  Everything is loaded before anything is used; which records, which leaf values and which forced actions come from
+    // the lane table (vecs 9..14).
     if (lane < 2 * kUpd) {
-        const int trav = lane < kUpd ? 0 : 1, x = trav ? lane - kUpd : lane;
-        const int m = x == 0 ? 0 : x < 6 ? 1 : 2;
-        const int j = x - (m == 0 ? 0 : m == 1 ? 1 : 6);
-        const int nX = 4 - m;
-        const int stride = m == 0 ? 12 : m == 1 ? 3 : 1;   // leaf group of (prefix, i+1, 0, ...) = base + (i+1)*stride
-        const int base = m == 0 ? 0 : m == 1 ? j * 12 : j * 3;
-        uint32_t ae[5];
+        const bool trav1 = lane >= kUpd;
+        uint4 u[6];
 #pragma unroll
-        for (int q = 0; q < 5; q++) ae[q] = (anc.w[q >> 1] >> (16 * (q & 1))) & 0xFFFFu;
+        for (int q = 0; q < 6; q++) u[q] = lds_read_u4(e.tab + 1024u * (uint32_t)(kLvUpd + q));
+        const uint32_t ro[5] = {u[0].x, u[0].y, u[0].z, u[0].w, u[1].x}, own = u[1].y;
+        const int nX = (int)u[1].z;
+        const uint32_t p6o[4] = {u[2].x, u[2].y, u[2].z, u[2].w};
+        const uint32_t am[5] = {u[3].x, u[3].y, u[3].z, u[3].w, u[4].x}, af[5] = {u[4].y, u[4].z, u[4].w, u[5].x, u[5].y};
         uint32_t rec[NP][5];
         int IX[NP], pv[NP][4];
 #pragma unroll
         for (int i = 0; i < NP; i++) {
+            const uint32_t wi = e.wsb + (uint32_t)(i * sizeof(WaveScratch));
 #pragma unroll
-            for (int q = 0; q < 5; q++) rec[i][q] = ws[i].npk[ae[q] == 0xFFFFu ? 0 : (ae[q] & 0xFFu)];   // slots < 86: one byte
-            IX[i] = (int)((ws[i].npk[anc.w[2] >> 16] >> 10) & 2047u);
-            const int8_t *p6 = ws[i].p6 + trav * 60;
+            for (int q = 0; q < 5; q++) rec[i][q] = lds_read_u32(wi + ro[q]);
+            IX[i] = (int)((lds_read_u32(wi + own) >> 10) & 2047u);
 #pragma unroll
-            for (int c = 0; c < 4; c++) pv[i][c] = p6[base + ((c < nX ? c : nX - 1) + 1) * stride];
+            for (int c = 0; c < 4; c++) pv[i][c] = lds_read_i8(wi + p6o[c]);
         }
         double fq[NP][5], sg[NP][4];
+        const uint32_t sig = lds_addr(e.s_sigcdf);
 #pragma unroll
         for (int i = 0; i < NP; i++) {
 #pragma unroll
-            for (int q = 0; q < 5; q++) {   // plies at or below the node's own: the factor 1.0, read from LDS like the others (one select, on the address)
-                const int forced = ae[q] >> 8;
-                const int act = forced ? forced - 1 : (int)(rec[i][q] >> 21);
-                const double *f = ae[q] != 0xFFFFu ? s_sigcdf + (int)((rec[i][q] >> 10) & 2047u) * kRow + act : s_one;
-                fq[i][q] = *f;
-            }
-            const double2 s01 = *reinterpret_cast<const double2 *>(s_sigcdf + IX[i] * kRow), s23 = *reinterpret_cast<const double2 *>(s_sigcdf + IX[i] * kRow + 2);
+            for (int q = 0; q < 5; q++)
+                fq[i][q] = lds_read_f64(sig + ((rec[i][q] >> 10) & 2047u) * (uint32_t)(kRow * 8) + (((rec[i][q] >> 18) & am[q]) | af[q]));
+            const double2 s01 = *reinterpret_cast<const double2 *>(e.s_sigcdf + IX[i] * kRow), s23 = *reinterpret_cast<const double2 *>(e.s_sigcdf + IX[i] * kRow + 2);
             sg[i][0] = s01.x; sg[i][1] = s01.y; sg[i][2] = s23.x; sg[i][3] = s23.y;
         }
 #pragma unroll
         for (int i = 0; i < NP; i++) {
             // even plies are traverser 0's, odd plies traverser 1's: two chains, root first (1.0 * x = x, x * 1.0 = x: the reference's products)
             const double even = (fq[i][0] * fq[i][2]) * fq[i][4], odd = fq[i][1] * fq[i][3];
-            const double sX = trav == 0 ? even : odd, rX = trav == 0 ? odd : even;
+            const double sX = trav1 ? odd : even, rX = trav1 ? even : odd;
             const double w = sX > 0.0 ? rX / sX : 0.0;       // weight = opp_reach / sampling_probs[player] if > 0 else 0
             double cfv[4], v = 0.0;
 #pragma unroll
@@ -457,7 +471,7 @@ __device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint
 #pragma unroll
             for (int c = 0; c < 4; c++) {
                 const double delta = w * (cfv[c] - v);
-                if (c < nX && delta != 0.0) atomicAdd(&s_dR[IX[i] * 4 + c], delta);
+                if (c < nX && delta != 0.0) atomicAdd(&e.s_dR[IX[i] * 4 + c], delta);
             }
         }
     }
@@ -468,18 +482,18 @@ __device__ __forceinline__ void walk_pairs(WaveScratch *ws, int lane, const uint
 #endif
 }
 
-// the lane table of a context (one launch of 64 threads, at the first traversal launch)
-__global__ void __launch_bounds__(64) k_lane_table(uint32_t *__restrict__ g_tab) {
+// the lane table of a context (one launch of 64 threads, at the first traversal launch): [kLaneSlotVecs][64] uint4
+__global__ void __launch_bounds__(64) k_lane_table(uint4 *__restrict__ g_tab) {
     const int lane = threadIdx.x;
-    uint32_t w[kLaneWords];
-    for (int i = 0; i < kLaneWords; i++) w[i] = 0u;
-    lane_slot_build<0, 0>(w, lane);
-    lane_slot_build<1, 0>(w, lane);
-    lane_slot_build<2, 0>(w, lane);
-    lane_slot_build<3, 0>(w, lane);
-    lane_slot_build<4, 0>(w, lane);
-    lane_slot_build<5, 0>(w, lane);
-    lane_slot_build<5, 1>(w, lane);
+    LaneTabRow row;
+    for (int i = 0; i < kLaneSlotVecs; i++) row.v[i] = make_uint4(0u, 0u, 0u, 0u);
+    lane_slot_build<0, 0>(row, lane);
+    lane_slot_build<1, 0>(row, lane);
+    lane_slot_build<2, 0>(row, lane);
+    lane_slot_build<3, 0>(row, lane);
+    lane_slot_build<4, 0>(row, lane);
+    lane_slot_build<5, 0>(row, lane);
+    lane_slot_build<5, 1>(row, lane);
     for (int q = 0; q < 2; q++) {
         const int t = lane + 64 * q;
         const bool on = t < 2 * 60;
@@ -487,36 +501,18 @@ __global__ void __launch_bounds__(64) k_lane_table(uint32_t *__restrict__ g_tab)
         // ply-5 ancestor: traverser 0 -> opponent node (one child); traverser 1 -> traverser node (3 branches)
         int pj = j, kk = 0;
         if (trv == 1) { pj = j / 3; kk = j - pj * 3; }
-        w[kLwLeafRec + q] = (uint32_t)(offsetof(WaveScratch, npk) + 4 * (npk_offset(5) + (trv ? 60 : 0) + pj));
-        w[kLwLeafAmask + q] = (trv == 1 && kk > 0) ? 0u : ~0u;
-        w[kLwLeafAforce + q] = (trv == 1 && kk > 0) ? (uint32_t)(kk - 1) : 0u;
+        row.v[kLvLeaf + q] = make_uint4((uint32_t)(offsetof(WaveScratch, npk) + 4 * (npk_offset(5) + (trv ? 60 : 0) + pj)),
+                                        (trv == 1 && kk > 0) ? 0u : ~0u, (trv == 1 && kk > 0) ? (uint32_t)(kk - 1) : 0u, 0u);
     }
-    uint16_t row[kAncRow] = {0, 0, 0, 0, 0, 0};
-    if (lane < 2 * kUpd) anc_build(lane, row);
-    for (int i = 0; i < 3; i++) w[kLwAnc + i] = (uint32_t)row[2 * i] | ((uint32_t)row[2 * i + 1] << 16);
-    for (int i = 0; i < kLaneWords; i++) g_tab[((i >> 2) * 64 + lane) * 4 + (i & 3)] = w[i];
+    upd_build(row, lane);
+    for (int i = 0; i < kLaneSlotVecs; i++) g_tab[i * 64 + lane] = row.v[i];
 }
 
-struct LaneVecs { uint4 v[kLaneVecs]; };
-__device__ __forceinline__ LaneVecs lane_table_load(const uint4 *__restrict__ g_tab, int lane) {
-    LaneVecs r;
-#pragma unroll
-    for (int f = 0; f < kLaneVecs; f++) r.v[f] = g_tab[f * 64 + lane];
-    return r;
-}
-__device__ __forceinline__ void lane_table_unpack(const LaneVecs &r, uint32_t ws_base, LaneSlots &ls, AncRegs &anc) {
-    uint32_t w[kLaneWords];
-#pragma unroll
-    for (int f = 0; f < kLaneVecs; f++) { w[4 * f] = r.v[f].x; w[4 * f + 1] = r.v[f].y; w[4 * f + 2] = r.v[f].z; w[4 * f + 3] = r.v[f].w; }
-    ls.plane4[0] = ls.amask[0] = ls.aforce[0] = 0u;
-#pragma unroll
-    for (int S = 1; S < 7; S++) { ls.plane4[S] = w[kLwPlane + S - 1]; ls.amask[S] = w[kLwAmask + S - 1]; ls.aforce[S] = w[kLwAforce + S - 1]; }
-#pragma unroll
-    for (int S = 0; S < 7; S++) ls.kword[S] = ws_base + w[kLwKword + S];
-#pragma unroll
-    for (int q = 0; q < 2; q++) { ls.leaf_rec[q] = ws_base + w[kLwLeafRec + q]; ls.leaf_amask[q] = w[kLwLeafAmask + q]; ls.leaf_aforce[q] = w[kLwLeafAforce + q]; }
-#pragma unroll
-    for (int i = 0; i < 3; i++) anc.w[i] = w[kLwAnc + i];
+// a wavefront's part of the walk's set-up: its scratch's identity record(s) (lane 0; made visible to the wave's other lanes by the first
+// wave_lds_sync of walk_pairs, long before the update step reads it)
+__device__ __forceinline__ void wave_scratch_init(WaveScratch *ws, int n_scratch, int lane, int n_infosets) {
+    if (lane == 0)
+        for (int i = 0; i < n_scratch; i++) ws[i].npk[kIdentSlot] = (uint32_t)n_infosets << 10;
 }
 
 // which group table a workgroup adds into: neighbours in dispatch order -- eight consecutive workgroups, one per XCD -- share a table
@@ -541,22 +537,21 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                  const double *__restrict__ g_sigcdf, double *__restrict__ g_groups,
                  int n_infosets, uint32_t seed_lo, uint32_t seed_hi, uint32_t iteration, uint32_t b0, uint32_t nb,
                  unsigned long long *__restrict__ g_wg_counts, uint32_t *__restrict__ g_visit, unsigned long long *__restrict__ g_clock,
-                 const uint4 *__restrict__ g_lane_tab, const uint32_t *__restrict__ g_iter) {
+                 const uint4 *__restrict__ g_lane_tab, const uint32_t *__restrict__ g_iter, uint32_t track_seen) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
     if (g_iter) iteration = *g_iter;   // graph-captured iteration loops (scopa_mccfr_graph_mode): the iteration number lives in a device word that
                                        // the apply kernel advances, so that one captured graph serves every replay; draws stay keyed by it
-    __shared__ double s_one[1];
     __shared__ uint32_t s_next[1];   // next pair of this workgroup not taken yet
     __shared__ uint32_t s_slice[1];  // wavefronts that have left the pair loop
-    __shared__ uint4 s_lane_tab[kLaneVecs * 64];   // the lane table, staged once per workgroup (16 wavefronts reading it from L2 each: 147 KB per workgroup)
+    __shared__ uint4 s_lane_tab[kLaneSlotVecs * 64];   // the lane table, staged once per workgroup; a stage reads its slot's 16 bytes when it runs
     const unsigned long long t_start = wall_clock64();   // 100 MHz device-wide clock: this workgroup's phase stamps (sampled launches only)
 #ifdef SCOPA_WALK_STAMPS
     const unsigned long long c_entry_ = clock64();
 #endif
     const int I = n_infosets;
-    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows)
-    double *s_dR = s_sigcdf + (size_t)I * kRow;                                  // [I][4] (16-byte aligned)
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I + 1][kRow]: sigma[4] | 4 x uint32 thresholds (48-byte rows); row I = all ones (the identity record's)
+    double *s_dR = s_sigcdf + (size_t)(I + 1) * kRow;                            // [I][4] (16-byte aligned)
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_dR + (size_t)I * 4); // [wavefronts of this workgroup][2 pairs in flight]
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + 2 * (blockDim.x >> 6));  // [I] traverser visits
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));  // [1653] (+pad)
@@ -565,9 +560,8 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, n_waves = blockDim.x >> 6, nthr = blockDim.x;
     if (tid < 2) s_vis[tid] = 0u;
-    const uint4 lane_piece = tid < kLaneVecs * 64 ? g_lane_tab[tid] : make_uint4(0u, 0u, 0u, 0u);
+    const uint4 lane_piece = tid < kLaneSlotVecs * 64 ? g_lane_tab[tid] : make_uint4(0u, 0u, 0u, 0u);
     if (tid == 0) {
-        s_one[0] = 1.0;
         s_slice[0] = 0u;
         const uint32_t per_wg = (nb + gridDim.x - 1) / gridDim.x, W = blockDim.x >> 6;
         const uint32_t first = blockIdx.x * per_wg, count = first < nb ? (nb - first < per_wg ? nb - first : per_wg) : 0u;
@@ -591,20 +585,22 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         const uint32_t wi = tid < kDecision / 2 ? gi[tid] : 0u;
         const uint32_t wp = tid < kTerminal / 4 ? gp[tid] : 0u;
         const uint16_t last_inf = g_infoset[kDecision - 1];
-        for (int i = tid; i < I * 4; i += nthr) s_dR[i] = 0.0;
-        for (int r = tid; r < I; r += nthr) { s_cnt[r] = 0u; s_seen[r] = 0; }
+        for (int i = tid; i < I * 2; i += nthr) reinterpret_cast<double2 *>(s_dR)[i] = make_double2(0.0, 0.0);
+        for (int r = tid; r < I; r += nthr) s_cnt[r] = 0u;
+        if (track_seen) for (int r = tid; r < I; r += nthr) s_seen[r] = 0;
+        if (tid < 4) s_sigcdf[(size_t)I * kRow + tid] = 1.0;                      // the identity row
 #pragma unroll
         for (int j = 0; j < kSig; j++) {
             const int idx = tid + j * nthr;
             if (idx < I * 3) s2[idx] = v[j];
         }
         for (int idx = tid + kSig * nthr; idx < I * 3; idx += nthr) s2[idx] = g2[idx];  // narrower workgroups (many infosets): the rest, plainly
-        if (tid < kLaneVecs * 64) s_lane_tab[tid] = lane_piece;
+        if (tid < kLaneSlotVecs * 64) s_lane_tab[tid] = lane_piece;
         if (tid < kDecision / 2) reinterpret_cast<uint32_t *>(s_inf)[tid] = wi;
         if (tid == 0) s_inf[kDecision - 1] = last_inf;
         if (tid < kTerminal / 4) reinterpret_cast<uint32_t *>(s_pay)[tid] = wp;
     }
-    for (int i = tid + nthr; i < kLaneVecs * 64; i += nthr) s_lane_tab[i] = g_lane_tab[i];   // workgroups narrower than 576 threads (deals with > ~1430 infosets): the rest of the table
+    for (int i = tid + nthr; i < kLaneSlotVecs * 64; i += nthr) s_lane_tab[i] = g_lane_tab[i];   // workgroups narrower than 960 threads (deals with many infosets): the rest of the table
     for (int i = tid + nthr; i < kDecision / 2; i += nthr) reinterpret_cast<uint32_t *>(s_inf)[i] = gi[i];
     for (int i = tid + nthr; i < kTerminal / 4; i += nthr) reinterpret_cast<uint32_t *>(s_pay)[i] = gp[i];
     __syncthreads();
@@ -615,9 +611,10 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
 #endif
 
     WaveScratch *ws = s_wave + 2 * wave;
-    AncRegs anc;
-    LaneSlots ls;
-    lane_table_unpack(lane_table_load(s_lane_tab, lane), lds_addr(ws), ls, anc);
+    wave_scratch_init(ws, 2, lane, I);
+    WalkEnv env;
+    env.wsb = lds_addr(ws); env.tab = lds_addr(s_lane_tab) + 16u * (uint32_t)lane;
+    env.s_inf = s_inf; env.s_pay = s_pay; env.s_sigcdf = s_sigcdf; env.s_dR = s_dR; env.s_seen = track_seen ? s_seen : nullptr; env.s_cnt = s_cnt;
     unsigned int my_pairs = 0;   // pairs this wavefront walked
     // ---- main loop: every WAVEFRONT walks its own traversal pairs, no workgroup barrier inside --------------------------
     // The workgroup owns pairs [first, first + count); its wavefronts TAKE them from a counter in LDS instead of owning a fixed share:
@@ -638,10 +635,10 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
         for (;;) {
             if (g == 2 && c + 1 < count) {      // two pairs in flight
                 const uint32_t two[2] = {b0 + first + c, b0 + first + c + 1};
-                walk_pairs<2>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, two, iteration, seed_lo, seed_hi, my_pairs, anc, ls, s_one);
+                walk_pairs<2>(env, lane, two, iteration, seed_lo, seed_hi, my_pairs);
             } else if (c < count) {
                 const uint32_t one[1] = {b0 + first + c};
-                walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_dR, s_seen, s_cnt, one, iteration, seed_lo, seed_hi, my_pairs, anc, ls, s_one);
+                walk_pairs<1>(env, lane, one, iteration, seed_lo, seed_hi, my_pairs);
             }
             if (count <= W || c + g >= count) break;   // nothing was left behind the static takes / the counter has run out
             g = count - c > 4 * W ? 2u : 1u;             // single pairs towards the end: the last take bounds the imbalance
@@ -676,7 +673,7 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
                     if (v != 0.0) atomicAdd(&tab[group_cell(k, r)], v);
                 }
                 const unsigned int c = atomicExch(&s_cnt[r], 0u);
-                if (c != 0u) { atomicAdd(&tab[group_cell(4, r)], (double)c); s_seen[r] = 1; }
+                if (c != 0u) { atomicAdd(&tab[group_cell(4, r)], (double)c); if (track_seen) s_seen[r] = 1; }
             }
         }
     }
@@ -686,9 +683,10 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
     // bytes; float64 atomics execute at the memory side and return nothing) ------------------------------------------------------
     const unsigned long long t_walk = wall_clock64();
     {
-        // infosets first seen by this launch: the loads go out first, their answers are used after the atomics have been issued
-        const bool first0 = tid < I && (s_seen[tid] || s_cnt[tid]) && g_visit[tid] == 0u;
-        const bool first1 = tid + nthr < I && (s_seen[tid + nthr] || s_cnt[tid + nthr]) && g_visit[tid + nthr] == 0u;
+        // infosets first seen by this launch (only while the deal still has unseen ones: track_seen): the loads go out first, their answers are used
+        // after the atomics have been issued
+        const bool first0 = track_seen && tid < I && (s_seen[tid] || s_cnt[tid]) && g_visit[tid] == 0u;
+        const bool first1 = track_seen && tid + nthr < I && (s_seen[tid + nthr] || s_cnt[tid + nthr]) && g_visit[tid + nthr] == 0u;
         double *tab = g_groups + (size_t)group_of(blockIdx.x) * kDeltaTable;
         for (int k = 0; k < 5; k++)
             for (int r = tid; r < I; r += nthr) {
@@ -697,8 +695,9 @@ k_mccfr_traverse(const uint16_t *__restrict__ g_infoset, const int8_t *__restric
             }
         if (first0) g_visit[tid] = 0x40000000u + (uint32_t)tid;              // racing writers store the same value
         if (first1) g_visit[tid + nthr] = 0x40000000u + (uint32_t)(tid + nthr);
-        for (int r = tid + 2 * nthr; r < I; r += nthr)                       // narrow workgroups (many infosets): the rest, plainly
-            if ((s_seen[r] || s_cnt[r]) && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
+        if (track_seen)
+            for (int r = tid + 2 * nthr; r < I; r += nthr)                   // narrow workgroups (many infosets): the rest, plainly
+                if ((s_seen[r] || s_cnt[r]) && g_visit[r] == 0u) g_visit[r] = 0x40000000u + (uint32_t)r;
     }
     // exact visit counters: pairs walked per wavefront x the visits of a pair -> LDS -> this workgroup's own slot (a no-return atomic on a word nobody else adds to;
     // scopa_counters() adds the slots up
@@ -728,17 +727,16 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
               uint32_t batch, const uint4 *__restrict__ g_lane_tab) {
     extern __shared__ __align__(16) unsigned char smem[];
     __shared__ unsigned int s_vis[2];
-    __shared__ double s_one[1];
-    const LaneVecs lane_words = lane_table_load(g_lane_tab, threadIdx.x & 63);
-    if (threadIdx.x == 0) s_one[0] = 1.0;
+    __shared__ uint4 s_lane_tab[kLaneSlotVecs * 64];
+    for (int i = threadIdx.x; i < kLaneSlotVecs * 64; i += blockDim.x) s_lane_tab[i] = g_lane_tab[i];
     {
         const size_t deal = blockIdx.x;
         g_infoset += deal * kDecision; g_payoff += deal * kTerminal; g_key += deal * kDecision; g_regret += deal * kDecision * 4;
         g_strat += deal * kDecision * 4; g_meta += deal * 8; g_visit += deal * kDecision; g_counters += deal * 8;
     }
     const int I = g_meta[0];
-    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I][kRow] frozen rows
-    double *s_R = s_sigcdf + (size_t)I * kRow;                                   // [I][4] live regret table
+    double *s_sigcdf = reinterpret_cast<double *>(smem);                         // [I + 1][kRow] frozen rows; row I = all ones (the identity record's)
+    double *s_R = s_sigcdf + (size_t)(I + 1) * kRow;                             // [I][4] live regret table
     WaveScratch *s_wave = reinterpret_cast<WaveScratch *>(s_R + (size_t)I * 4);
     unsigned int *s_cnt = reinterpret_cast<unsigned int *>(s_wave + (blockDim.x >> 6));
     uint16_t *s_inf = reinterpret_cast<uint16_t *>(reinterpret_cast<unsigned char *>(s_cnt) + (((size_t)I * 4 + 15) & ~(size_t)15));
@@ -750,11 +748,13 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
     for (int r = tid; r < I; r += blockDim.x) { s_cnt[r] = 0u; s_seen[r] = 0; }
     for (int i = tid; i < kDecision; i += blockDim.x) s_inf[i] = g_infoset[i];
     for (int i = tid; i < kTerminal; i += blockDim.x) s_pay[i] = g_payoff[i];
+    if (tid < 4) s_sigcdf[(size_t)I * kRow + tid] = 1.0;
     __syncthreads();
     WaveScratch *ws = s_wave + wave;
-    AncRegs anc;
-    LaneSlots ls;
-    lane_table_unpack(lane_words, lds_addr(ws), ls, anc);
+    wave_scratch_init(ws, 1, lane, I);
+    WalkEnv env;
+    env.wsb = lds_addr(ws); env.tab = lds_addr(s_lane_tab) + 16u * (uint32_t)lane;
+    env.s_inf = s_inf; env.s_pay = s_pay; env.s_sigcdf = s_sigcdf; env.s_dR = s_R; env.s_seen = s_seen; env.s_cnt = s_cnt;
     unsigned int my_pairs = 0;   // pairs this wavefront walked
     for (uint32_t it = 0; it < n_iters; it++) {
         for (int r = tid; r < I; r += blockDim.x) {  // freeze this iteration's strategy
@@ -768,7 +768,7 @@ k_mccfr_multi(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict__
         __syncthreads();
         for (uint32_t pg = (uint32_t)wave; pg < batch; pg += (uint32_t)n_waves) {
             const uint32_t one[1] = {pg};
-            walk_pairs<1>(ws, lane, s_inf, s_pay, s_sigcdf, s_R, s_seen, s_cnt, one, iter0 + it, seed_lo, seed_hi, my_pairs, anc, ls, s_one);
+            walk_pairs<1>(env, lane, one, iter0 + it, seed_lo, seed_hi, my_pairs);
         }
         __syncthreads();
         for (int r = tid; r < I; r += blockDim.x) {  // strategy_sum += count * sigma(frozen)
@@ -1011,7 +1011,7 @@ k_mccfr_replay(const uint16_t *__restrict__ g_infoset, const int8_t *__restrict_
 // ---------------------------------------------------------------------------------------------------------------------
 
 static size_t traverse_lds_bytes(int n_infosets, int waves) {
-    size_t b = (size_t)n_infosets * (kRow + 4) * sizeof(double);  // sigma|threshold rows, delta table
+    size_t b = ((size_t)(n_infosets + 1) * kRow + (size_t)n_infosets * 4) * sizeof(double);  // sigma|threshold rows (+ the identity row), delta table
     b += (size_t)waves * 2 * sizeof(WaveScratch);              // per-wavefront records, two pairs in flight
     b += (((size_t)n_infosets * 4 + 15) & ~(size_t)15);        // visit counts
     b += 1656 * 2 + 576;                                       // node -> infoset, leaf payoffs
@@ -1022,8 +1022,8 @@ static size_t traverse_lds_bytes(int n_infosets, int waves) {
 // the context's lane table (k_lane_table), built on its stream before the first launch that reads it
 static int32_t ensure_lane_table(scopa_ctx *ctx) {
     if (ctx->d_lane_tab) return SCOPA_OK;
-    SC_HIP(ctx, hipMalloc(&ctx->d_lane_tab, (size_t)kLaneWords * 64 * sizeof(uint32_t)));
-    hipLaunchKernelGGL(k_lane_table, dim3(1), dim3(64), 0, ctx->stream, ctx->d_lane_tab);
+    SC_HIP(ctx, hipMalloc(&ctx->d_lane_tab, (size_t)kLaneSlotVecs * 64 * sizeof(uint4)));
+    hipLaunchKernelGGL(k_lane_table, dim3(1), dim3(64), 0, ctx->stream, (uint4 *)ctx->d_lane_tab);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -1032,12 +1032,28 @@ static int32_t ensure_lane_table(scopa_ctx *ctx) {
 // adds its deltas into the context's group tables (all-zero whenever no launch's result is pending).
 struct TraverseGeom { int threads; size_t lds; uint32_t grid; };
 
+// First-visit marks (d_visit: which keys the reference's dict would hold, mc_cfr.py:32-35) only ever go from 0 to non-zero, and once every infoset
+// of the deal has one a traversal launch has nothing left to record: its walks then skip the `seen` flags and its epilogue the d_visit scan.  The
+// marks are counted on the host -- one 6.6 KB read-back, a stream synchronisation -- at most every 16th launch, and only until they are complete.
+static int32_t refresh_all_seen(scopa_ctx *ctx, bool now) {
+    if (ctx->mccfr_all_seen) return SCOPA_OK;
+    if (!now && ++ctx->mccfr_seen_wait < 16u) return SCOPA_OK;
+    ctx->mccfr_seen_wait = 0;
+    uint32_t h[kDecision];
+    SC_HIP(ctx, hipMemcpyAsync(h, ctx->d_visit, (size_t)ctx->n_infosets * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    bool all = true;
+    for (int r = 0; r < ctx->n_infosets; r++) all = all && h[r] != 0u;
+    ctx->mccfr_all_seen = all;
+    return SCOPA_OK;
+}
+
 // everything a traversal launch needs that is not a launch: the kernel's LDS cap, the lane table, current sigma | threshold rows
 static int32_t prepare_traverse(scopa_ctx *ctx, uint32_t nb, TraverseGeom *g) {
-    // 16 wavefronts per workgroup when the tables leave room for 16 scratch areas (<= ~1430 infosets), fewer for deals
-    // with more infosets (the tables alone fit up to 1653, the maximum)
+    // 16 wavefronts per workgroup when the tables leave room for 16 x 2 scratch areas (<= ~960 infosets), fewer for deals
+    // with more infosets, down to ONE at the maximum of 1653 (85 bytes per infoset + 23 KB must fit the 160 KB)
     int waves = 16;
-    while (waves > 2 && traverse_lds_bytes(ctx->n_infosets, waves) + kStaticLds > (size_t)ctx->lds_limit) waves -= 2;
+    while (waves > 1 && traverse_lds_bytes(ctx->n_infosets, waves) + kStaticLds > (size_t)ctx->lds_limit) waves = waves > 2 ? waves - 2 : 1;
     g->threads = waves * 64;
     g->lds = traverse_lds_bytes(ctx->n_infosets, waves);
     SC_REQUIRE(ctx, g->lds + kStaticLds <= (size_t)ctx->lds_limit, SCOPA_ELIMIT, "mccfr traverse: infoset tables do not fit in LDS");
@@ -1047,6 +1063,7 @@ static int32_t prepare_traverse(scopa_ctx *ctx, uint32_t nb, TraverseGeom *g) {
     SC_REQUIRE(ctx, g->grid <= 1024u, SCOPA_ELIMIT, "mccfr traverse: more than 1024 compute units");
     static_assert(kClockStride >= 4 * 512, "clock sample stride");
     if (int32_t rc = ensure_lane_table(ctx)) return rc;
+    if (int32_t rc = refresh_all_seen(ctx, false)) return rc;
     if (!ctx->sigcdf_valid) {  // tables were changed by another entry point since the last apply
         hipLaunchKernelGGL(k_mccfr_prepare, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
@@ -1071,11 +1088,13 @@ static int32_t launch_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, 
     if (sampled)
         hipExtLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ev0, ev1, 0, ctx->d_infoset, ctx->d_payoff,
                               ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)nullptr);
+                              iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)nullptr,
+                              ctx->mccfr_all_seen ? 0u : 1u);
     else
         hipLaunchKernelGGL(k_mccfr_traverse, dim3(grid), dim3(threads), lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                            ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)nullptr);
+                           iteration, b0, nb, ctx->d_counters + 8, ctx->d_visit, clock, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)nullptr,
+                           ctx->mccfr_all_seen ? 0u : 1u);
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;
 }
@@ -1089,8 +1108,9 @@ void scopa::mccfr_graphs_clear(scopa_ctx *ctx) {
 }
 
 static int32_t graph_for(scopa_ctx *ctx, uint32_t batch, uint32_t k, hipGraphExec_t *out) {
+    const uint32_t track = ctx->mccfr_all_seen ? 0u : 1u;   // a launch argument of the captured traversals: part of the key
     for (auto &e : ctx->mccfr_graphs)
-        if (e.batch == batch && e.k == k) { *out = (hipGraphExec_t)e.exec; return SCOPA_OK; }
+        if (e.batch == batch && e.k == k && e.track == track) { *out = (hipGraphExec_t)e.exec; return SCOPA_OK; }
     TraverseGeom g;
     if (int32_t rc = prepare_traverse(ctx, batch, &g)) return rc;
     uint32_t *d_iter = reinterpret_cast<uint32_t *>(ctx->d_meta + 2);
@@ -1099,7 +1119,7 @@ static int32_t graph_for(scopa_ctx *ctx, uint32_t batch, uint32_t k, hipGraphExe
     for (uint32_t i = 0; i < k; i++) {
         hipLaunchKernelGGL(k_mccfr_traverse, dim3(g.grid), dim3(g.threads), g.lds, ctx->stream, ctx->d_infoset, ctx->d_payoff,
                            ctx->d_sigcdf, ctx->d_groups, ctx->n_infosets, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32),
-                           0u, 0u, batch, ctx->d_counters + 8, ctx->d_visit, (unsigned long long *)nullptr, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)d_iter);
+                           0u, 0u, batch, ctx->d_counters + 8, ctx->d_visit, (unsigned long long *)nullptr, (const uint4 *)ctx->d_lane_tab, (const uint32_t *)d_iter, track);
         hipLaunchKernelGGL(k_mccfr_apply_groups, dim3((ctx->n_infosets * kApplyLanes + kApplyThreads - 1) / kApplyThreads), dim3(kApplyThreads), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf, d_iter);
     }
@@ -1110,7 +1130,7 @@ static int32_t graph_for(scopa_ctx *ctx, uint32_t batch, uint32_t k, hipGraphExe
     (void)hipGraphDestroy(graph);
     if (e_inst != hipSuccess) return scopa::fail(ctx, SCOPA_EHIP, "mccfr graph: instantiate", e_inst);
     if (ctx->mccfr_graphs.size() >= 16) { (void)hipGraphExecDestroy((hipGraphExec_t)ctx->mccfr_graphs.front().exec); ctx->mccfr_graphs.erase(ctx->mccfr_graphs.begin()); }
-    ctx->mccfr_graphs.push_back({batch, k, (void *)exec});
+    ctx->mccfr_graphs.push_back({batch, k, track, (void *)exec});
     *out = exec;
     return SCOPA_OK;
 }
@@ -1121,7 +1141,7 @@ int32_t launch_mccfr_multi(scopa_ctx *ctx, int n_deals, int max_infosets, const 
                            unsigned long long *d_counters, uint64_t seed, uint32_t iter0, uint32_t n_iters, uint32_t batch) {
     int waves = 16;
     auto need = [&](int w) {
-        size_t b = (size_t)max_infosets * (kRow + 4) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
+        size_t b = ((size_t)(max_infosets + 1) * kRow + (size_t)max_infosets * 4) * sizeof(double) + (size_t)w * sizeof(WaveScratch);
         b += (((size_t)max_infosets * 4 + 15) & ~(size_t)15) + 1656 * 2 + 576 + (size_t)max_infosets;
         return (b + 15) & ~(size_t)15;
     };
@@ -1236,6 +1256,7 @@ int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
         SC_HIP(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(ctx->d_meta + 2), (int)ctx->iteration, 1, ctx->stream));
         for (uint32_t left = n_iters; left > 0;) {
             const uint32_t k = left >= 64u ? 64u : left;
+            if (int32_t rc = refresh_all_seen(ctx, true)) return rc;   // between chunks, until the marks are complete
             hipGraphExec_t exec = nullptr;
             if (int32_t rc = graph_for(ctx, batch, k, &exec)) return rc;
             SC_HIP(ctx, hipGraphLaunch(exec, ctx->stream));

@@ -202,6 +202,8 @@ int32_t scopa_tables_reset(scopa_ctx *ctx) {
     SC_HIP(ctx, hipMemsetAsync(ctx->d_delta, 0, (size_t)(ctx->d_delta == ctx->d_delta_own ? kDecision : ctx->n_infosets) * 5 * sizeof(double), ctx->stream));
     ctx->iteration = 0;
     ctx->sigcdf_valid = false;
+    ctx->mccfr_all_seen = false;
+    ctx->mccfr_seen_wait = 0;
     return SCOPA_OK;
 }
 

@@ -416,9 +416,9 @@ def test_mccfr_graph_mode_replays_the_same_iterations(ctx, sl, oracle):
 
 
 def test_mccfr_narrow_workgroups_give_the_same_deltas(ctx, sl, oracle):
-    """Deals with very many infosets leave room for fewer than 16 wavefronts per traversal workgroup (8 or fewer above ~1430
-    infosets: narrower than the 576 threads that stage the lane table in one step).  The test hook scopa_debug_lds_limit makes the
-    seed-42 deal run with 8, 4 and 2 wavefronts per workgroup: visit counts exact, deltas as the 16-wavefront launch's and the
+    """Deals with very many infosets leave room for fewer than 16 wavefronts per traversal workgroup (narrower than the 960 threads
+    that stage the lane table in one step; ONE wavefront at the maximum of 1653 infosets).  The test hook scopa_debug_lds_limit makes
+    the seed-42 deal run with 8, 4, 2 and 1 wavefronts per workgroup: visit counts exact, deltas as the 16-wavefront launch's and the
     oracle's."""
     t = oracle.Tree(seed=42)
     ctx.set_deal(sl.deal_py_seed(42))
@@ -428,7 +428,7 @@ def test_mccfr_narrow_workgroups_give_the_same_deltas(ctx, sl, oracle):
     ctx.mccfr_seed(0x5C09A)
     dR, dS, dv, tv = t.mccfr_batched_delta(R, 0x5C09A, 4, 100, 3000)
     try:
-        for limit in (0, 100 * 1024, 88 * 1024, 82 * 1024):       # 16, 8, 4, 2 wavefronts per workgroup at 738 infosets
+        for limit in (0, 112 * 1024, 98 * 1024, 90 * 1024, 86 * 1024):   # 16, 8, 4, 2, 1 wavefronts per workgroup at 738 infosets (82 098 + 3 648 per wavefront bytes)
             ctx.debug_lds_limit(limit)
             c0 = ctx.counters()
             ctx.mccfr_delta_set(np.zeros((t.n_infosets, 5)))
