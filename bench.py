@@ -576,6 +576,7 @@ def main():
     launches, kernel_ms = ctx.prof_read()
     dev_n1, dev_ms1 = ctx.prof_device()
     phases = ctx.prof_phases()
+    spread = ctx.prof_spread()
     ctx.prof_enable(0)
     d1, _ = ctx.counters()
     med = sorted(times)[len(times) // 2]
@@ -659,6 +660,7 @@ def main():
             "kernel": "k_mccfr_traverse", "kernel_avg_us": kern_us, "launches_timed": launches,
             "kernel_avg_us_device_clock": 1e3 * dev_ms1 / max(dev_n1, 1), "launches_device_clock": dev_n1,
             "workgroup_phase_us": {"prologue": phases[0], "walks": phases[1], "epilogue": phases[2]},
+            "workgroup_spread_us": {"mean_start_behind_first": spread[0], "last_start_behind_first": spread[1], "longest_workgroup": spread[2]},
             "bounds": bounds,
             "bound_note": "the kernel's working set (frozen strategy rows, delta table, tree maps) is LDS-resident by design, so the resources that can "
                           "bound it are VALU issue and the LDS array; `bound` is whichever of the candidate ceilings the kernel sits closest to.  Per-pair "

@@ -387,6 +387,9 @@ int32_t scopa_prof_read(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
 int32_t scopa_prof_device(scopa_ctx *ctx, int64_t *launches, double *kernel_ms);
 /* after scopa_prof_device: mean microseconds a workgroup of the sampled launches spent in (prologue, traversal walks, epilogue) */
 int32_t scopa_prof_phases(scopa_ctx *ctx, double out_us[3]);
+/* beside the phases: { mean start of a workgroup behind the first workgroup of its launch, the LAST workgroup's start behind the first, the longest
+ * workgroup of a launch } in microseconds, means over the sampled launches -- what a launch's time is made of beside its workgroups' own phases */
+int32_t scopa_prof_spread(scopa_ctx *ctx, double out_us[3]);
 
 #ifdef __cplusplus
 }

@@ -34,7 +34,7 @@ SYMBOLS = [
     "scopa_full_step_batch", "scopa_full_step_batch_host", "scopa_full_random_playouts",
     "scopa_team_state_init", "scopa_team_state_step", "scopa_team_state_legal", "scopa_team_state_rewards_x2", "scopa_team_state_infoset_string",
     "scopa_team_step_batch", "scopa_team_step_batch_host", "scopa_team_random_playouts",
-    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_set_form", "scopa_p2p_set_budget", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device", "scopa_prof_phases",
+    "scopa_mccfr_iterate_sharded", "scopa_p2p_create", "scopa_p2p_connect", "scopa_p2p_allreduce_delta", "scopa_p2p_set_form", "scopa_p2p_set_budget", "scopa_p2p_status", "scopa_p2p_destroy", "scopa_exploitability", "scopa_counters", "scopa_prof_enable", "scopa_prof_read", "scopa_prof_device", "scopa_prof_phases", "scopa_prof_spread",
 ]
 
 
@@ -187,8 +187,14 @@ def lib():
         "scopa_prof_read": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
         "scopa_prof_device": (i32, [vp, C.POINTER(i64), C.POINTER(C.c_double)]),
         "scopa_prof_phases": (i32, [vp, C.POINTER(C.c_double * 3)]),
+        "scopa_prof_spread": (i32, [vp, C.POINTER(C.c_double * 3)]),
     }
+    # A/B tooling only (tests/tools/ab_time.sh): a variant library built from an OLDER revision, named through SCOPA_HIP_LIBRARY, may lack entry points
+    # added since -- with SCOPA_AB_OLD_LIBRARY=1 those are left unbound (calling one raises AttributeError); the product's own library must export them all
+    lenient = bool(os.environ.get("SCOPA_HIP_LIBRARY")) and os.environ.get("SCOPA_AB_OLD_LIBRARY") == "1"
     for name, (res, args) in sig.items():
+        if lenient and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         fn.restype, fn.argtypes = res, args
     if L.scopa_abi_version() != 1:
@@ -556,6 +562,12 @@ class Context:
         out = (C.c_double * 3)()
         self._ck(self._L.scopa_prof_phases(self._h, C.byref(out)), "scopa_prof_phases")
         return tuple(out)
+
+    def prof_spread(self):
+        """(mean workgroup start behind the launch's first, last workgroup's start behind the first, longest workgroup) in us; after prof_device()."""
+        out = (C.c_double * 3)()
+        self._ck(self._L.scopa_prof_spread(self._h, C.byref(out)), "scopa_prof_spread")
+        return [out[0], out[1], out[2]]
 
     def prof_device(self):
         """-> (traversal launches, their summed milliseconds by the kernel's own 100 MHz clock) since the context was created"""

@@ -53,6 +53,7 @@ struct scopa_ctx {
     unsigned long long *d_clock = nullptr;   // [2048 sampled launches][512 workgroups][4] phase stamps on the 100 MHz device clock (allocated by scopa_prof_enable)
     uint16_t clock_grid[2048] = {0};         // workgroups of each sampled launch
     double prof_phase_us[3] = {0.0, 0.0, 0.0};   // mean (prologue, walks, epilogue) per workgroup of the samples last folded by scopa_prof_device
+    double prof_spread_us[3] = {0.0, 0.0, 0.0};   // scopa_prof_spread: workgroup start offsets and the longest workgroup of the sampled launches
     size_t scratch_bytes = 0;
 
     unsigned long long *d_counters = nullptr;  // [0] decision visits, [1] terminal visits, [2] aux

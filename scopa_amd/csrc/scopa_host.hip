@@ -357,19 +357,29 @@ int32_t scopa_prof_device(scopa_ctx *ctx, int64_t *launches, double *kernel_ms) 
     if (n > 0) {
         std::vector<unsigned long long> h((size_t)n * scopa::kClockStride);
         SC_HIP(ctx, hipMemcpy(h.data(), ctx->d_clock, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        double ph[3] = {0.0, 0.0, 0.0};
-        long long wgs = 0;
+        double ph[3] = {0.0, 0.0, 0.0}, sp[4] = {0.0, 0.0, 0.0, 0.0};
+        long long wgs = 0, launches_seen = 0;
         for (int64_t s = 0; s < n; s++) {
-            unsigned long long t0 = ~0ull, t1 = 0ull;
+            unsigned long long t0 = ~0ull, t1 = 0ull, late = 0ull, longest = 0ull;
             for (int w = 0; w < ctx->clock_grid[s]; w++) {
                 const unsigned long long *q = &h[(size_t)s * scopa::kClockStride + 4 * w];
                 t0 = q[0] < t0 ? q[0] : t0; t1 = q[3] > t1 ? q[3] : t1;
                 for (int k = 0; k < 3; k++) ph[k] += (double)(q[k + 1] - q[k]);
                 wgs++;
             }
+            for (int w = 0; w < ctx->clock_grid[s]; w++) {     // where a launch's time goes beside its workgroups' own phases: how late they start, how long the longest runs
+                const unsigned long long *q = &h[(size_t)s * scopa::kClockStride + 4 * w];
+                sp[0] += (double)(q[0] - t0);
+                late = q[0] - t0 > late ? q[0] - t0 : late;
+                longest = q[3] - q[0] > longest ? q[3] - q[0] : longest;
+            }
+            if (ctx->clock_grid[s]) { sp[1] += (double)late; sp[2] += (double)longest; launches_seen++; }
             if (t1 > t0) ticks += t1 - t0;
         }
         for (int k = 0; k < 3; k++) ctx->prof_phase_us[k] = wgs ? ph[k] * 1e-2 / (double)wgs : 0.0;   // 10 ns ticks -> us, mean over workgroups
+        ctx->prof_spread_us[0] = wgs ? sp[0] * 1e-2 / (double)wgs : 0.0;                                // mean start of a workgroup behind its launch's first
+        ctx->prof_spread_us[1] = launches_seen ? sp[1] * 1e-2 / (double)launches_seen : 0.0;            // the last workgroup's start behind the first, mean over launches
+        ctx->prof_spread_us[2] = launches_seen ? sp[2] * 1e-2 / (double)launches_seen : 0.0;            // the longest workgroup of a launch, mean over launches
     }
     if (launches) *launches = n;
     if (kernel_ms) *kernel_ms = (double)ticks * 1e-5;   // 10 ns ticks
@@ -380,6 +390,14 @@ int32_t scopa_prof_phases(scopa_ctx *ctx, double out_us[3]) {
     // mean over the sampled launches' workgroups of (prologue, walks, epilogue) on the device clock; call after scopa_prof_device
     if (!ctx || !out_us) return SCOPA_EINVAL;
     for (int k = 0; k < 3; k++) out_us[k] = ctx->prof_phase_us[k];
+    return SCOPA_OK;
+}
+
+int32_t scopa_prof_spread(scopa_ctx *ctx, double out_us[3]) {
+    // beside the phases: mean start of a workgroup behind the first of its launch | the LAST workgroup's start behind the first | the longest workgroup of a
+    // launch (both means over the sampled launches); call after scopa_prof_device
+    if (!ctx || !out_us) return SCOPA_EINVAL;
+    for (int k = 0; k < 3; k++) out_us[k] = ctx->prof_spread_us[k];
     return SCOPA_OK;
 }
 
