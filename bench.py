@@ -573,6 +573,8 @@ def main():
         fence()
         own_times.append(time.perf_counter() - t0)             # this rank's own clock around the region ...
         times.append(all_max(own_times[-1]))                    # ... and the maximum over ranks, which is what counts
+    if use_dist:
+        drv.final_check()                                      # light exchange form: the replicas' tables are compared before anything is reported (no-op otherwise)
     launches, kernel_ms = ctx.prof_read()
     dev_n1, dev_ms1 = ctx.prof_device()
     phases = ctx.prof_phases()

@@ -177,6 +177,8 @@ class AdvantageNetwork:
             raise ValueError("train_backend must be 'torch' or 'hip'")
         self.train_backend = train_backend
         self._ctx = None             # the solver's library context (set by DeepCFR): the hip backend launches on its stream
+        self._ctx_stream = None      # ... and that stream as a torch stream: _train_hip orders itself against the caller's current stream through it
+        self._warned_torch_path = False
         self._hip = None             # hip backend: (moment buffer [2][13776], running loss [1]) and the step count
         self._hip_step = 0
         self._sample_cache = None    # ((rows in memory, batch, epochs), device tensor of the index batches): see _sample_rows
@@ -251,8 +253,16 @@ class AdvantageNetwork:
         self._rng.seed(42)
         self._rng.shuffle(list(range(16)))
         self._weights_changed()
-        if self.train_backend == "hip" and self.grad_sync is None and batch_size % 16 == 0 and batch_size >= 16:
-            return self._train_hip(n, batch_size, epochs, defer)
+        if self.train_backend == "hip":
+            if self.grad_sync is None and batch_size % 16 == 0 and batch_size >= 16:
+                return self._train_hip(n, batch_size, epochs, defer)
+            if not self._warned_torch_path:
+                # the two paths keep SEPARATE Adam states (the hand-written step's moment buffer and step count / torch.optim.Adam's): a run that mixes them
+                # continues each from where that path left off -- say so once instead of doing it silently
+                import warnings
+                warnings.warn("AdvantageNetwork(train_backend='hip'): this train() call takes the PyTorch optimiser (ragged batch of %d rows or gradient all-reduce); "
+                              "its Adam state is separate from the hand-written step's" % batch_size, RuntimeWarning, stacklevel=2)
+                self._warned_torch_path = True
         if self.use_graph and self.grad_sync is None:
             return self._train_graphed(n, batch_size, epochs, defer)
         rows_all = self._sample_rows(n, batch_size, epochs)
@@ -269,6 +279,23 @@ class AdvantageNetwork:
         params = self.param_list()
         if any(p.dtype != torch.float32 or not p.is_contiguous() for p in params):
             raise RuntimeError("train_backend='hip' needs contiguous float32 parameters")
+        grp = self.optimizer.param_groups[0]   # the kernel implements torch.optim.Adam's defaults: anything else must not be dropped silently
+        if tuple(grp.get("betas", (0.9, 0.999))) != (0.9, 0.999) or grp.get("eps", 1e-8) != 1e-8 or grp.get("weight_decay", 0) != 0 or grp.get("amsgrad", False) \
+                or grp.get("maximize", False):
+            raise RuntimeError("train_backend='hip' implements Adam(betas=(0.9, 0.999), eps=1e-8, weight_decay=0): other settings need train_backend='torch'")
+        # Stream contract: the launches go to the solver's stream (the library context's).  Called from another current stream, order this call behind
+        # what that stream has queued (the rows a traversal wrote, a zeroed loss) and the caller's later work behind this call's launches.
+        cur = torch.cuda.current_stream(self.device) if self._ctx_stream is not None else None
+        foreign = cur is not None and cur.cuda_stream != self._ctx_stream.cuda_stream
+        if foreign:
+            self._ctx_stream.wait_stream(cur)
+            with torch.cuda.stream(self._ctx_stream):
+                out = self._train_hip_on_stream(params, n, batch_size, epochs, defer)
+            cur.wait_stream(self._ctx_stream)
+            return out
+        return self._train_hip_on_stream(params, n, batch_size, epochs, defer)
+
+    def _train_hip_on_stream(self, params, n, batch_size, epochs, defer):
         if self._hip is None:
             self._hip = (torch.zeros(2 * sum(p.numel() for p in params), dtype=torch.float32, device=self.device),
                          torch.zeros(1, dtype=torch.float32, device=self.device))
@@ -439,7 +466,7 @@ class StrategyBuffer:
             return masks / masks.sum(dim=-1, keepdim=True)
         total = float(sum(self.weights))
         with torch.no_grad():
-            if feats.shape[0] <= 4096:                       # all snapshots at once: [S, N, .] activations
+            if len(self._slots) * feats.shape[0] <= 65536:   # all snapshots at once: [S, N, 128] activations (S x N rows: 32 MB at the gate; 100 snapshots x 4096 rows were 0.5 GB per ply)
                 if self._gathered is None:                   # once per buffer state (an evaluation asks eight times, a ply each)
                     idx = torch.tensor(self._slots, device=feats.device)
                     self._gathered = (tuple(t[idx] for t in self._store), torch.tensor(self.weights, dtype=torch.float32, device=feats.device) / total)
@@ -502,7 +529,7 @@ class DeepCFR:
             self.advantage_nets = [AdvantageNetwork(self.input_dim, 16, device, memory_size=memory_size, use_graph=graph_training, train_backend=train_backend)
                                    for _ in range(num_players)]
             for a in self.advantage_nets:
-                a._ctx = self._engine.ctx
+                a._ctx, a._ctx_stream = self._engine.ctx, self._stream
         self.strategy_buffers = [StrategyBuffer() for _ in range(num_players)]
         self.training_history = {"losses": [[] for _ in range(num_players)], "values": [[] for _ in range(num_players)],
                                  "buffer_sizes": [[] for _ in range(num_players)], "eval_rewards": [], "eval_scopas": []}

@@ -144,6 +144,12 @@ inline int32_t fail(scopa_ctx *ctx, int32_t code, const char *what, hipError_t e
 
 int32_t ensure_scratch(scopa_ctx *ctx, size_t bytes);
 
+// roctx ranges around the solver's phases (traverse / exchange + apply / train), for rocprofv3 --marker-trace timelines: on only with SCOPA_ROCTX=1 in the
+// environment (resolved once, from librocprofiler-sdk-roctx.so / libroctx64.so by dlopen: no link-time dependency, nothing in the loop otherwise)
+void range_push(const char *name);
+void range_pop();
+struct Range { explicit Range(const char *n) { range_push(n); } ~Range() { range_pop(); } };
+
 // hipFuncAttributeMaxDynamicSharedMemorySize is a per-DEVICE property of a kernel, so the "already raised" flag lives in the
 // context (one context = one device), not in a process-wide static: a second context on another device raises it again.
 enum LdsAttrKernel : uint32_t { kLdsTraverse = 1u, kLdsReplay = 8u, kLdsCfrExact = 16u, kLdsCfrSched = 512u, kLdsExploit = 32u, kLdsCfrSync = 64u, kLdsSdcfr = 128u, kLdsMulti = 256u, kLdsSdcfr2 = 1024u, kLdsSdcfr3 = 2048u, kLdsSdcfr4 = 4096u, kLdsSdcfr5 = 8192u, kLdsSdcfr6 = 16384u, kLdsSdcfr7 = 32768u, kLdsSdPolicy = 65536u, kLdsSdWalk2 = 131072u, kLdsSdWalk4 = 262144u, kLdsSdWalk8 = 524288u, kLdsSdWalk1 = 1048576u, kLdsSdWalk8b = 1u << 21, kLdsSdWalk4b = 1u << 22, kLdsSdWalk2b = 1u << 23, kLdsSdWalk1b = 1u << 24 };

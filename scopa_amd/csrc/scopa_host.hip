@@ -57,6 +57,34 @@ bool prof_events(scopa_ctx *ctx, hipEvent_t *start, hipEvent_t *stop) {
 
 }  // namespace scopa
 
+#include <dlfcn.h>
+namespace scopa {
+namespace {
+int (*g_roctx_push)(const char *) = nullptr;
+int (*g_roctx_pop)() = nullptr;
+int g_roctx_state = 0;   // 0 = not looked up yet, 1 = on, -1 = off
+void roctx_resolve() {
+    g_roctx_state = -1;
+    const char *on = getenv("SCOPA_ROCTX");
+    if (!on || on[0] != '1') return;
+    for (const char *lib : {"librocprofiler-sdk-roctx.so", "libroctx64.so"}) {
+        void *h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+        if (!h) continue;
+        g_roctx_push = reinterpret_cast<int (*)(const char *)>(dlsym(h, "roctxRangePushA"));
+        g_roctx_pop = reinterpret_cast<int (*)()>(dlsym(h, "roctxRangePop"));
+        if (g_roctx_push && g_roctx_pop) { g_roctx_state = 1; return; }
+    }
+}
+}  // namespace
+void range_push(const char *name) {
+    if (g_roctx_state == 0) roctx_resolve();
+    if (g_roctx_state == 1) (void)g_roctx_push(name);
+}
+void range_pop() {
+    if (g_roctx_state == 1) (void)g_roctx_pop();
+}
+}  // namespace scopa
+
 extern "C" {
 
 int32_t scopa_abi_version(void) { return SCOPA_ABI_VERSION; }
@@ -391,6 +419,23 @@ int32_t scopa_prof_phases(scopa_ctx *ctx, double out_us[3]) {
     if (!ctx || !out_us) return SCOPA_EINVAL;
     for (int k = 0; k < 3; k++) out_us[k] = ctx->prof_phase_us[k];
     return SCOPA_OK;
+}
+
+// development (tests/tools/wg_starts.py; not part of include/scopa.h): the raw per-workgroup stamps (start | prologue done | walks done | end, 10 ns ticks) of the
+// last `n` sampled launches, [n][grid][4]; returns the grid of those launches or a negative status
+int32_t scopa_debug_clock_dump(scopa_ctx *ctx, unsigned long long *out, int32_t n, int32_t max_grid) {
+    if (!ctx || !out || n <= 0 || !ctx->d_clock) return SCOPA_EINVAL;
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int64_t have = ctx->prof_launches < scopa::kClockSamples ? ctx->prof_launches : scopa::kClockSamples;
+    if (have < n) return SCOPA_ESTATE;
+    int grid = 0;
+    for (int32_t s = 0; s < n; s++) {
+        const int64_t slot = (ctx->prof_launches - 1 - s) % scopa::kClockSamples;
+        grid = ctx->clock_grid[slot];
+        if (grid <= 0 || grid > max_grid) return SCOPA_ELIMIT;
+        SC_HIP(ctx, hipMemcpy(out + (size_t)s * max_grid * 4, ctx->d_clock + (size_t)slot * scopa::kClockStride, (size_t)grid * 4 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    }
+    return grid;
 }
 
 int32_t scopa_prof_spread(scopa_ctx *ctx, double out_us[3]) {

@@ -1179,6 +1179,7 @@ int32_t scopa_mccfr_traverse(scopa_ctx *ctx, uint32_t iteration, uint32_t b0, ui
     SC_REQUIRE(ctx, nb <= (1u << 30), SCOPA_EINVAL, "scopa_mccfr_traverse: batch too large");
     if (nb == 0) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
+    scopa::Range r("scopa mccfr traverse (split path)");
     const int32_t rc = launch_traverse(ctx, iteration, b0, nb);
     if (rc != SCOPA_OK) return rc;
     hipLaunchKernelGGL(k_mccfr_fold, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_groups, ctx->d_delta, ctx->n_infosets);
@@ -1230,6 +1231,7 @@ int32_t scopa_mccfr_apply(scopa_ctx *ctx) {
     if (!ctx) return SCOPA_EINVAL;
     SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_mccfr_apply: no deal set");
     SC_HIP(ctx, hipSetDevice(ctx->device));
+    scopa::Range r("scopa mccfr apply (split path)");
     if (!ctx->sigcdf_valid) {  // no traversal since another entry point changed the tables: the rows the apply reads sigma from are stale
         hipLaunchKernelGGL(k_mccfr_prepare, dim3((ctx->n_infosets + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_sigcdf, ctx->n_infosets);
@@ -1274,8 +1276,10 @@ int32_t scopa_mccfr_iterate(scopa_ctx *ctx, uint32_t batch, uint32_t n_iters) {
         return SCOPA_OK;
     }
     for (uint32_t it = 0; it < n_iters; it++) {
-        const int32_t rc = launch_traverse(ctx, ctx->iteration, 0, batch);
+        int32_t rc;
+        { scopa::Range r("scopa mccfr traverse"); rc = launch_traverse(ctx, ctx->iteration, 0, batch); }
         if (rc != SCOPA_OK) return rc;
+        scopa::Range r("scopa mccfr apply");
         hipLaunchKernelGGL(k_mccfr_apply_groups, dim3((ctx->n_infosets * kApplyLanes + kApplyThreads - 1) / kApplyThreads), dim3(kApplyThreads), 0, ctx->stream, ctx->d_key,
                            ctx->d_regret, ctx->d_strat, ctx->d_groups, ctx->n_infosets, ctx->d_sigcdf, (uint32_t *)nullptr);
         SC_HIP(ctx, hipGetLastError());
@@ -1302,8 +1306,10 @@ int32_t scopa_mccfr_iterate_sharded(scopa_ctx *ctx, uint32_t b0, uint32_t nb, ui
     for (uint32_t it = 0; it < n_iters; it++) {
         scopa::P2PArgs xa{};
         SC_REQUIRE(ctx, scopa::p2p_next_args(ctx, &xa), SCOPA_ESTATE, "mccfr sharded iteration: peer exchange not connected");
-        const int32_t rc = launch_traverse(ctx, ctx->iteration, b0, nb);
+        int32_t rc;
+        { scopa::Range r("scopa mccfr traverse"); rc = launch_traverse(ctx, ctx->iteration, b0, nb); }
         if (rc != SCOPA_OK) return rc;
+        scopa::Range r("scopa mccfr exchange + apply");
         hipLaunchKernelGGL(k_mccfr_exchange_apply, dim3((ctx->n_infosets + 3) / 4), dim3(64), 0, ctx->stream, xa, ctx->d_groups, ctx->d_key,
                            ctx->d_regret, ctx->d_strat, ctx->d_sigcdf, ctx->n_infosets);
         SC_HIP(ctx, hipGetLastError());

@@ -20,6 +20,9 @@
 // (scopa_amd/distributed.py validates this exchange against it before using it).
 #include <string.h>
 
+#include <cstdio>
+#include <cstdlib>
+
 #include "scopa_ctx.h"
 #include "scopa_p2p.h"
 
@@ -133,7 +136,15 @@ int32_t scopa_p2p_connect(scopa_ctx *ctx, const uint8_t *handles) {
         memcpy(&h, handles + (size_t)r * 64, 64);
         void *ptr = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&ptr, h, hipIpcMemLazyEnablePeerAccess);
-        if (e != hipSuccess) return fail(ctx, SCOPA_EHIP, "scopa_p2p_connect: hipIpcOpenMemHandle", e);
+        if (e != hipSuccess) {   // first contact with another device's memory happens unattended (the driver's multi-GPU run): name the call and the pair
+            char what[192];
+            int peer_access = -1;
+            (void)hipGetLastError();
+            snprintf(what, sizeof what, "scopa_p2p_connect: hipIpcOpenMemHandle(rank %d's inbox) on rank %d / device %d (HSA_ENABLE_IPC_MODE_LEGACY=%s; same-process peer access to device %d: %s)",
+                     r, p->rank, ctx->device, getenv("HSA_ENABLE_IPC_MODE_LEGACY") ? getenv("HSA_ENABLE_IPC_MODE_LEGACY") : "unset", r,
+                     (r < 64 && hipDeviceCanAccessPeer(&peer_access, ctx->device, r) == hipSuccess) ? (peer_access ? "possible" : "not possible") : "unknown");
+            return fail(ctx, SCOPA_EHIP, what, e);
+        }
         p->peer[r] = ptr; p->opened[r] = true;
     }
     if (!p->d_inbox_tab) SC_HIP(ctx, hipMalloc(reinterpret_cast<void **>(&p->d_inbox_tab), kP2PMaxWorld * sizeof(double *)));

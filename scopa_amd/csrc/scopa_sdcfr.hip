@@ -1307,6 +1307,7 @@ int32_t scopa_sdcfr_traverse_fused(scopa_ctx *ctx, int32_t traverser, int32_t ba
                "scopa_sdcfr_traverse_fused: memory rows are stored 8 / 16 bytes at a time: d_mem_feat must be 8-byte, d_mem_regret / d_mem_mask 16-byte aligned");
     if (!batch) return SCOPA_OK;
     SC_HIP(ctx, hipSetDevice(ctx->device));
+    scopa::Range range_("scopa sdcfr traverse");
     if (!ctx->d_sdnode) SC_HIP(ctx, hipMalloc(&ctx->d_sdnode, sizeof(uint2) * kDecision));
     if (!ctx->sdnode_valid) {
         hipLaunchKernelGGL(k_sdcfr_nodeinfo, dim3((kDecision + 255) / 256), dim3(256), 0, ctx->stream, ctx->d_states, (uint2 *)ctx->d_sdnode);

@@ -11,6 +11,8 @@
 //   k_sdcfr_train_adam : one workgroup: sums the partials in order, 2-norm of the whole gradient, clip coefficient min(1, 1 / (norm + 1e-6)), Adam's update
 //                        (bias-corrected, eps outside the square root, as torch.optim.Adam) in place on the net's tensors and on the [2][13776] moment buffer.
 // MFMA roles (one instruction = a 16 x 16 tile over 4 K values): A lane l = A[l % 16][l / 16], B lane l = B[l / 16][l % 16], D lane l register r = D[4 (l / 16) + r][l % 16].
+#include <cmath>
+
 #include "scopa_ctx.h"
 
 using namespace scopa;
@@ -182,7 +184,7 @@ k_sdcfr_train_grad(const int64_t *__restrict__ g_rows, int n_rows, long long cap
 
 __global__ void __launch_bounds__(1024)
 k_sdcfr_train_adam(const float *__restrict__ g_partial, int n_partials, int n_rows, float *__restrict__ W1, float *__restrict__ B1, float *__restrict__ W2,
-                   float *__restrict__ B2, float *__restrict__ W3, float *__restrict__ B3, float *__restrict__ g_state /* [2][kParams] */, int step, float lr,
+                   float *__restrict__ B2, float *__restrict__ W3, float *__restrict__ B3, float *__restrict__ g_state /* [2][kParams] */, float step_size, float bc2_sqrt,
                    float beta1, float beta2, float eps, float *__restrict__ g_loss) {
     __shared__ float s_red[16];
     const int tid = threadIdx.x;
@@ -220,8 +222,6 @@ k_sdcfr_train_adam(const float *__restrict__ g_partial, int n_partials, int n_ro
     for (int k = 0; k < 16; k++) tot += s_red[k];
     const float norm = sqrtf(tot);
     const float inv = 1.0f / (norm + 1e-6f), coef = inv < 1.0f ? inv : 1.0f;   // clip_grad_norm_(max_norm = 1.0): clip_coef = max_norm / (total_norm + 1e-6), clamped to 1
-    const float bc1 = 1.0f - powf(beta1, (float)step), bc2 = 1.0f - powf(beta2, (float)step);
-    const float step_size = lr / bc1, bc2_sqrt = sqrtf(bc2);
 #pragma unroll
     for (int j = 0; j < kPer; j++) {
         const int i = tid + 1024 * j;
@@ -255,13 +255,17 @@ int32_t scopa_sdcfr_train_steps(scopa_ctx *ctx, const int64_t *d_rows, int32_t n
     SC_REQUIRE(ctx, ((uintptr_t)d_w1 & 7) == 0 && ((uintptr_t)d_w2 & 15) == 0 && ((uintptr_t)d_w3 & 15) == 0, SCOPA_EINVAL,
                "scopa_sdcfr_train_steps: the weight tensors are staged 8 / 16 bytes at a time: d_w1 must be 8-byte, d_w2 / d_w3 16-byte aligned");
     SC_HIP(ctx, hipSetDevice(ctx->device));
+    scopa::Range range_("scopa sdcfr train");
     if (!ctx->d_train_partial) SC_HIP(ctx, hipMalloc(&ctx->d_train_partial, sizeof(float) * (size_t)kMaxPartials * (kParams + 1)));
     const int n_tiles = n_rows / 16, grid = n_tiles < kMaxPartials ? n_tiles : kMaxPartials;
     for (int e = 0; e < n_steps; e++) {
         hipLaunchKernelGGL(k_sdcfr_train_grad, dim3(grid), dim3(256), 0, ctx->stream, d_rows + (size_t)e * n_rows, (int)n_rows, (long long)capacity, d_feat, d_regret, d_mask, (const float *)d_w1,
                            (const float *)d_b1, (const float *)d_w2, (const float *)d_b2, (const float *)d_w3, (const float *)d_b3, (float *)ctx->d_train_partial);
+        // torch.optim.Adam's scalars (_single_tensor_adam): bias_correction1 = 1 - beta1 ** step, step_size = lr / bias_correction1, bias_correction2_sqrt = sqrt(1 - beta2 ** step)
+        // in Python floats (float64), rounded to float32 only where they meet the tensors -- computed the same way here (in-kernel powf on float32 betas was ~1e-5 off at small steps)
+        const double step = (double)(first_step + e), bc1 = 1.0 - std::pow(0.9, step), bc2 = 1.0 - std::pow(0.999, step);
         hipLaunchKernelGGL(k_sdcfr_train_adam, dim3(1), dim3(1024), 0, ctx->stream, (const float *)ctx->d_train_partial, grid, (int)n_rows, d_w1, d_b1, d_w2, d_b2, d_w3, d_b3,
-                           d_state, (int)(first_step + e), lr, 0.9f, 0.999f, 1e-8f, d_loss);
+                           d_state, (float)((double)lr / bc1), (float)std::sqrt(bc2), 0.9f, 0.999f, 1e-8f, d_loss);
     }
     SC_HIP(ctx, hipGetLastError());
     return SCOPA_OK;

@@ -32,6 +32,7 @@ class ShardedMCCFR:
         self.fused_exchange, self.always_exchange = bool(fused_exchange), bool(always_exchange)
         self.replica_check = replica_check if replica_check is not None else getattr(engine, "replica_check", None)
         self.check_every = int(check_every)
+        self._since_check = 0   # iterations through the light exchange form since the replicas were last compared -- carried ACROSS run() calls
 
     def iteration(self, batch_total):
         b0, nb = shard_range(batch_total, self.rank, self.world)
@@ -47,17 +48,31 @@ class ShardedMCCFR:
     def run(self, batch_total, n_iters):
         if self.fused_exchange:
             b0, nb = shard_range(batch_total, self.rank, self.world)
-            guarded = self.replica_check is not None and getattr(self.engine, "exchange_form", None) == "light" and self.check_every > 0
+            guarded = self._guarded()
             left = int(n_iters)
             while left > 0:
-                k = min(left, self.check_every) if guarded else left
+                k = min(left, self.check_every - self._since_check) if guarded else left   # a driver that calls run() in short chunks is checked too
                 self.engine.mccfr_iterate_sharded(b0, nb, k)
                 left -= k
-                if guarded and (left > 0 or k == self.check_every):
-                    self.replica_check()
+                if guarded:
+                    self._since_check += k
+                    if self._since_check >= self.check_every:
+                        self.final_check()
             return
         for _ in range(int(n_iters)):
             self.iteration(batch_total)
+
+
+    def _guarded(self):
+        return self.replica_check is not None and getattr(self.engine, "exchange_form", None) == "light" and self.check_every > 0
+
+    def final_check(self):
+        """Compare the replicas' tables now if iterations have gone through the light exchange form since the last comparison (every rank must call it:
+        the comparison is a collective).  run() calls it every `check_every` iterations; a caller that stops earlier -- bench.py at the end of its timed
+        regions -- calls it itself."""
+        if self._guarded() and self._since_check > 0:
+            self._since_check = 0
+            self.replica_check()
 
 
 def connect_peer_exchange(ctx, rank, world, device, rounds=32, form="fenced"):
@@ -156,6 +171,10 @@ def connect_peer_exchange(ctx, rank, world, device, rounds=32, form="fenced"):
     return False, why
 
 
+import os as _os
+_os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # the host driver only supports dmabuf IPC (hipIpcGetMemHandle / RCCL fail without it); must be set before the first HIP call
+
+
 def make_gpu_engine(local_rank, perm16, seed, distributed=False, rank=0, exchange="rccl", exchange_form="fenced"):
     """Context on `local_rank` launching on a dedicated torch stream, with a torch-owned delta tensor bound as the
     all-reduce payload.  Returns (ctx, delta_tensor, stream, all_reduce).  distributed: a torch.distributed process group is
@@ -203,6 +222,8 @@ def make_gpu_engine(local_rank, perm16, seed, distributed=False, rank=0, exchang
             return ctx, delta, stream, ctx.p2p_allreduce_delta
         if exchange == "p2p":
             raise RuntimeError(f"peer-memory exchange unavailable: {why}")
+        import sys
+        print(f"[scopa_amd rank {rank} / cuda:{local_rank}] peer-memory exchange not used, falling back to torch.distributed all-reduce: {why}", file=sys.stderr, flush=True)
     return ctx, delta, stream, (all_reduce if distributed else (lambda: None))
 
 
