@@ -11,7 +11,7 @@ import collections, csv, glob, json, os, statistics as st, subprocess, sys
 
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 src = sys.argv[1] if len(sys.argv) > 1 else os.path.join(R, "gpurun_out", "prof")
-tag = sys.argv[2] if len(sys.argv) > 2 else "r03"
+tag = sys.argv[2] if len(sys.argv) > 2 else "r04"
 P = os.path.join(R, "profiles")
 commit = subprocess.run(["git", "-C", R, "log", "-1", "--format=%h", "--", "scopa_amd/csrc/scopa_mccfr.hip"], capture_output=True, text=True).stdout.strip()
 import hashlib
@@ -48,10 +48,10 @@ json.dump({"kernel": "k_mccfr_traverse", "batch": 4096, "commit": commit, "sourc
            "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes, %d dispatches each (profiles/%s_pmc_*.csv; tests/tools/profile_round.sh)"
                      % (res["FETCH_SIZE"]["k_mccfr_traverse"]["dispatches"], tag),
            "FETCH_SIZE_KB_raw": f, "WRITE_SIZE_KB": w,
-           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE counts 64 B per 128-B request for wide coalesced reads -> read bytes doubled (an upper bound here: not all reads are 16 B/lane); WRITE_SIZE taken as is (exact for float atomics: one dword per lane)",
-           "bytes_per_launch": (2 * f + w) * 1e3, "bytes_per_launch_uncorrected": (f + w) * 1e3,
+           "correction": "MI355X_MICROARCH.md HBM section: on gfx950 FETCH_SIZE = TCC_EA0_RDREQ x 64 B while every read request is a 128-byte one (calibrated this round for gathers too: profiles/r04_lanes_pmc.json) -> read bytes doubled; WRITE_SIZE taken as is (exact for float atomics: one dword per lane); the counters' unit is 1024 bytes",
+           "bytes_per_launch": (2 * f + w) * 1024.0, "bytes_per_launch_uncorrected": (f + w) * 1024.0,
            "apply_groups_FETCH_KB_raw": af, "apply_groups_WRITE_KB": aw,
-           "iteration_bytes": (2 * f + w + 2 * (af or 0) + (aw or 0)) * 1e3},
+           "iteration_bytes": (2 * f + w + 2 * (af or 0) + (aw or 0)) * 1024.0},
           open(f"{P}/hbm_traffic.json", "w"), indent=1)
 print(open(f"{P}/hbm_traffic.json").read())
 
@@ -153,7 +153,7 @@ for batch in (4096, 32768):
     for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
         for k in ("k_sdcfr_walk", "k_sdcfr_policy"):
             hb[(ctr, k)] = sd_counters(f"{d}/table/pmc_{ctr}/sdcfr_counters.csv", k)[0].get(ctr, 0.0)
-    rows_bytes = 41 * 264 * batch
+    rows_bytes = 41 * 200 * batch
     line = json.loads(open(f"{d}/table/stats.json").read().strip().splitlines()[-1])
     wd = {"walk_avg_us_under_kernel_trace": walk_us, "policy_avg_us_under_kernel_trace": pol_us, "calls": walk_calls,
           "walk_valu_instr_per_traversal": w["SQ_INSTS_VALU"] / batch, "walk_lds_instr_per_traversal": w["SQ_INSTS_LDS"] / batch,
@@ -170,14 +170,14 @@ for batch in (4096, 32768):
     json.dump({"kernels": "k_sdcfr_policy + k_sdcfr_walk", "batch": batch, "commit": sd_commit, "source_sha256": sd_sha,
                "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE, separate passes (tests/tools/profile_sdcfr.sh)",
                "walk_FETCH_SIZE_KB_raw": fw, "walk_WRITE_SIZE_KB": ww, "policy_FETCH_SIZE_KB_raw": fp, "policy_WRITE_SIZE_KB": wp,
-               "bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1e3, "bytes_per_launch_uncorrected": (fw + fp + ww + wp) * 1e3,
+               "bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1024.0, "bytes_per_launch_uncorrected": (fw + fp + ww + wp) * 1024.0,
                "memory_rows_bytes_per_launch": rows_bytes,
-               "note": "per player's traversal call (both launches).  The necessary HBM traffic is the memory rows (41 rows x 264 B per traversal); policy table, node table and "
+               "note": "per player's traversal call (both launches).  The necessary HBM traffic is the memory rows (41 rows x 200 B per traversal: features and regrets; the mask is a view of the features); policy table, node table and "
                        "frontier are LDS-resident; FETCH_SIZE doubled per the guide's gfx950 correction for wide coalesced reads"},
               open(f"{P}/sdcfr_hbm_traffic_b{batch}.json", "w"), indent=1)
     open(f"{P}/{tag}_sdcfr_kernel_stats_b{batch}.csv", "w").write(open(stats_csv).read())
     open(f"{P}/{tag}_bench_sdcfr_b{batch}_under_rocprof_stats.json", "w").write(json.dumps(line) + "\n")
-    print(batch, "table", json.dumps(wd, indent=1), json.dumps({"bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1e3, "rows": rows_bytes}))
+    print(batch, "table", json.dumps(wd, indent=1), json.dumps({"bytes_per_launch": (2 * (fw + fp) + ww + wp) * 1024.0, "rows": rows_bytes}))
 
 # the names round 2's review asked for (the B = 4096 files: BASELINE configs[3]'s batch)
 import shutil

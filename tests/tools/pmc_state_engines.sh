@@ -1,5 +1,6 @@
 #!/usr/bin/env bash
 # SQ and TCC counter passes of the state-engine step kernels (benchmarks/state_engines_bench.py), per kernel: instructions per game-step, unit busy shares, HBM bytes per game-step
+set -euo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 OUT="$ROOT/gpurun_out/pmc_engines"; rm -rf "$OUT"; mkdir -p "$OUT"; cd /tmp && export TMPDIR=/tmp
 ARGS="--mini ${MINI:-16777216} --team ${TEAM:-16777216} --full ${FULL:-8388608}"

@@ -4,7 +4,7 @@
 # visit/: the forward-per-visit kernel k_sdcfr_traverse (scopa_sdcfr_mode 1 in the timed region: SCOPA_SDCFR_MODE=1): three SQ passes + stats
 # table/: the default form, k_sdcfr_policy + k_sdcfr_walk: two SQ passes, FETCH_SIZE / WRITE_SIZE passes, stats
 # Counters are collected in runs of their own (never with a trace domain other than --kernel-trace); rocprofv3 gets the program itself.
-set -uo pipefail
+set -euo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 OUT="$ROOT/gpurun_out/prof_sdcfr"
 rm -rf "$OUT"; mkdir -p "$OUT/visit" "$OUT/table"

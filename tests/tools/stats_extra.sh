@@ -1,6 +1,7 @@
 #!/usr/bin/env bash
 # rocprofv3 --kernel-trace --stats of the round's other kernels: the hand-written optimiser step (tests/tools/sdcfr_train_breakdown.py), the three batched step
 # kernels (benchmarks/state_engines_bench.py) and the device evaluator (benchmarks/eval_bench.py): per-kernel durations under gpurun_out/stats_extra/
+set -euo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 O="$ROOT/gpurun_out/stats_extra"; rm -rf "$O"; mkdir -p "$O"; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train" -o s -- python3 "$ROOT/tests/tools/sdcfr_train_breakdown.py" > "$O/train.log" 2>&1 || exit 1
