@@ -1,0 +1,120 @@
+#!/usr/bin/env python3
+"""Fuzz the product's Python mirrors (scopa_amd.envs) against the LIVE reference (container only; TEST INFRASTRUCTURE, never shipped to the GPU box).
+Random playouts of MiniScopa (several deals), Team MiniScopa TPI and FullScopa (the reference's own deal, seed 42) with clone() at random plies and a
+share of arbitrary (mostly illegal = silent no-op) actions; after every action the two sides must agree on terminal flag, mover, legal actions of every
+player, every infoset string, rewards / returns, history_str and the visible game objects.
+    python oracle/fuzz_reference.py [playouts per game, default 300]"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, HERE)
+sys.path.insert(0, os.path.dirname(HERE))
+if not os.path.isdir("/root/reference"):
+    sys.exit("reference not present (GPU box?)")
+import refshim  # noqa: E402
+
+ns = refshim.import_reference()
+import importlib  # noqa: E402
+import pyspiel  # noqa: E402  (the stand-in)
+
+from scopa_amd import envs as my  # noqa: E402
+from scopa_amd.envs.openspiel_mini_scopa import MiniScopaGame as MyMiniGame  # noqa: E402
+
+N = int(sys.argv[1]) if len(sys.argv) > 1 else 300
+rng = np.random.RandomState(4)
+checks = 0
+
+
+def cards(cs, cid):
+    return [cid(c) for c in cs]
+
+
+def view(st, n_players, cid, team=False, full=False):
+    g = st.env.game
+    d = dict(term=bool(st.is_terminal()), cur=int(st.current_player()) if not st.is_terminal() else -4,
+             legal=[[int(x) for x in st.legal_actions(p)] for p in range(2)], legal_cur=[int(x) for x in st.legal_actions()],
+             info=[st.information_state_string(p) for p in range(2)], rewards=[float(r) for r in st.rewards()],
+             returns=[float(r) for r in st.returns()], hist=st.history_str(),
+             hands=[cards(p.hand, cid) for p in g.players], table=cards(g.table, cid),
+             ncap=[len(p.captures) for p in g.players], scopas=[int(p.scopas) for p in g.players], step=int(st.env.step_count))
+    return d
+
+
+def mini_cid(c):
+    S = ["cuori", "fiori", "picche", "bello"]
+    R = {"cuori": [2, 5, 8, 10], "fiori": [2, 5, 7, 9], "picche": [3, 6, 8, 9], "bello": [3, 6, 7, 10]}
+    return S.index(c.suit) * 4 + R[c.suit].index(c.rank)
+
+
+def full_cid(c):
+    return ["denari", "coppe", "spade", "bastoni"].index(c.suit) * 10 + (c.rank - 1) if c.suit in ("denari", "coppe", "spade", "bastoni") else FULL_SUITS.index(c.suit) * 10 + (c.rank - 1)
+
+
+def run(name, make_ref, make_my, n_actions, cid, p_clone, p_wild, terminal_clone=True):
+    global checks
+    for k in range(N):
+        a, b = make_ref(k), make_my(k)
+        plies = 0
+        while not a.is_terminal():
+            assert not b.is_terminal(), (name, k, plies)
+            if rng.rand() < p_clone:
+                a, b = a.clone(), b.clone()
+            legal = a.legal_actions()
+            act = int(legal[rng.randint(len(legal))]) if rng.rand() >= p_wild else int(rng.randint(n_actions))
+            a.apply_action(act)
+            b.apply_action(act)
+            va, vb = view(a, 2, cid), view(b, 2, cid)
+            assert va == vb, (name, k, plies, act, {x: (va[x], vb[x]) for x in va if va[x] != vb[x]})
+            checks += len(va)
+            plies += 1
+        assert b.is_terminal()
+        dead = int(rng.randint(n_actions))         # an action after the end: a dead step that still grows the history
+        a.apply_action(dead); b.apply_action(dead)
+        va, vb = view(a, 2, cid), view(b, 2, cid)
+        assert va == vb, (name, k, "dead step", {x: (va[x], vb[x]) for x in va if va[x] != vb[x]})
+        if not terminal_clone:
+            continue
+        ca, cb = a.clone(), b.clone()          # a terminal state's clone stays terminal
+        ca.apply_action(0); cb.apply_action(0)
+        va, vb = view(ca, 2, cid), view(cb, 2, cid)
+        assert va == vb, (name, k, "terminal clone", {x: (va[x], vb[x]) for x in va if va[x] != vb[x]})
+    print(f"{name}: {N} playouts agree")
+
+
+# ---- MiniScopa: the reference's own deal and others through MiniScopaEnv(seed=...) -------------------------------------------------
+game = pyspiel.load_game("mini_scopa")
+SEEDS = [42, 42, 0, 1, 7, 123, 99991]
+
+
+def ref_mini(k):
+    s = SEEDS[k % len(SEEDS)]
+    if s == 42:
+        return game.new_initial_state()
+    return ns.spiel.MiniScopaState(game, env=ns.game.MiniScopaEnv(seed=s), skip_reset=True)
+
+
+def my_mini(k):
+    s = SEEDS[k % len(SEEDS)]
+    return (my.load_game("mini_scopa") if s == 42 else MyMiniGame(seed=s)).new_initial_state()
+
+
+run("mini_scopa", ref_mini, my_mini, 16, mini_cid, 0.3, 0.35)
+
+# ---- Team MiniScopa TPI (default deal) ----------------------------------------------------------------------------------------------
+importlib.import_module("envs.openspiel_team_mini_scopa")
+tgame = pyspiel.load_game("team_mini_scopa_tpi")
+run("team_mini_scopa_tpi", lambda k: tgame.new_initial_state(), lambda k: my.load_game("team_mini_scopa_tpi").new_initial_state(), 16, mini_cid, 0.3, 0.3)
+
+# ---- FullScopa (the reference's deal: seed 42; clones of other deals rebuild the seed-42 deck in the reference, full_scopa_game.py:315-320) ---------
+fg = importlib.import_module("envs.full_scopa_game")
+importlib.import_module("envs.openspiel_full_scopa")
+FULL_SUITS = fg.FullDeck.suits
+fgame = pyspiel.load_game("full_scopa")
+# no clones here: the reference's FullScopaState.clone() raises (openspiel_full_scopa.py:100 builds `FullScopaGame(...)`, which in that module is the pyspiel.Game
+# wrapper defined below it, not the rules object: AttributeError 'players' in set_state) -- the mirror's clone() is the build's own
+run("full_scopa", lambda k: fgame.new_initial_state(), lambda k: my.load_game("full_scopa").new_initial_state(), 40, lambda c: FULL_SUITS.index(c.suit) * 10 + (c.rank - 1), 0.0, 0.25,
+    terminal_clone=False)
+print("checks:", checks)

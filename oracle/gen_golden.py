@@ -671,7 +671,14 @@ def gen_team(ns):
                     st = st.clone()                      # clone mid-game must not disturb anything
                 st.apply_action(a)
                 trail.append(snap(st))
-            cases.append(dict(seed=seed, actions=acts, init=init, trail=trail, player_rewards=[float(st.env.rewards[f"player_{i}"]) for i in range(4)]))
+            player_rewards = [float(st.env.rewards[f"player_{i}"]) for i in range(4)]
+            # actions applied after the end: dead steps for the env (team_mini_scopa_game.py:174-176), yet action_history -- and with it history_str and the
+            # A[...] part of the infoset strings, which a terminal state still hands out -- keeps growing (openspiel_team_mini_scopa.py:88-92)
+            dead = [int(rng.randint(16)) for _ in range(2)]
+            end = st.clone() if k % 2 else st
+            for a in dead:
+                end.apply_action(a)
+            cases.append(dict(seed=seed, actions=acts, init=init, trail=trail, player_rewards=player_rewards, dead_actions=dead, after_end=snap(end)))
     # default construction path of the reference: TPIMiniScopaState(game) -> TeamMiniScopaEnv() -> reset() -> seed 42
     st = game.new_initial_state()
     default = snap(st)

@@ -85,6 +85,8 @@ class TPIMiniScopaState:
     def __init__(self, game, seed=42):
         self._game = game
         self._ts = _lib.TeamState(seed=seed)
+        self._dead = []      # actions applied AFTER the end of the game: dead steps for the env (team_mini_scopa_game.py:174-176), but the reference's
+                             # action_history -- and with it history_str and the A[...] part of every infoset string -- still grows (openspiel_team_mini_scopa.py:88-92)
         self.env = _EnvView(self, seed)
 
     def get_game(self):
@@ -92,7 +94,7 @@ class TPIMiniScopaState:
 
     @property
     def action_history(self):
-        return self._ts.history()
+        return self._ts.history() + self._dead
 
     def current_player(self):
         """the coordinator (team) of the seat to move; PlayerId.TERMINAL (-4) at the end"""
@@ -102,6 +104,9 @@ class TPIMiniScopaState:
         return self._ts.legal()
 
     def apply_action(self, action):
+        if self._ts.is_terminal():
+            self._dead.append(int(action))
+            return
         self._ts.step(action)
 
     def is_terminal(self):
@@ -120,14 +125,21 @@ class TPIMiniScopaState:
         return self.rewards()
 
     def information_state_string(self, player):
-        return self._ts.infoset_string(player)
+        s = self._ts.infoset_string(player)
+        if self._dead and s.endswith("]"):
+            tail = "-".join(map(str, self._dead))
+            s = s[:-1] + ("-" if not s.endswith("A[]") else "") + tail + "]"
+        return s
 
     def history_str(self):
-        return self._ts.history_str()
+        if not self._dead:
+            return self._ts.history_str()
+        h = "-".join(map(str, self.action_history))
+        return f"TERMINAL:{h}:" + ",".join(f"{r:.2f}" for r in self.rewards())
 
     def clone(self):
         c = TPIMiniScopaState.__new__(TPIMiniScopaState)
-        c._game, c._ts = self._game, self._ts.copy()
+        c._game, c._ts, c._dead = self._game, self._ts.copy(), list(self._dead)
         c.env = _EnvView(c, self.env.seed)
         return c
 
