@@ -394,11 +394,14 @@ def test_graph_training_and_eager_training_give_the_same_nets(ctx):
     assert not np.array_equal(r0[:64 * 41], r0[2 * 64 * 41:3 * 64 * 41])  # and iteration 2's regrets differ from iteration 0's: the nets moved
 
 
+HIP_STEP_ATOL = 3e-6   # measured 2e-7 .. 1.1e-6 (differently ordered float32 sums) since Adam's bias corrections are computed on the host in double, as torch.optim.Adam does (round 3: 2e-5)
+
+
 @pytest.mark.parametrize("batch_rows,epochs", [(128, 3), (32, 2), (4096, 2)])
 def test_hip_training_step_matches_the_pytorch_step(ctx, batch_rows, epochs):
     """train_backend="hip" (scopa_sdcfr_train_step: forward, masked MSE, backward, clip_grad_norm_(1.0), Adam in two hand-written launches) against the
     default PyTorch step on the same memory rows and the same index batches: same loss, same weights after every train() call (float32 rounding of
-    differently ordered sums: 2e-5, the tolerance fused vs foreach Adam is held to), over three calls so that Adam's moments and step count carry over."""
+    differently ordered sums: 3e-6), over three calls so that Adam's moments and step count carry over."""
     import torch
     from scopa_amd.envs import load_game
     from scopa_amd.algorithms.deep_cfr import DeepCFR
@@ -428,8 +431,40 @@ def test_hip_training_step_matches_the_pytorch_step(ctx, batch_rows, epochs):
         (l0, w0), (l1, w1) = out
         assert abs(l0 - l1) < 1e-5 * max(1.0, abs(l0)), (it, l0, l1)
         for x, y in zip(w0, w1):
-            np.testing.assert_allclose(x, y, atol=2e-5, rtol=0)
+            np.testing.assert_allclose(x, y, atol=HIP_STEP_ATOL, rtol=0)
     assert ds[1].advantage_nets[0]._hip_step == 3 * epochs and ds[0].advantage_nets[0]._hip_step == 0
+
+
+def test_hip_training_step_orders_itself_against_a_foreign_stream(ctx):
+    """AdvantageNetwork.train(train_backend="hip") called OUTSIDE the solver's stream (the public method, from torch's default stream): the launches go to the
+    library context's stream, so the call must order itself behind what the caller's stream has queued and the caller's later reads behind its launches --
+    same loss and bit-identical weights as the call made inside the solver's stream."""
+    import torch
+    from scopa_amd.envs import load_game
+    from scopa_amd.algorithms.deep_cfr import DeepCFR
+    outs = []
+    for inside in (True, False):
+        torch.manual_seed(9)
+        d = DeepCFR(load_game("mini_scopa"), num_players=2, device="cuda:0", batch=256, train_backend="hip")
+        a = d.advantage_nets[0]
+        for it in range(3):
+            d._iteration = it
+            d._traverse_batch(0, 256, sync=False)                     # rows still being written on the solver's stream when train() is called
+            if inside:
+                with torch.cuda.stream(d._stream):
+                    loss = a.train(batch_size=128, epochs=4)
+            else:
+                loss = a.train(batch_size=128, epochs=4)              # torch's current (default) stream
+                w_now = [p.detach().clone() for p in a.net.parameters()]   # a read on the caller's stream right after the call: must see the trained weights
+            torch.cuda.synchronize()
+            if not inside:
+                for x, y in zip(w_now, a.net.parameters()):
+                    assert torch.equal(x, y)
+        outs.append((loss, [p.detach().cpu().numpy().copy() for p in a.net.parameters()]))
+    (l0, w0), (l1, w1) = outs
+    assert l0 == l1
+    for x, y in zip(w0, w1):
+        assert np.array_equal(x, y)
 
 
 def test_hip_training_step_rejects_bad_arguments_and_trains(ctx):
@@ -451,7 +486,7 @@ def test_hip_training_step_rejects_bad_arguments_and_trains(ctx):
         with pytest.raises(_lib.ScopaError):
             c.sdcfr_train_steps(*bad)
     a.buffer.total = 20                                          # 20 rows in memory: the reference's min(n, 32) batch is 20 -- not whole tiles -> PyTorch path
-    with torch.cuda.stream(d._stream):
+    with torch.cuda.stream(d._stream), pytest.warns(RuntimeWarning, match="separate"):    # ... and says that its Adam state is not the hand-written step's
         a.train(epochs=1)
     d._stream.synchronize()
     assert a._hip_step == 0
