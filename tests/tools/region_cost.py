@@ -1,0 +1,16 @@
+import os, sys, time
+sys.path.insert(0, os.getcwd())
+import torch
+from scopa_amd import _lib
+st = torch.cuda.Stream()
+ctx = _lib.Context(0, stream=st.cuda_stream); ctx.set_deal(_lib.deal_py_seed(42)); ctx.mccfr_seed(0x5C09A)
+ctx.mccfr_iterate(4096, 20000); torch.cuda.synchronize()
+def region(K, sync):
+    sync(); t0 = time.perf_counter(); ctx.mccfr_iterate(4096, K); sync(); return time.perf_counter() - t0
+for name, sync in (("torch.cuda.synchronize", torch.cuda.synchronize), ("ctx.synchronize", ctx.synchronize)):
+    for K in (1, 5, 20, 100, 1000):
+        ts = sorted(region(K, sync) for _ in range(41))
+        print(f"{name:24s} K={K:5d}: median region {ts[20]*1e6:9.1f} us = {ts[20]*1e6/K:7.2f} us/iteration   min {ts[0]*1e6:9.1f}")
+# host time of the enqueue alone
+t0 = time.perf_counter(); ctx.mccfr_iterate(4096, 1000); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
+print(f"enqueue of 1000 iterations returns after {(t1-t0)*1e6:.0f} us; device done after {(t2-t0)*1e6:.0f} us")
