@@ -256,9 +256,9 @@ k_eval_tabular_step(scopa_state *__restrict__ states, int32_t *__restrict__ node
                     const int32_t *__restrict__ trained_seat, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream) {
     const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    scopa_state s = states[i];
-    if (is_terminal(s)) return;
-    const int p = s.step & 1, nl = s.nh[p];
+    uint4 sw = reinterpret_cast<const uint4 *>(states)[i];     // the state as its four words (scopa_rules.h step_words): no struct member indexed by the mover
+    if ((sw.z & 0xFFFFu) == 0u || ((sw.z >> 24) & SCOPA_STEP_COUNT_MASK) >= (((sw.z >> 24) & SCOPA_STEP_CLONED) ? 16u : 8u)) return;   // terminal
+    const int p = (int)((sw.z >> 24) & 1u), nl = (int)((sw.z >> (8 * p)) & 255u);
     const int idx = node_idx[i];
     const philox_out x = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)ply, stream, seed_lo, seed_hi);
     int k = nl - 1;
@@ -282,8 +282,8 @@ k_eval_tabular_step(scopa_state *__restrict__ states, int32_t *__restrict__ node
         const int a = (int)(u * (double)nl);
         k = a < nl - 1 ? a : nl - 1;
     }
-    step(s, nib(s.hand[p], k));
-    states[i] = s;
+    step_words(sw.x, sw.y, sw.z, sw.w, nib((sw.x >> (16 * p)) & 0xFFFFu, k));
+    reinterpret_cast<uint4 *>(states)[i] = sw;
     node_idx[i] = idx * nl + k;
 }
 

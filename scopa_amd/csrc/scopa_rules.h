@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <string.h>
 
 #include "../../include/scopa.h"
 
@@ -82,78 +83,109 @@ SC_HD int sc_ctz32(uint32_t x) {   // x != 0
     return __builtin_ctz(x);
 #endif
 }
+// true if the predicate holds in ANY lane of the wavefront (device) / for this state (host): lets a loop over table positions stop, wave-uniformly, where
+// no game of the wavefront has a card left -- games advanced in lockstep have tables of similar length, and a uniform branch costs one scalar instruction
+SC_HD bool sc_any(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p) != 0ull;
+#else
+    return p;
+#endif
+}
 SC_HD uint32_t capture_mask(uint32_t table, int nt, int target) {
     if (nt == 0 || target <= 0) return 0u;
     uint32_t ranks = 0u;       // the table as a nibble list of RANKS (2..10), zero beyond nt
 #pragma unroll
-    for (int i = 0; i < 8; i++)
-        if (i < nt) ranks |= (uint32_t)card_rank(nib(table, i)) << (4 * i);
+    for (int i = 0; i < 8; i++) {
+        if (!sc_any(i < nt)) break;
+        ranks |= (uint32_t)card_rank(nib(table, i)) << (4 * i);
+    }
+    ranks &= nt >= 8 ? 0xFFFFFFFFu : ((1u << (4 * nt)) - 1u);   // (unused table nibbles are 0 = a card id: masked here instead of a test per card)
     {   // (1) the first table card of the played rank: the lowest zero nibble of ranks ^ (target in every nibble) -- nibbles beyond nt hold `target` != 0
         const uint32_t x = ranks ^ ((uint32_t)target * 0x11111111u);
         const uint32_t z = (x - 0x11111111u) & ~x & 0x88888888u;   // bit 4 i + 3 set for the lowest zero nibble i (higher ones may be false, the lowest never is)
         if (z) return 1u << (sc_ctz32(z) >> 2);
     }
     // (2) the reference's subset-sum: comb_sums[s] is written once, when card i first makes s reachable, as comb_sums[s - rank_i] (as it stood BEFORE card i) +
-    // [i].  Kept here: the reachable set and, per sum, the index of the card that first reached it (a nibble each); the subset of `target` is then read
-    // back along that chain -- card first[target], then the subset of target - rank, which was complete before that card -- instead of carrying an 8-bit
-    // subset per sum through every card.
+    // [i].  Kept here: the reachable set and, per sum, the INDEX of the card that first reached it, as three bit planes over the sums (bit s of F_b = bit b of
+    // that index) -- a card updates all sums at once and ORs its fresh sums into the planes its (compile-time) index has set: no loop over the fresh sums, no
+    // branch (a rank of 0 beyond the table's end makes `fresh` empty).  The subset of `target` is then read back along the chain -- card first[target], then the
+    // subset of target - rank, which was complete before that card -- instead of carrying an 8-bit subset per sum through every card.
     uint32_t valid = 1u;       // bit s: sum s reachable
-    uint64_t first = 0ull;     // nibble s: index of the card at which s became reachable
+    uint32_t f0 = 0u, f1 = 0u, f2 = 0u;
     const uint32_t upto = (2u << target) - 1u;
 #pragma unroll
     for (int i = 0; i < 8; i++) {
-        if (i >= nt) break;
-        const int r = (int)((ranks >> (4 * i)) & 15u);
-        uint32_t fresh = (valid << r) & ~valid & upto;
+        if (!sc_any(i < nt)) break;
+        const uint32_t r = (ranks >> (4 * i)) & 15u;
+        const uint32_t fresh = (valid << r) & ~valid & upto;
         valid |= fresh;
-        while (fresh) {        // one or two sums as a rule
-            const int s = sc_ctz32(fresh);
-            fresh &= fresh - 1u;
-            first |= (uint64_t)i << (4 * s);
-        }
+        if (i & 1) f0 |= fresh;
+        if (i & 2) f1 |= fresh;
+        if (i & 4) f2 |= fresh;
     }
     if (!((valid >> target) & 1u)) return 0u;
     uint32_t mask = 0u;
-    int rem = target;
-    for (int step = 0; step < 5 && rem > 0; step++) {   // at most five cards (ranks >= 2, target <= 10)
-        const int i = (int)((first >> (4 * rem)) & 15ull);
-        mask |= 1u << i;
-        rem -= (int)((ranks >> (4 * i)) & 15u);
+    uint32_t rem = (uint32_t)target;
+#pragma unroll
+    for (int step = 0; step < 5; step++) {   // at most five cards (ranks >= 2, target <= 10); steps past the end of the chain (rem == 0) add nothing
+        if (!sc_any(rem != 0u)) break;
+        const uint32_t i = ((f0 >> rem) & 1u) | (((f1 >> rem) & 1u) << 1) | (((f2 >> rem) & 1u) << 2);
+        const bool on = rem != 0u;
+        mask |= on ? (1u << i) : 0u;
+        rem -= on ? ((ranks >> (4 * i)) & 15u) : 0u;
     }
     return mask;
 }
 
 // ---- MiniScopaEnv.step + MiniScopaGame.play_card, mini_scopa_game.py:93-104,140-167 ------------------------
-SC_HD void step(scopa_state &s, int action) {
-    if (is_terminal(s)) return;  // _was_dead_step (:141-143)
-    const int p = s.step & 1;
-    const uint32_t hand = s.hand[p];
-    const int nh = s.nh[p];
+// On the state's four 32-bit words (x = hand[0] | hand[1] << 16, y = table, z = nh[0] | nh[1] << 8 | nt << 16 | step << 24, w = ncap[0] | ncap[1] << 8 |
+// scopas[0] << 16 | scopas[1] << 24): the mover's fields are picked with shifts by 16 p / 8 p.  (Indexing the struct's arrays with the run-time mover sent the
+// whole state to LDS in the kernels -- ten DS accesses per step; round 4.)
+SC_HD void step_words(uint32_t &x, uint32_t &y, uint32_t &z, uint32_t &w, int action) {
+    const uint32_t stepb = z >> 24, nt = (z >> 16) & 255u;
+    if (((z & 0xFFFFu) == 0u) || ((stepb & SCOPA_STEP_COUNT_MASK) >= ((stepb & SCOPA_STEP_CLONED) ? 16u : 8u))) return;  // terminal: _was_dead_step (:141-143)
+    const uint32_t p = stepb & 1u;
+    const uint32_t hand = (x >> (16u * p)) & 0xFFFFu;
+    const int nh = (int)((z >> (8u * p)) & 255u);
     int pos = -1;
 #pragma unroll
     for (int i = 3; i >= 0; i--)  // first card in hand order that is `action` (:155)
         if (i < nh && nib(hand, i) == action) pos = i;
     if (pos >= 0) {
-        const uint32_t cap = capture_mask(s.table, s.nt, card_rank(action));
+        const uint32_t cap = capture_mask(y, (int)nt, card_rank(action));
         if (cap) {
             uint32_t nt_new = 0, tab = 0;
+            const uint32_t keep = ~cap & (nt >= 8u ? 0xFFu : ((1u << nt) - 1u));   // table positions that stay, in order
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (i < s.nt && !((cap >> i) & 1u)) { tab |= (uint32_t)nib(s.table, i) << (4 * nt_new); nt_new++; }
-            s.ncap[p] = (uint8_t)(s.ncap[p] + (s.nt - nt_new) + 1);  // captured + [card] (:98)
-            s.table = tab;
-            s.nt = (uint8_t)nt_new;
-            if (nt_new == 0) s.scopas[p]++;                            // (:100-101), last ply included
-        } else if (s.nt < 8) {
-            s.table |= (uint32_t)action << (4 * s.nt);                 // (:103)
-            s.nt++;
+            for (int i = 0; i < 8; i++) {
+                if (!sc_any(i < (int)nt)) break;
+                const uint32_t k = (keep >> i) & 1u;
+                tab |= (k ? (uint32_t)nib(y, i) : 0u) << (4 * nt_new);
+                nt_new += k;
+            }
+            y = tab;
+            const uint32_t mine = w >> (8u * p);                         // the mover's bytes: ncap at bits 0-7, scopas at bits 16-23
+            const uint32_t ncap = (mine + (nt - nt_new) + 1u) & 255u;    // captured + [card] (:98); uint8 arithmetic, as the struct's fields
+            const uint32_t scop = ((mine >> 16) + (nt_new == 0u ? 1u : 0u)) & 255u;   // (:100-101), last ply included
+            w = (w & ~(0x00FF00FFu << (8u * p))) | ((ncap | (scop << 16)) << (8u * p));
+            z = (z & ~(255u << 16)) | (nt_new << 16);
+        } else if (nt < 8u) {
+            y |= (uint32_t)action << (4u * nt);                         // (:103)
+            z += 1u << 16;
         }   // a ninth table card cannot happen in play (table ranks are distinct and an equal rank always captures); a crafted
             // state that would need it keeps its eight cards -- the packed state has no ninth slot and no error channel
-
-        s.hand[p] = (uint16_t)nib_remove(hand, pos);                   // (:104)
-        s.nh[p] = (uint8_t)(nh - 1);
+        x = (x & ~(0xFFFFu << (16u * p))) | (nib_remove(hand, pos) << (16u * p));   // (:104)
+        z -= 1u << (8u * p);                                            // nh[p]--
     }  // else: card not in hand -> silent no-op that still consumes the turn (:155-159)
-    s.step++;
+    z += 1u << 24;                                                      // step_count++ (the clone bit above it is never reached: counts stop at 16)
+}
+
+SC_HD void step(scopa_state &s, int action) {
+    uint32_t v[4];
+    memcpy(v, &s, 16);
+    step_words(v[0], v[1], v[2], v[3], action);
+    memcpy(&s, v, 16);
 }
 
 // evaluate_game (:106-114) times two: r2[i] = 2*r_i - total, an integer; zero until terminal.

@@ -14,17 +14,33 @@
 using namespace scopa;
 
 // ---- kernel 1: batched step.  One lane per game; a state is one 16-byte (dwordx4) coalesced load/store. --------
+#ifndef SCOPA_STEP_UNROLL
+#define SCOPA_STEP_UNROLL 2
+#endif
 __global__ void __launch_bounds__(256) k_step_batch(scopa_state *__restrict__ states,
                                                      const uint8_t *__restrict__ actions, int64_t n) {
+    // U games per lane and pass, all loads issued before any state is stepped: U times the bytes in flight per wavefront (the kernel moves 33 bytes
+    // per game-step and waits on HBM latency, not on its arithmetic, while the tables are short)
+    constexpr int U = SCOPA_STEP_UNROLL;
     const int64_t stride = (int64_t)gridDim.x * blockDim.x;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
-        const uint4 raw = reinterpret_cast<const uint4 *>(states)[i];
-        scopa_state s;
-        memcpy(&s, &raw, 16);
-        step(s, actions[i] & 15);
-        uint4 out;
-        memcpy(&out, &s, 16);
-        reinterpret_cast<uint4 *>(states)[i] = out;
+    uint4 *st = reinterpret_cast<uint4 *>(states);
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += U * stride) {
+        uint4 v[U];
+        int act[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t j = i + u * stride;
+            v[u] = j < n ? st[j] : make_uint4(0u, 0u, 0u, 0u);
+            act[u] = j < n ? actions[j] & 15 : 0;
+        }
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            const int64_t j = i + u * stride;
+            if (j < n) {
+                step_words(v[u].x, v[u].y, v[u].z, v[u].w, act[u]);
+                st[j] = v[u];
+            }
+        }
     }
 }
 
