@@ -150,7 +150,7 @@ def state_engines(device=0, n_mini=1 << 24, n_team=1 << 23, n_full=1 << 22):
         out = seb.measure(ctx, n_mini, n_team, n_full, 1024, stream, device)
     finally:
         ctx.close()
-    pmc = _profile("r03_pmc_state_engines.json") or {}
+    pmc = _profile("pmc_state_engines.json") or {}
     for key, kern in (("mini", "k_step_batch"), ("team", "k_team_step_batch"), ("full", "k_full_step_batch")):
         r = out.get(key)
         if not r:
@@ -160,8 +160,8 @@ def state_engines(device=0, n_mini=1 << 24, n_team=1 << 23, n_full=1 << 22):
         wg = r["whole_game"]
         r["roofline"] = {"bound": "hbm", "achieved": wg["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": wg["frac"],
                          "traffic": per_step * r["games"] if per_step else None,
-                         "traffic_source": "profiles/r03_pmc_state_engines.json (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, per game-step) x games per launch; "
-                                           "taken on round 3's kernels (unchanged since, up to the terminal rule's clone bit)" if per_step else None,
+                         "traffic_source": "profiles/pmc_state_engines.json (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, per game-step; "
+                                           "tests/tools/pmc_state_engines.sh) x games per launch" if per_step else None,
                          "best_ply_frac": r["best_ply"]["frac"],
                          "note": "achieved = algorithmic bytes per game-step (state in + action + state out) x games x plies / the whole game's launches"}
     return out

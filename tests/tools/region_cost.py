@@ -14,3 +14,10 @@ for name, sync in (("torch.cuda.synchronize", torch.cuda.synchronize), ("ctx.syn
 # host time of the enqueue alone
 t0 = time.perf_counter(); ctx.mccfr_iterate(4096, 1000); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
 print(f"enqueue of 1000 iterations returns after {(t1-t0)*1e6:.0f} us; device done after {(t2-t0)*1e6:.0f} us")
+# host cost of the enqueue alone at queue depths that cannot fill the ring
+for K in (10, 20, 50, 100, 200):
+    ts = []
+    for _ in range(21):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); ctx.mccfr_iterate(4096, K); t1 = time.perf_counter(); torch.cuda.synchronize(); ts.append((t1 - t0) / K)
+    ts.sort()
+    print(f"enqueue K={K:4d}: host returns after {ts[10]*1e6:6.2f} us per iteration (min {ts[0]*1e6:.2f}, max {ts[-1]*1e6:.2f})")
