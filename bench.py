@@ -703,7 +703,7 @@ def main():
             "timing": {"protocol": f"pre-phase {n_pre} iterations ({pre_s:.2f} s), then --warmup, then the --steps region timed {regions} times "
                                    "(barrier + device sync both sides, max over ranks); value and ms_per_step are the MEDIAN region",
                        "regions": regions, "region_ms_median": 1e3 * med, "region_ms_min": 1e3 * min(times), "region_ms_max": 1e3 * max(times),
-                       "region_ms_first": 1e3 * times[0], "ms_per_step_min": 1e3 * min(times) / args.steps, "ms_per_step_max": 1e3 * max(times) / args.steps,
+                       "region_ms_first": 1e3 * times[0], "region_ms_all": [round(1e3 * t, 4) for t in times], "ms_per_step_min": 1e3 * min(times) / args.steps, "ms_per_step_max": 1e3 * max(times) / args.steps,
                        "pre_phase_iterations": n_pre, "pre_phase_s": pre_s},
             "roofline": roofline,
             "decision_visits": visits,
