@@ -13,12 +13,13 @@
 // 80 nodes (plies 0..5), each lane deriving its node from its parent's record word, fetched from the parent's lane with a cross-lane
 // read (index arithmetic: the game tree is regular), sampling its action from the frozen sigma|threshold row and keeping its own
 // record in a register for the next ply and in LDS for the update step.  What is static per lane (parent lane, forced action, draw
-// word, ancestor slots) comes from a table built once per context (k_lane_table).  The 16 wavefronts of a workgroup TAKE their pairs
+// word, the update lane's ancestor records, leaf values and forced actions) comes from a table built once per context (k_lane_table), staged
+// into LDS by the prologue and read 16 bytes at a time by the stage that needs it.  The 16 wavefronts of a workgroup TAKE their pairs
 // from a counter in LDS and run independently -- only wave-level LDS ordering between stages, no workgroup barrier in the main loop
 // -- so they hide each other's latencies (v3 had workgroup-wide plies and was latency-bound).
 // Random draws are Philox4x32-10 blocks keyed by the node: block (ntl, j >> 1) of the (global traversal id, iteration, traverser)
 // stream serves the four nodes (j even | odd) x (opponent node | traverser node below it), one 32-bit word each.  All 58 blocks of a
-// pair are computed in ONE dense pre-pass (draw_pair) and kept as 31-bit integers that are compared with integer thresholds
+// pair are computed in ONE dense pre-pass (draw_pairs: one 16-byte LDS store per lane) and kept as 31-bit integers that are compared with integer thresholds
 // ceil(cdf * 2^31) -- so WHICH traversals are sampled does not depend on launch geometry, pass size or GPU count (the sums of their
 // increments do, at rounding level: float64 atomics add in arrival order -- LDS within a workgroup, memory-side into a group table -- so two
 // runs agree to ~1e-15 relative per iteration, not bit for bit, and since the rounded regrets feed the next iteration's integer thresholds a
@@ -28,20 +29,22 @@
 // task): reach and sampling probability rebuilt from the <= 5 ancestor records (the reference's products in the reference's order),
 // v as the reference's fma chain over <= 4 leaf payoffs, <= 4 LDS ds_add_f64 into the workgroup's delta table.  Every stage
 // gathers what it reads before it stores anything (branch-free loads, slots beyond a node's action count selected away).
-// Everything a pair touches is LDS resident (sigma|threshold rows 35 KB, delta 24 KB, 16 x 2 x 1.4 KB wave scratch, tree maps 4 KB
-// at 738 infosets; one 1024-thread workgroup per CU).  A workgroup finally adds its non-zero cells to one of 16 GROUP TABLES in HBM
+// Everything a pair touches is LDS resident (sigma|threshold rows 35 KB, delta 24 KB, 16 x 2 x 1.8 KB wave scratch, tree maps 4 KB,
+// lane table 15 KB at 738 infosets; one 1024-thread workgroup per CU).  A workgroup finally adds its non-zero cells to one of 16 GROUP TABLES in HBM
 // with memory-side float64 atomics; k_mccfr_apply_groups (one small launch; k_mccfr_exchange_apply for N > 1, which exchanges the
 // rows with the peers first, scopa_p2p.h; k_mccfr_fold + k_mccfr_apply on the split path) sums the group tables in table order and
 // applies them.  Strategy sums are integer visit counts (sigma is frozen, so strategy_sum += count * sigma).
 //
-// History (rocprofv3, B = 4096 per traverser, profiles/; full table in DESIGN.md section 4): v1 one lane per leaf path + global f64
+// History (rocprofv3, B = 4096 per traverser, profiles/; full table in profiles/HISTORY.md section 4): v1 one lane per leaf path + global f64
 // atomics + one global counter atomic per wavefront: 122 us (100 us of it 8192 same-address atomics); v2 per-workgroup slabs +
 // a reduce kernel + traverser-specialised walk: 20-23 us; v3 unique nodes with workgroup-wide plies: same time (latency-bound);
 // v4-v7 (unique nodes per wavefront, dense Philox pre-pass, integer thresholds, node records in registers): 13.6 us + 8.3 us of
 // slab reduce; v8-v11 (round 2: slabs -> sparse atomics into group tables, lane-per-cell apply kernel, one Philox pass of 31-bit
 // draws, gather-then-store stages): 12.2 us + 4.9 us, 15.6 us per iteration; v12-v14 (one record word handed down, update step
 // rebuilds its products, lane table, pairs taken from a workgroup counter, two pairs in flight): 15.4 us, and 60.7 us instead of
-// 86.4 us at B = 65536.
+// 86.4 us at B = 65536; round 4 (lane table read per stage instead of unpacked per wavefront, one draw store per lane, identity record,
+// first-visit tracking off once every infoset is marked, a lane per row in the epilogue): 680 -> 520 vector instructions per wavefront
+// at one pair per wavefront, 13.3-13.6 -> 12.6-12.9 us per iteration (DESIGN.md section 4 has the attribution by phase).
 #include <hip/hip_ext.h>
 
 #include "scopa_ctx.h"
