@@ -2,7 +2,7 @@
 """When do the workgroups of a k_mccfr_traverse launch start, by blockIdx?  Sampled launches carry per-workgroup stamps on the 100 MHz device clock
 (start | prologue done | walks done | end); this prints, averaged over the last 32 sampled launches, the start offset behind the launch's first workgroup
 and the end offset, for every 8th workgroup, and per residue blockIdx % 8 (the XCD a workgroup lands on, if dispatch is round-robin).
-    python tests/tools/wg_starts.py [batch]"""
+    python tests/tools/wg_starts.py [batch] [idle]"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
@@ -11,8 +11,14 @@ from scopa_amd import _lib
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 ctx = _lib.Context(0); ctx.set_deal(_lib.deal_py_seed(42)); ctx.mccfr_seed(0x5C09A)
 ctx.mccfr_iterate(B, 2000); ctx.synchronize()
-ctx.prof_enable(7)
-ctx.mccfr_iterate(B, 7 * 40); ctx.synchronize()
+IDLE = len(sys.argv) > 2 and sys.argv[2] == "idle"      # every sampled launch is the first after a stream synchronisation (an idle GPU) instead of one in a running loop
+if IDLE:
+    ctx.prof_enable(1)
+    for _ in range(40):
+        ctx.mccfr_iterate(B, 1); ctx.synchronize()
+else:
+    ctx.prof_enable(7)
+    ctx.mccfr_iterate(B, 7 * 40); ctx.synchronize()
 ctx.prof_read()
 L = _lib.lib()
 n, G = 32, 512
