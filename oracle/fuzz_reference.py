@@ -103,6 +103,25 @@ def my_mini(k):
 
 run("mini_scopa", ref_mini, my_mini, 16, mini_cid, 0.3, 0.35)
 
+# a State built around an env that has ALREADY ended (skip_reset=True): the wrapper's own terminal flag starts False (openspiel_mini_scopa.py:14) and only
+# follows apply_action (:49-53), so until the first (dead) step such a state lists its mover's hand and hands out infoset strings
+from scopa_amd.envs.openspiel_mini_scopa import MiniScopaState as MyMiniState  # noqa: E402
+for k in range(min(N, 60)):
+    a, b = ref_mini(k), my_mini(k)
+    while not a.is_terminal():
+        legal = a.legal_actions()
+        act = int(legal[rng.randint(len(legal))]) if rng.rand() >= 0.35 else int(rng.randint(16))
+        a.apply_action(act); b.apply_action(act)
+    wa = ns.spiel.MiniScopaState(game, env=a.env, skip_reset=True)
+    wb = MyMiniState(b.get_game(), env=b.env, skip_reset=True)
+    va, vb = view(wa, 2, mini_cid), view(wb, 2, mini_cid)
+    assert va == vb and not wb.is_terminal(), ("wrapped ended env", k, {x: (va[x], vb[x]) for x in va if va[x] != vb[x]})
+    wa.apply_action(3); wb.apply_action(3)
+    va, vb = view(wa, 2, mini_cid), view(wb, 2, mini_cid)
+    assert va == vb and wb.is_terminal(), ("wrapped ended env, after a dead step", k, {x: (va[x], vb[x]) for x in va if va[x] != vb[x]})
+    checks += 2 * len(va)
+print("mini_scopa: states wrapped around ended envs agree")
+
 # ---- Team MiniScopa TPI (default deal) ----------------------------------------------------------------------------------------------
 importlib.import_module("envs.openspiel_team_mini_scopa")
 tgame = pyspiel.load_game("team_mini_scopa_tpi")

@@ -44,9 +44,10 @@ class MiniScopaState:
             return []
         if player is None:
             player = self.current_player()
-        out, n = (C.c_int32 * 4)(), C.c_int32()
-        _lib.lib().scopa_state_legal(C.byref(self.env.game.packed), int(player), C.byref(out), C.byref(n))
-        return [out[i] for i in range(n.value)]
+        # from the hand alone, as the reference: the WRAPPER's terminal flag decides above, not the env's (a state built around an env that has already
+        # ended, skip_reset=True, still lists the hand -- the flag only follows apply_action, :49-53)
+        legal = [c.id for c in self.env.game.players[player].hand]
+        return legal if legal else [0]
 
     def apply_action(self, action):
         self.action_history.append(action)
@@ -86,8 +87,9 @@ class MiniScopaState:
             player = self.current_player()
         if self._is_terminal or player < 0:
             return "TERMINAL"
-        buf = C.create_string_buffer(96)
-        _lib.lib().scopa_state_infoset_string(C.byref(self.env.game.packed), int(player), buf, 96)
+        key, buf = C.c_uint64(), C.create_string_buffer(96)         # the key of (player, hand, table) whatever the env's own terminal state: see legal_actions
+        _lib.lib().scopa_state_infoset_key(C.byref(self.env.game.packed), int(player), C.byref(key))
+        _lib.lib().scopa_key_to_string(key, buf, 96)
         return buf.value.decode()
 
     def clone(self):
