@@ -32,6 +32,10 @@ def cards(cs, cid):
     return [cid(c) for c in cs]
 
 
+ORDERED_CAPS = True    # MiniScopa's mirror keeps captures as lists in capture order; the Team / FullScopa mirrors keep captured cards as bit masks of the packed
+                       # state (order of `player.captures` is not kept: nothing in the reference reads more than its length) and are compared sorted
+
+
 def view(st, n_players, cid, team=False, full=False):
     g = st.env.game
     d = dict(term=bool(st.is_terminal()), cur=int(st.current_player()) if not st.is_terminal() else -4,
@@ -39,7 +43,8 @@ def view(st, n_players, cid, team=False, full=False):
              info=[st.information_state_string(p) for p in range(2)], rewards=[float(r) for r in st.rewards()],
              returns=[float(r) for r in st.returns()], hist=st.history_str(),
              hands=[cards(p.hand, cid) for p in g.players], table=cards(g.table, cid),
-             ncap=[len(p.captures) for p in g.players], scopas=[int(p.scopas) for p in g.players], step=int(st.env.step_count))
+             ncap=[len(p.captures) for p in g.players], caps=[cards(p.captures, cid) if ORDERED_CAPS else sorted(cards(p.captures, cid)) for p in g.players],
+             scopas=[int(p.scopas) for p in g.players], step=int(st.env.step_count))
     return d
 
 
@@ -122,6 +127,7 @@ for k in range(min(N, 60)):
     checks += 2 * len(va)
 print("mini_scopa: states wrapped around ended envs agree")
 
+ORDERED_CAPS = False
 # ---- Team MiniScopa TPI (default deal) ----------------------------------------------------------------------------------------------
 importlib.import_module("envs.openspiel_team_mini_scopa")
 tgame = pyspiel.load_game("team_mini_scopa_tpi")
