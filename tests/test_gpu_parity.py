@@ -250,6 +250,40 @@ def test_mccfr_batched_delta_vs_reference_sample(ctx, sl, golden, case):
     assert set(np.flatnonzero(seen)) == set(idx)                 # exactly the reference's dict keys exist afterwards
 
 
+def test_mccfr_first_visit_tracking_switches_off_once_every_infoset_is_marked(ctx, sl, oracle):
+    """A traversal launch records which infosets it sees for the first time (the keys the reference's dict would hold, mc_cfr.py:32-35).  Once every infoset
+    of the deal is marked the host stops asking for it (scopa_mccfr.hip refresh_all_seen: checked at most every 16th launch): the walks skip their `seen`
+    flags and the epilogue its scan.  The marks grow monotonically to all 738, stay what they are afterwards, and a launch on the tracking-off path gives the
+    oracle's deltas and exact counts like a launch on a fresh context."""
+    t = oracle.Tree(seed=42)
+    ctx.set_deal(sl.deal_py_seed(42))
+    ctx.mccfr_seed(0x5C09A)
+    prev = np.zeros(t.n_infosets, bool)
+    for chunk in range(12):
+        ctx.mccfr_iterate(256, 20)                                  # 240 launches in all: the host re-counts the marks every 16th
+        seen = ctx.visited_get() != 0
+        assert np.all(seen[prev])                                   # monotone
+        prev = seen
+    assert prev.all()                                               # 61 440 traversal pairs reach every infoset of the deal
+    marks = ctx.visited_get().copy()
+    ctx.mccfr_iterate(256, 40)                                      # by now launches run with tracking off
+    assert np.array_equal(ctx.visited_get(), marks)
+    R, S, _ = ctx.tables_get()
+    it = ctx.mccfr_iteration()
+    c0 = ctx.counters()
+    ctx.mccfr_delta_set(np.zeros((t.n_infosets, 5)))
+    ctx.mccfr_traverse(it, 0, 3000)
+    d = ctx.mccfr_delta_get()
+    c1 = ctx.counters()
+    dR, dS, dv, tv = t.mccfr_batched_delta(R, 0x5C09A, it, 0, 3000)
+    assert (c1[0] - c0[0], c1[1] - c0[1]) == (dv, tv) == (463 * 3000, 240 * 3000)
+    assert np.array_equal(d[:, 4], np.rint(dS.sum(1)))
+    np.testing.assert_allclose(d[:, :4], dR, rtol=1e-12, atol=1e-12 * max(1.0, np.abs(dR).max()))
+    ctx.tables_reset()                                              # a reset clears the marks: tracking is on again
+    ctx.mccfr_traverse(0, 0, 8)
+    assert 0 < int((ctx.visited_get() != 0).sum()) < t.n_infosets
+
+
 # batches beyond 4096 exercise how a workgroup's wavefronts take pairs (scopa_mccfr.hip, main loop): 4101 = 16 wavefronts x 256
 # workgroups + a ragged last workgroup; 5000 = between one and two pairs per wavefront (single takes from the counter); 10240 = two pairs
 # in flight, then single takes; 17923 = more than four pairs per wavefront (double takes, single ones towards the end, ragged tail)
