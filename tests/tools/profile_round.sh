@@ -23,4 +23,4 @@ for BATCH in 4096 65536; do
   rocprofv3 --kernel-trace --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_LDS_IDX_ACTIVE SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR --output-format csv -d "$OUT/sq_b_$BATCH" -o p -- python3 "$B" --no-cpu-baseline --no-sdcfr --no-subrecords --batch $BATCH --steps 20 --warmup 5 --regions 3 --pre-phase-s 0 > "$OUT/sq_b_$BATCH.json" 2> "$OUT/sq_b_$BATCH.err" || exit 1
   rm -f "$OUT"/sq_?_$BATCH/*kernel_trace.csv
 done
-ls -la "$OUT" "$OUT"/*/ | head -60
+ls "$OUT"
