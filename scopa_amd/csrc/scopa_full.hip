@@ -29,11 +29,25 @@ k_full_step_batch(scopa_full_state *__restrict__ states, const uint8_t *__restri
     if (w0 >= n) return;
     const long long left = n - w0;                                                       // games of this wavefront that exist (>= 1)
     unsigned char *st = s_stage[wave];
+    int act = 0;                                                                         // (asked for with the states, not after them)
     const uint4 *src = reinterpret_cast<const uint4 *>(states + w0);
+    if (left >= 64) {                                   // a whole wavefront (all but the last): the four loads are issued together, unguarded
+        act = actions[w0 + lane];
+        uint4 v[4];
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int c = k * 64 + lane, j = c >> 2, part = c & 3;
-        if (j < left) *reinterpret_cast<uint4 *>(st + j * kFullLdsStride + part * 16) = src[c];
+        for (int k = 0; k < 4; k++) v[k] = src[k * 64 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = k * 64 + lane;
+            *reinterpret_cast<uint4 *>(st + (c >> 2) * kFullLdsStride + (c & 3) * 16) = v[k];
+        }
+    } else {
+        if (lane < left) act = actions[w0 + lane];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = k * 64 + lane, j = c >> 2, part = c & 3;
+            if (j < left) *reinterpret_cast<uint4 *>(st + j * kFullLdsStride + part * 16) = src[c];
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (lane < left) {
@@ -42,17 +56,25 @@ k_full_step_batch(scopa_full_state *__restrict__ states, const uint8_t *__restri
         for (int k = 0; k < 4; k++) raw[k] = *reinterpret_cast<const uint4 *>(st + lane * kFullLdsStride + k * 16);
         scopa_full_state s;
         memcpy(&s, raw, 64);
-        step(s, decks + (size_t)s.game * 40, actions[w0 + lane] % 40);
+        step(s, decks + (size_t)s.game * 40, act % 40);
         memcpy(raw, &s, 64);
 #pragma unroll
         for (int k = 0; k < 4; k++) *reinterpret_cast<uint4 *>(st + lane * kFullLdsStride + k * 16) = raw[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint4 *dst = reinterpret_cast<uint4 *>(states + w0);
+    if (left >= 64) {
 #pragma unroll
-    for (int k = 0; k < 4; k++) {
-        const int c = k * 64 + lane, j = c >> 2, part = c & 3;
-        if (j < left) dst[c] = *reinterpret_cast<const uint4 *>(st + j * kFullLdsStride + part * 16);
+        for (int k = 0; k < 4; k++) {
+            const int c = k * 64 + lane;
+            dst[c] = *reinterpret_cast<const uint4 *>(st + (c >> 2) * kFullLdsStride + (c & 3) * 16);
+        }
+    } else {
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int c = k * 64 + lane, j = c >> 2, part = c & 3;
+            if (j < left) dst[c] = *reinterpret_cast<const uint4 *>(st + j * kFullLdsStride + part * 16);
+        }
     }
 }
 

@@ -11,12 +11,26 @@
 #include "../../include/scopa.h"
 
 #define SCF_HD __host__ __device__ __forceinline__
+#if defined(__HIP_DEVICE_COMPILE__)
+#define SCF_UNROLL _Pragma("unroll")     /* the table loops: slot shifts become constants on the device; the host keeps them as loops */
+#else
+#define SCF_UNROLL
+#endif
 
 namespace scopa_full {
 
 constexpr int kMaxTable = 20;  // 2 x 10 six-bit slots
 
 SCF_HD int rank_of(int c) { return c % 10 + 1; }
+// true if the predicate holds in ANY lane of the wavefront (device) / for this state (host): the loops over the table's twenty slots stop, wave-uniformly,
+// above the longest table of the wavefront's games (tables hold 4-6 cards in play, and games advanced in lockstep have tables of similar length)
+SCF_HD bool any_lane(bool p) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return __builtin_amdgcn_ballot_w64(p) != 0ull;
+#else
+    return p;
+#endif
+}
 // The two-element arrays of the state are never indexed with a run-time value: a run-time index into a struct member sends the whole state
 // to scratch memory on the device (84 scratch accesses per step in the first form of k_full_step_batch); a select between the two words keeps
 // it in registers.
@@ -57,39 +71,42 @@ SCF_HD void state_init(scopa_full_state &s, const uint8_t *deck, uint32_t game) 
 
 // find_capture_combinations()[0] (:90-118): the first table card of the played rank if any; else the subset whose
 // membership mask is the SMALLEST integer among all subsets summing to the rank (the reference enumerates masks
-// 1, 2, 3, ... and play_card takes the first).  Smallest integer = decide bits from the top: leave card i out whenever
-// the remaining sum is still reachable with the cards below it.
-// pre[i] = sums reachable with table cards 0..i-1 (bit k = sum k, sums above 10 dropped), built ONCE in a pass up the table and read in
-// the pass down (first form: the reachable set recomputed from card 0 at every step of the way down -- quadratic in the table, behind
-// divisions by 10 for the slot of every card it touched).  Both loops are unrolled over the table's twenty slots, so slot shifts are
-// constants and pre[] / rk[] live in registers; iterations above every lane's table length are skipped by the guard.
+// 1, 2, 3, ... and play_card takes the first).
+// One pass up the table: a subset that holds card i has a larger mask than any subset of the cards below it, so the smallest mask for a sum is
+// the one found FIRST when the cards are added in table order (0/1 knapsack over the sums 0..10, kept as the 11-bit set `reach`), and it is the
+// card that first reached the sum plus the smallest mask of the rest, which was fixed earlier.  The index of that card is kept as five bit planes
+// over the sums (f[b] bit k = bit b of the index; the loop is unrolled, so which planes a card writes is a constant) and the subset is read back
+// from the played rank down, a card per step.  (First forms: the reachable sets of every prefix in twenty registers and a second pass down the
+// table; before that the set recomputed from card 0 at every step down.)  Slots above every lane's table are skipped wave-uniformly (any_lane).
 SCF_HD uint32_t capture_mask(const scopa_full_state &s, int target) {
     const int nt = s.nt;
     if (nt == 0) return 0u;
-    uint32_t pre[kMaxTable + 1];
-    int rk[kMaxTable];
-    pre[0] = 1u;
-    int match = -1;
-#pragma unroll
+    uint32_t reach = 1u, eq = 0u;                         // sums reachable so far; table cards of the played rank
+    uint32_t f[5] = {0u, 0u, 0u, 0u, 0u};
+    uint32_t rk[3] = {0u, 0u, 0u};                        // the ranks, a nibble per slot
+SCF_UNROLL
     for (int i = 0; i < kMaxTable; i++) {
-        rk[i] = 0;
-        pre[i + 1] = pre[i];
-        if (i < nt) {
-            const int r = rank_of(tab_get(s, i));
-            rk[i] = r;
-            if (r == target && match < 0) match = i;
-            pre[i + 1] = pre[i] | ((pre[i] << r) & 0x7FFu);
-        }
+        if (!any_lane(i < nt)) break;
+        const int c = tab_get(s, i);
+        const uint32_t r = i < nt ? (uint32_t)(c - 10 * ((c * 26) >> 8) + 1) : 0u;   // rank_of for c < 64; a slot above the table counts as rank 0: no match, no new sum
+        eq |= (uint32_t)(r == (uint32_t)target) << i;
+        const uint32_t fresh = (reach << r) & ~reach & 0x7FFu;
+        reach |= fresh;
+SCF_UNROLL
+        for (int b = 0; b < 5; b++) if ((i >> b) & 1) f[b] |= fresh;
+        rk[i >> 3] |= r << (4 * (i & 7));
     }
-    if (match >= 0) return 1u << match;
-    if (!((pre[kMaxTable] >> target) & 1u)) return 0u;    // (pre[kMaxTable] == pre[nt])
+    if (eq) return eq & (0u - eq);                        // the first of them
+    if (!((reach >> target) & 1u)) return 0u;
     uint32_t mask = 0u;
     int rem = target;
-#pragma unroll
-    for (int i = kMaxTable - 1; i >= 0; i--) {
-        if (i < nt && rem > 0 && !((pre[i] >> rem) & 1u)) {   // not reachable without card i: it is in
-            mask |= 1u << i;
-            rem -= rk[i];
+    for (int k = 0; k < 10; k++) {                        // ranks are >= 1: ten cards at most
+        if (!any_lane(rem > 0)) break;
+        if (rem > 0) {
+            const uint32_t idx = ((f[0] >> rem) & 1u) | (((f[1] >> rem) & 1u) << 1) | (((f[2] >> rem) & 1u) << 2) | (((f[3] >> rem) & 1u) << 3) | (((f[4] >> rem) & 1u) << 4);
+            mask |= 1u << idx;
+            const uint32_t w = idx >= 16u ? rk[2] : (idx >= 8u ? rk[1] : rk[0]);
+            rem -= (int)((w >> (4u * (idx & 7u))) & 15u);
         }
     }
     return mask;
@@ -145,21 +162,27 @@ SCF_HD void step(scopa_full_state &s, const uint8_t *deck, int action) {  // Ful
     if (pos >= 0) {  // play_card (:120-150), capture_choice None
         const uint32_t cm = capture_mask(s, rank_of(action));
         if (cm) {
-            scopa_full_state t = s;
+            uint64_t taken = 1ull << action, t0 = 0ull, t1 = 0ull;   // captured cards + the played one; the table that stays, in order
             int nk = 0;
-            t.table[0] = t.table[1] = 0;
-#pragma unroll
+SCF_UNROLL
             for (int i = 0; i < kMaxTable; i++) {
+                if (!any_lane(i < s.nt)) break;
                 if (i < s.nt) {
                     const int c = tab_get(s, i);
-                    if ((cm >> i) & 1u) cap_add(t, p, 1ull << c); else tab_set(t, nk++, c);
+                    if ((cm >> i) & 1u) taken |= 1ull << c;
+                    else {
+                        const int w = nk >= 10;
+                        const uint64_t put = (uint64_t)c << (6 * (nk - 10 * w));
+                        t0 |= w ? 0ull : put; t1 |= w ? put : 0ull;
+                        nk++;
+                    }
                 }
             }
-            cap_add(t, p, 1ull << action);
-            t.nt = (uint8_t)nk;
-            t.last_capture = (uint8_t)p;
-            if (nk == 0) { t.scopas[0] = (uint8_t)(t.scopas[0] + (p ? 0 : 1)); t.scopas[1] = (uint8_t)(t.scopas[1] + (p ? 1 : 0)); }
-            s = t;
+            s.table[0] = t0; s.table[1] = t1;
+            cap_add(s, p, taken);
+            s.nt = (uint8_t)nk;
+            s.last_capture = (uint8_t)p;
+            if (nk == 0) { s.scopas[0] = (uint8_t)(s.scopas[0] + (p ? 0 : 1)); s.scopas[1] = (uint8_t)(s.scopas[1] + (p ? 1 : 0)); }
         } else if (s.nt < kMaxTable) {
             tab_set(s, s.nt, action);
             s.nt++;

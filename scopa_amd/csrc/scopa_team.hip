@@ -26,13 +26,23 @@ k_team_step_batch(scopa_team_state *__restrict__ states, const uint8_t *__restri
     const int pieces = left >= 64 ? 160 : (int)((left * 40 + 15) / 16);             // whole 16-byte pieces covering the wavefront's states ...
     const bool tail8 = left < 64 && ((left * 40) & 15);                               // ... of which the last is half a piece when an odd number of states is left
     unsigned char *st = s_stage[wave];
+    int act = 0;                                                                         // (asked for with the states, not after them)
     const uint4 *src = reinterpret_cast<const uint4 *>(states + w0);
+    if (left >= 64) {                                   // a whole wavefront (all but the last): the three loads are issued together, unguarded
+        act = actions[w0 + lane];
+        const uint4 v0 = src[lane], v1 = src[64 + lane], v2 = src[128 + (lane & 31)];   // (the upper half re-reads the lower half's pieces: same cache lines, no branch between the loads)
+        *reinterpret_cast<uint4 *>(st + lane * 16) = v0;
+        *reinterpret_cast<uint4 *>(st + (64 + lane) * 16) = v1;
+        *reinterpret_cast<uint4 *>(st + (128 + (lane & 31)) * 16) = v2;                  // (twice the same bytes to the same place)
+    } else {
+        if (lane < left) act = actions[w0 + lane];
 #pragma unroll
-    for (int k = 0; k < 3; k++) {
-        const int c = k * 64 + lane;
-        if (c < pieces) {
-            if (tail8 && c == pieces - 1) *reinterpret_cast<uint2 *>(st + c * 16) = *reinterpret_cast<const uint2 *>(src + c);
-            else *reinterpret_cast<uint4 *>(st + c * 16) = src[c];
+        for (int k = 0; k < 3; k++) {
+            const int c = k * 64 + lane;
+            if (c < pieces) {
+                if (tail8 && c == pieces - 1) *reinterpret_cast<uint2 *>(st + c * 16) = *reinterpret_cast<const uint2 *>(src + c);
+                else *reinterpret_cast<uint4 *>(st + c * 16) = src[c];
+            }
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -40,15 +50,23 @@ k_team_step_batch(scopa_team_state *__restrict__ states, const uint8_t *__restri
         uint2 raw[5];
 #pragma unroll
         for (int k = 0; k < 5; k++) raw[k] = *reinterpret_cast<const uint2 *>(st + lane * 40 + k * 8);
-        scopa_team_state s;
-        memcpy(&s, raw, 40);
-        step(s, actions[w0 + lane]);
-        memcpy(raw, &s, 40);
+        uint32_t w[10];
+#pragma unroll
+        for (int k = 0; k < 5; k++) { w[2 * k] = raw[k].x; w[2 * k + 1] = raw[k].y; }
+        step_words(w, act);
+#pragma unroll
+        for (int k = 0; k < 5; k++) raw[k] = make_uint2(w[2 * k], w[2 * k + 1]);
 #pragma unroll
         for (int k = 0; k < 5; k++) *reinterpret_cast<uint2 *>(st + lane * 40 + k * 8) = raw[k];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     uint4 *dst = reinterpret_cast<uint4 *>(states + w0);
+    if (left >= 64) {
+        dst[lane] = *reinterpret_cast<const uint4 *>(st + lane * 16);
+        dst[64 + lane] = *reinterpret_cast<const uint4 *>(st + (64 + lane) * 16);
+        if (lane < 32) dst[128 + lane] = *reinterpret_cast<const uint4 *>(st + (128 + lane) * 16);
+        return;
+    }
 #pragma unroll
     for (int k = 0; k < 3; k++) {
         const int c = k * 64 + lane;

@@ -47,14 +47,23 @@ SC_HD int r2_team0_of(const scopa_team_state &s) {
     return t0 - t1;   // total == 0 gives 0 like the reference's special case
 }
 
-// TPIMiniScopaState.apply_action (:88-92) + TeamMiniScopaEnv.step (:173-201) + play_card (:111-123)
-SC_HD void step(scopa_team_state &s, int action) {
-    if (is_terminal(s)) return;  // _was_dead_step; the packed history holds the 16 plies of a game only
+// TPIMiniScopaState.apply_action (:88-92) + TeamMiniScopaEnv.step (:173-201) + play_card (:111-123), on the state's ten 32-bit words:
+//   w0, w1 history | w2 table | w3 = hand[0] | hand[1] << 16, w4 = hand[2] | hand[3] << 16 | w5, w6 = cap likewise | w7 = nh[0..3], a byte each |
+//   w8 = scopas[0..3] | w9 = nt | step << 8 | last_capture_team << 16 | flags << 24.
+// The seat's fields are picked with selects and shifts (indexing the struct's arrays with the run-time seat had sent the whole state to LDS in
+// k_team_step_batch, a second staging buffer's worth; round 4, as scopa::step_words).
+SC_HD void step_words(uint32_t (&w)[10], int action) {
+    if (w[9] & ((uint32_t)kTerminal << 24)) return;  // _was_dead_step; the packed history holds the 16 plies of a game only
     action &= 15;
-    s.history |= (uint64_t)action << (4 * s.step);
-    const int seat = seat_to_move(s);
-    const uint32_t hand = s.hand[seat];
-    const int nh = s.nh[seat];
+    const uint32_t stepc = (w[9] >> 8) & 255u, seat = stepc & 3u;
+    uint32_t nt = w[9] & 255u;
+    const uint32_t hbits = (uint32_t)action << (4u * (stepc & 7u));
+    w[0] |= (stepc & 8u) ? 0u : hbits;
+    w[1] |= (stepc & 8u) ? hbits : 0u;
+    const bool hi = (seat & 2u) != 0u;
+    const uint32_t sh16 = 16u * (seat & 1u), sh8 = 8u * seat;
+    const uint32_t hand = ((hi ? w[4] : w[3]) >> sh16) & 0xFFFFu;
+    const int nh = (int)((w[7] >> sh8) & 255u);
     int pos = -1;
 #pragma unroll
     for (int i = 3; i >= 0; i--)
@@ -62,36 +71,55 @@ SC_HD void step(scopa_team_state &s, int action) {
     if (pos >= 0) {
         // the table never holds two cards of one rank (an equal rank always captures), hence at most 8 cards: MiniScopa's
         // 8-slot capture rule applies unchanged
-        const uint32_t cap = scopa::capture_mask(s.table, s.nt, card_rank(action));
+        const uint32_t cap = scopa::capture_mask(w[2], (int)nt, card_rank(action));
         if (cap) {
             uint32_t nt_new = 0, tab = 0, taken = 1u << action;
 #pragma unroll
-            for (int i = 0; i < 8; i++)
-                if (i < s.nt) {
-                    const int c = nib(s.table, i);
+            for (int i = 0; i < 8; i++) {
+                if (!scopa::sc_any(i < (int)nt)) break;
+                if (i < (int)nt) {
+                    const uint32_t c = (uint32_t)nib(w[2], i);
                     if ((cap >> i) & 1u) taken |= 1u << c;
-                    else { tab |= (uint32_t)c << (4 * nt_new); nt_new++; }
+                    else { tab |= c << (4 * nt_new); nt_new++; }
                 }
-            s.cap[seat] = (uint16_t)(s.cap[seat] | taken);
-            s.table = tab; s.nt = (uint8_t)nt_new;
-            s.last_capture_team = (uint8_t)(seat >> 1);
-            if (nt_new == 0) s.scopas[seat]++;
-        } else if (s.nt < 8) {
-            s.table |= (uint32_t)action << (4 * s.nt);
-            s.nt++;
-        } else s.flags |= kTableOverflow;  // unreachable by the argument above; kept loud rather than silent
-        s.hand[seat] = (uint16_t)scopa::nib_remove(hand, pos);
-        s.nh[seat] = (uint8_t)(nh - 1);
+            }
+            w[5] |= hi ? 0u : taken << sh16;
+            w[6] |= hi ? taken << sh16 : 0u;
+            w[2] = tab; nt = nt_new;
+            w[9] = (w[9] & ~(255u << 16)) | ((seat >> 1) << 16);                                          // last_capture_team
+            if (nt_new == 0) w[8] = (w[8] & ~(255u << sh8)) | ((((w[8] >> sh8) + 1u) & 255u) << sh8);     // scopas[seat]++ (uint8)
+        } else if (nt < 8u) {
+            w[2] |= (uint32_t)action << (4u * nt);
+            nt++;
+        } else w[9] |= (uint32_t)kTableOverflow << 24;  // unreachable by the argument above; kept loud rather than silent
+        const uint32_t left = scopa::nib_remove(hand, pos) & 0xFFFFu;
+        if (hi) w[4] = (w[4] & ~(0xFFFFu << sh16)) | (left << sh16);
+        else    w[3] = (w[3] & ~(0xFFFFu << sh16)) | (left << sh16);
+        w[7] -= 1u << sh8;                                                                                 // nh[seat]-- (nh >= 1 here)
     }  // else: card not in hand -> silent no-op that still consumes the turn (:184-186)
-    s.step++;
-    if ((s.nh[0] | s.nh[1] | s.nh[2] | s.nh[3]) == 0 || s.step >= kPlies) {
-        s.flags |= kTerminal;
-        if (s.nt > 0 && s.last_capture_team != 0xFF) {  // leftovers to the first seat of the last capturing team (:133-139)
+    const uint32_t step_new = (stepc + 1u) & 255u;
+    w[9] = (w[9] & 0xFFFF0000u) | (step_new << 8) | (nt & 255u);
+    if (w[7] == 0u || step_new >= (uint32_t)kPlies) {
+        w[9] |= (uint32_t)kTerminal << 24;
+        const uint32_t lct = (w[9] >> 16) & 255u;
+        if (nt > 0u && lct != 0xFFu) {  // leftovers to the first seat of the last capturing team (:133-139)
             uint32_t m = 0;
-            for (int i = 0; i < s.nt; i++) m |= 1u << nib(s.table, i);
-            s.cap[s.last_capture_team * 2] = (uint16_t)(s.cap[s.last_capture_team * 2] | m);
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (!scopa::sc_any(i < (int)nt)) break;
+                if (i < (int)nt) m |= 1u << nib(w[2], i);
+            }
+            w[5] |= (lct & 1u) ? 0u : m;
+            w[6] |= (lct & 1u) ? m : 0u;
         }
     }
+}
+
+SC_HD void step(scopa_team_state &s, int action) {
+    uint32_t w[10];
+    memcpy(w, &s, 40);
+    step_words(w, action);
+    memcpy(&s, w, 40);
 }
 
 }  // namespace scopa_team
