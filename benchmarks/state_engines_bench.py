@@ -46,7 +46,7 @@ def report(name, n, bytes_step, times, extra):
             "seconds_per_ply": times, **extra}
 
 
-def measure(ctx, n_mini=1 << 26, n_team=1 << 25, n_full=1 << 24, n_pool=4096, stream=None, device=0):
+def measure(ctx, n_mini=1 << 26, n_team=1 << 25, n_full=1 << 24, n_pool=4096, stream=None, device=0, warm_up=True):
     """The three engines on context `ctx`; stream: the torch stream the context launches on (event timing), or None (host clock)."""
     import types
     import torch
@@ -69,8 +69,9 @@ def measure(ctx, n_mini=1 << 26, n_team=1 << 25, n_full=1 << 24, n_pool=4096, st
             pool[i]["nh"] = (4, 4)
         base = torch.from_numpy(pool.view(np.uint8).reshape(pool.size, 16)).to(dev)
         st = base.repeat((a.mini + pool.size - 1) // pool.size, 1)[:a.mini].contiguous()
-        warm = base.clone(); wact = torch.zeros(pool.size, dtype=torch.uint8, device=dev)
-        ctx.step_batch(warm.data_ptr(), wact.data_ptr(), pool.size); ctx.synchronize()   # the kernel's first launch loads its code object: not a ply's time
+        if warm_up:                                                    # the kernel's first launch loads its code object: not a ply's time
+            warm = base.clone(); wact = torch.zeros(pool.size, dtype=torch.uint8, device=dev)
+            ctx.step_batch(warm.data_ptr(), wact.data_ptr(), pool.size); ctx.synchronize()
         times = []
         for ply in range(8):
             mover = ply & 1
@@ -92,8 +93,9 @@ def measure(ctx, n_mini=1 << 26, n_team=1 << 25, n_full=1 << 24, n_pool=4096, st
             pool[i] = _lib.TeamState(seed=i).s[0]
         base = torch.from_numpy(pool.view(np.uint8).reshape(pool.size, 40)).to(dev)
         st = base.repeat((a.team + pool.size - 1) // pool.size, 1)[:a.team].contiguous()
-        warm = base.clone(); wact = torch.zeros(pool.size, dtype=torch.uint8, device=dev)
-        ctx.team_step_batch(warm.data_ptr(), wact.data_ptr(), pool.size); ctx.synchronize()
+        if warm_up:
+            warm = base.clone(); wact = torch.zeros(pool.size, dtype=torch.uint8, device=dev)
+            ctx.team_step_batch(warm.data_ptr(), wact.data_ptr(), pool.size); ctx.synchronize()
         times = []
         for ply in range(16):
             seat = ply & 3                                             # hand[4] u16 at bytes 12..19, nh[4] at bytes 28..31
@@ -119,8 +121,9 @@ def measure(ctx, n_mini=1 << 26, n_team=1 << 25, n_full=1 << 24, n_pool=4096, st
         d_decks = torch.from_numpy(decks).to(dev)
         base = torch.from_numpy(pool.view(np.uint8).reshape(pool.size, 64)).to(dev)
         st = base.repeat((a.full + pool.size - 1) // pool.size, 1)[:a.full].contiguous()
-        warm = base.clone(); wact = torch.zeros(fpool, dtype=torch.uint8, device=dev)
-        ctx.full_step_batch(warm.data_ptr(), wact.data_ptr(), d_decks.data_ptr(), fpool); ctx.synchronize()
+        if warm_up:
+            warm = base.clone(); wact = torch.zeros(fpool, dtype=torch.uint8, device=dev)
+            ctx.full_step_batch(warm.data_ptr(), wact.data_ptr(), d_decks.data_ptr(), fpool); ctx.synchronize()
         times, plies = [], 0
         for ply in range(40):
             if bool((st[:1 << 16, 54] != 0).all()):                   # terminal flag of a sample: every game has the same length
@@ -148,12 +151,13 @@ def main():
     ap.add_argument("--full", type=int, default=1 << 24)
     ap.add_argument("--pool", type=int, default=4096)
     ap.add_argument("--host-clock", action="store_true", help="time launches with the host clock between synchronisations instead of HIP events")
+    ap.add_argument("--no-warm-up", action="store_true", help="no small first launch per kernel (under a profiler, whose per-kernel averages would mix it in)")
     a = ap.parse_args()
     import torch
     from scopa_amd import _lib
     stream = None if a.host_clock else torch.cuda.Stream()
     ctx = _lib.Context(0, stream=stream.cuda_stream if stream is not None else None)
-    print(json.dumps(measure(ctx, a.mini, a.team, a.full, a.pool, stream)))
+    print(json.dumps(measure(ctx, a.mini, a.team, a.full, a.pool, stream, warm_up=not a.no_warm_up)))
 
 
 if __name__ == "__main__":

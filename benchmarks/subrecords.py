@@ -140,7 +140,7 @@ def sdcfr_large_batch(device=0, batch=32768, launches=8):
                                  "SURVEY 8(d)'s 412 B/visit is not a bound here (features, masks and advantages never reach HBM: the policy table is LDS-resident)"}}
 
 
-def state_engines(device=0, n_mini=1 << 24, n_team=1 << 23, n_full=1 << 22):
+def state_engines(device=0, n_mini=1 << 24, n_team=1 << 24, n_full=1 << 23):   # the sizes tests/tools/stats_extra.sh and pmc_state_engines.sh profile
     import torch
     from scopa_amd import _lib
     from benchmarks import state_engines_bench as seb

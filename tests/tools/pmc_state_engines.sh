@@ -13,9 +13,11 @@ import csv, collections, json
 games = {"k_step_batch": ${MINI:-16777216}, "k_team_step_batch": ${TEAM:-16777216}, "k_full_step_batch": ${FULL:-8388608}}
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for P in "afw":
-    for r in csv.DictReader(open("$OUT/%s/counters.csv" % P)):
-        k = r["Kernel_Name"].split("(")[0].replace("void ", "")
-        if int(r["Grid_Size"]) < games[k]: continue          # the bench's warm-up launch of each kernel (a pool's worth of games)
+    rows = [(r["Kernel_Name"].split("(")[0].replace("void ", ""), int(r["Grid_Size"]), r) for r in csv.DictReader(open("$OUT/%s/counters.csv" % P))]
+    full = collections.defaultdict(int)
+    for k, g, r in rows: full[k] = max(full[k], g)
+    for k, g, r in rows:
+        if g < full[k]: continue                             # the bench's warm-up launch of each kernel (a pool's worth of games)
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 out = {}
 for k, c in acc.items():

@@ -5,7 +5,7 @@ set -euo pipefail
 ROOT="${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/../.." && pwd)}"
 O="$ROOT/gpurun_out/stats_extra"; rm -rf "$O"; mkdir -p "$O"; cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/train" -o s -- python3 "$ROOT/tests/tools/sdcfr_train_breakdown.py" > "$O/train.log" 2>&1 || exit 1
-rocprofv3 --kernel-trace --stats --output-format csv -d "$O/engines" -o s -- python3 "$ROOT/benchmarks/state_engines_bench.py" --mini 16777216 --team 16777216 --full 8388608 > "$O/engines.json" 2> "$O/engines.err" || exit 1
+rocprofv3 --kernel-trace --stats --output-format csv -d "$O/engines" -o s -- python3 "$ROOT/benchmarks/state_engines_bench.py" --no-warm-up --mini 16777216 --team 16777216 --full 8388608 > "$O/engines.json" 2> "$O/engines.err" || exit 1
 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/eval" -o s -- python3 "$ROOT/benchmarks/eval_bench.py" --episodes 4194304 > "$O/eval.json" 2> "$O/eval.err" || exit 1
 rm -f "$O"/*/*kernel_trace.csv
 python3 - <<PY
