@@ -22,8 +22,9 @@ for P in "afw":
 out = {}
 for k, c in acc.items():
     m = {n: sum(v) / len(v) for n, v in c.items()}; n = games[k]
-    out[k] = {"games": n, "launches": len(c["SQ_WAVES"]), "valu_instr_per_wave_step": m["SQ_INSTS_VALU"] / m["SQ_WAVES"], "salu_instr_per_wave_step": m["SQ_INSTS_SALU"] / m["SQ_WAVES"],
-              "vmem_rd_per_wave_step": m["SQ_INSTS_VMEM_RD"] / m["SQ_WAVES"], "vmem_wr_per_wave_step": m["SQ_INSTS_VMEM_WR"] / m["SQ_WAVES"],
+    ws = m["SQ_WAVES"] * max(1.0, n / (64.0 * m["SQ_WAVES"]))      # wavefront-steps per launch (k_step_batch strides over the games: 32 steps per wavefront here)
+    out[k] = {"games": n, "launches": len(c["SQ_WAVES"]), "steps_per_wave": ws / m["SQ_WAVES"], "valu_instr_per_wave_step": m["SQ_INSTS_VALU"] / ws, "salu_instr_per_wave_step": m["SQ_INSTS_SALU"] / ws,
+              "vmem_rd_per_wave_step": m["SQ_INSTS_VMEM_RD"] / ws, "vmem_wr_per_wave_step": m["SQ_INSTS_VMEM_WR"] / ws,
               "valu_busy_share": 4.0 * m["SQ_ACTIVE_INST_VALU"] / 1024.0 / (m["SQ_BUSY_CYCLES"] / 32.0),
               "fetch_bytes_per_game_step_raw_x2": 2.0 * 1024.0 * m["FETCH_SIZE"] / n, "write_bytes_per_game_step": 1024.0 * m["WRITE_SIZE"] / n, "per_launch_mean": m}
     print(k, {a: (round(b, 2) if isinstance(b, float) else b) for a, b in out[k].items() if a != "per_launch_mean"})
