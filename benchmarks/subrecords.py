@@ -186,13 +186,18 @@ def evaluator(device=0, episodes=1 << 22, cfr_iterations=200):
     finally:
         ctx.close()
     f = by_form["integer thresholds per infoset (scopa_eval_tabular_prepare)"]
+    c = (_profile("pmc_eval.json") or {}).get("thresholds") or {}
+    per_ply = (c.get("fetch_bytes_per_episode_ply_raw_x2", 0) + c.get("write_bytes_per_episode_ply", 0)) or None
     return {"kernel": "k_eval_tabular_step", "workload": f"{episodes} episodes of 'average policy after {cfr_iterations} vanilla-CFR iterations vs uniform random', seats swapped at "
             "half time, eight launches (one per ply), one lane per episode", "episodes": episodes, "episodes_per_s": f["episodes_per_s"],
             "seconds_8_launches": f["seconds_8_launches"], "reward_vs_random": reward, "by_sampling_form": by_form,
-            "roofline": {"bound": "hbm", "achieved": f["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f["frac_of_hbm_peak"], "traffic": None,
-                         "algorithmic_bytes_per_episode_ply": 44,
+            "roofline": {"bound": "hbm", "achieved": f["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f["frac_of_hbm_peak"],
+                         "traffic": per_ply * episodes if per_ply else None,
+                         "traffic_source": "profiles/pmc_eval.json (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, per episode-ply; tests/tools/pmc_eval.sh) x episodes per launch" if per_ply else None,
+                         "valu_busy_share": c.get("valu_busy_share"), "algorithmic_bytes_per_episode_ply": 44,
                          "note": "achieved = 44 B per episode-ply (16-byte state in and out, 4-byte tree index in and out, 4-byte seat) x episodes x 8 / the eight launches; "
-                                 "the 32-byte policy rows come from cache.  No PMC pass of this kernel has been taken"}}
+                                 "the 32-byte policy rows come from cache (measured traffic = 44 B).  The launch is VALU-bound, not HBM-bound: the vector unit is busy 0.97 of the time (245 instructions per wavefront: "
+                                 "the move itself + Philox4x32-10 + the 64-bit threshold compares)"}}
 
 
 def all_records(device=0):

@@ -90,15 +90,20 @@ k_team_random_playouts(const int64_t *__restrict__ seeds, long long n, int8_t *_
     g.shuffle(perm, 16);
     scopa_team_state s;
     state_init(s, perm);
-    for (int ply = 0; ply < kPlies && !is_terminal(s); ply++) {
-        const int seat = seat_to_move(s), nl = s.nh[seat];
+    uint32_t w[10];                                                   // the state as words (scopa_team_rules.h): no run-time index into the struct
+    memcpy(w, &s, 40);
+    for (int ply = 0; ply < kPlies && !(w[9] & ((uint32_t)kTerminal << 24)); ply++) {
+        const uint32_t seat = (w[9] >> 8) & 3u;
+        const int nl = (int)((w[7] >> (8u * seat)) & 255u);
+        const uint32_t hand = (((seat & 2u) ? w[4] : w[3]) >> (16u * (seat & 1u))) & 0xFFFFu;
         const scopa::philox_out x = scopa::philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)ply, 48u, seed_lo, seed_hi);
         int k = (int)(scopa::u53(x.x0, x.x1) * (double)(nl > 0 ? nl : 1));
         k = k < nl - 1 ? k : (nl > 0 ? nl - 1 : 0);
-        step(s, nl > 0 ? nib(s.hand[seat], k) : 0);
+        step_words(w, nl > 0 ? nib(hand, k) : 0);
     }
+    memcpy(&s, w, 40);
     r2_team0[i] = (int8_t)r2_team0_of(s);
-    for (int p = 0; p < 4; p++) scopas[i * 4 + p] = s.scopas[p];
+    *reinterpret_cast<uint32_t *>(scopas + i * 4) = w[8];
 }
 
 extern "C" {

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # The round's profile set in one call on the GPU box: the MCCFR passes (profile_round.sh: kernel stats of the bench command with its sub-records, FETCH_SIZE /
 # WRITE_SIZE, SQ counters at two batches), the SDCFR passes at both batches (profile_sdcfr.sh), the lanes kernel's passes with the counter calibration
-# (profile_lanes.sh) the kernel stats of the other kernels (stats_extra.sh) and the counter passes of the three step kernels (pmc_state_engines.sh -> gpurun_out/pmc_engines/summary.json, kept as profiles/<tag>_pmc_state_engines.json).  Any failing step stops the script with a non-zero status.
+# (profile_lanes.sh) the kernel stats of the other kernels (stats_extra.sh) and the counter passes of the three step kernels (pmc_state_engines.sh -> gpurun_out/pmc_engines/summary.json, kept as profiles/<tag>_pmc_state_engines.json) and of the evaluator (pmc_eval.sh -> profiles/pmc_eval.json).  Any failing step stops the script with a non-zero status.
 #     gpurun --timeout 1200 -- 'bash tests/tools/profile_all.sh'
 # then, in the build container:  python tests/tools/fold_profiles.py gpurun_out/prof r04 && python tests/tools/fold_lanes.py gpurun_out/lanes r04
 set -euo pipefail
@@ -22,4 +22,6 @@ bash tests/tools/stats_extra.sh > gpurun_out/stats_extra.log 2>&1 || { tail -20 
 cat gpurun_out/stats_extra.log
 bash tests/tools/pmc_state_engines.sh > gpurun_out/pmc_engines.log 2>&1 || { tail -20 gpurun_out/pmc_engines.log; exit 1; }
 cat gpurun_out/pmc_engines.log
+bash tests/tools/pmc_eval.sh > gpurun_out/pmc_eval.log 2>&1 || { tail -20 gpurun_out/pmc_eval.log; exit 1; }
+cat gpurun_out/pmc_eval.log
 du -sh gpurun_out/prof gpurun_out/prof_sdcfr_b* gpurun_out/lanes gpurun_out/stats_extra
