@@ -1,8 +1,8 @@
 #!/usr/bin/env python3
 """The on-device evaluator (evaluate_agent, vanilla_cfr.py:157-216 / mc_cfr.py:146-206): episodes of "tabular average policy vs
 uniform random, seats swapped at half time" advanced in lockstep, one lane per episode, one launch per ply (k_eval_tabular_step: 16-byte state
-in / out, 4-byte tree index in / out, 4-byte seat, a 32-byte policy row from cache = 44 algorithmic bytes per episode-ply).  Reports episodes/s and
-achieved GB/s of the eight launches, and the estimate next to the exact expectation from tree enumeration.
+in / out, 4-byte tree index in / out, 4-byte seat, a 32-byte policy row from cache = 44 algorithmic bytes per episode-ply), or the whole match in one launch
+as walks over the deal's tree (k_eval_tabular_match: what evaluate_agent_device runs).  Reports episodes/s of both and achieved GB/s of the eight launches.
     python benchmarks/eval_bench.py [--episodes 16777216]"""
 import argparse, json, os, sys, time
 import numpy as np
@@ -34,6 +34,16 @@ def measure_kernels(ctx, pol, n, stream=None, device=0):
                 t0 = time.perf_counter(); call(); ctx.synchronize(); times.append(time.perf_counter() - t0)
         by_form[form] = {"seconds_8_launches": sum(times), "episodes_per_s": n / sum(times), "achieved_GBps": 8 * n * 44 / sum(times) / 1e9,
                          "frac_of_hbm_peak": 8 * n * 44 / sum(times) / 1e9 / 8000.0, "seconds_per_ply": times}
+    # the one-launch form (scopa_eval_tabular_match): synchronous, so the host clock around the call = launch + kernel + the 80-byte statistics copy
+    ctx.eval_tabular_prepare(pol.data_ptr())
+    ctx.eval_tabular_match(min(n, 4096), min(n, 4096) // 2, 16)
+    best = float("inf")
+    for _ in range(5):
+        t0 = time.perf_counter(); st = ctx.eval_tabular_match(n, (n + 1) // 2, 16); best = min(best, time.perf_counter() - t0)
+    m, r2 = int(st[:, 0].sum()), int(st[:, 1].sum())
+    by_form["one launch: walks over the deal's tree nodes, statistics summed in the kernel (scopa_eval_tabular_match)"] = {
+        "seconds_call": best, "episodes_per_s": n / best, "reward_vs_random": r2 / 2 / m,
+        "note": "host clock around the synchronous call (launch + kernel + statistics copy), best of 5; no state traffic per ply: 6 Philox draws and <= 3 threshold compares per episode"}
     return by_form, states
 
 
@@ -62,7 +72,7 @@ def main():
                       "reward_std_error": stats["reward_std_error"], "scopas_trained_vs_random": [stats["trained_avg"], stats["opponent_avg"]],
                       "seconds_8_launches": k, "seconds_per_ply": times, "episodes_per_s_kernels": n / k, "episode_plies_per_s": 8 * n / k,
                       "algorithmic_bytes_per_episode_ply": 44, "by_sampling_form": by_form, "achieved_GBps": 8 * n * 44 / k / 1e9, "frac_of_hbm_peak": 8 * n * 44 / k / 1e9 / 8000.0,
-                      "evaluate_agent_device_wall_s": wall, "episodes_per_s_incl_host_statistics": n / wall,
+                      "evaluate_agent_device_wall_s": wall, "episodes_per_s_evaluate_agent_device": n / wall,
                       "reference_python_episodes_per_s": "~550 (500 episodes every 5 iterations dominate run_mccfr_experiment.py; BASELINE.md section 2)"}))
 
 

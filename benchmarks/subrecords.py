@@ -190,7 +190,9 @@ def evaluator(device=0, episodes=1 << 22, cfr_iterations=200):
     per_ply = (c.get("fetch_bytes_per_episode_ply_raw_x2", 0) + c.get("write_bytes_per_episode_ply", 0)) or None
     return {"kernel": "k_eval_tabular_step", "workload": f"{episodes} episodes of 'average policy after {cfr_iterations} vanilla-CFR iterations vs uniform random', seats swapped at "
             "half time, eight launches (one per ply), one lane per episode", "episodes": episodes, "episodes_per_s": f["episodes_per_s"],
-            "seconds_8_launches": f["seconds_8_launches"], "reward_vs_random": reward, "by_sampling_form": by_form,
+            "seconds_8_launches": f["seconds_8_launches"], "reward_vs_random": reward,
+            "episodes_per_s_one_launch_match": by_form["one launch: walks over the deal's tree nodes, statistics summed in the kernel (scopa_eval_tabular_match)"]["episodes_per_s"],
+            "by_sampling_form": by_form,
             "roofline": {"bound": "hbm", "achieved": f["achieved_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": f["frac_of_hbm_peak"],
                          "traffic": per_ply * episodes if per_ply else None,
                          "traffic_source": "profiles/pmc_eval.json (FETCH_SIZE doubled per the guide's gfx950 correction + WRITE_SIZE, per episode-ply; tests/tools/pmc_eval.sh) x episodes per launch" if per_ply else None,

@@ -261,6 +261,13 @@ int32_t scopa_eval_step(scopa_ctx *ctx, scopa_state *d_states, int64_t n, const 
 int32_t scopa_eval_tabular_prepare(scopa_ctx *ctx, const double *d_policy);
 int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *d_node_idx, int64_t n, int32_t ply,
                                 const double *d_policy, const int32_t *d_trained_seat, uint32_t stream_id);
+/* the whole match of the PREPARED tabular policy vs uniform random in one launch (evaluate_agent's loop, vanilla_cfr.py:173-216): episodes i < n_seat0 have the
+ * policy in seat 0, the rest in seat 1; the same Philox draws and thresholds as eight scopa_eval_tabular_step calls, hence the same episodes bit for bit, walked
+ * as node indices of the deal's tree with no per-ply state traffic.  h_stats[seat][5] = episodes, sum of the trained side's rewards x2, sum of their squares,
+ * sum of its scopas, sum of the opponent's (integers: every reward is a multiple of 0.5).  d_states_out[n] / d_node_idx_out[n]: the final states / terminal
+ * indices as the per-ply form leaves them, or NULL.  Synchronous. */
+int32_t scopa_eval_tabular_match(scopa_ctx *ctx, int64_t n, int64_t n_seat0, uint32_t stream_id, scopa_state *d_states_out, int32_t *d_node_idx_out,
+                                 int64_t h_stats[10]);
 
 /* ---- policy value / exploitability (build-defined; the reference only calls OpenSpiel's, vanilla_cfr.py:112-118) --
  * h_policy[n_infosets][4] or NULL = the average policy of the strategy table (InfoNode.policy, vanilla_cfr.py:32-39).

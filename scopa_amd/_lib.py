@@ -27,7 +27,7 @@ SYMBOLS = [
     "scopa_mccfr_iterate", "scopa_mccfr_traverse", "scopa_mccfr_delta_buffer", "scopa_mccfr_bind_delta", "scopa_mccfr_delta_get", "scopa_mccfr_delta_set", "scopa_mccfr_apply",
     "scopa_mccfr_iteration_counter", "scopa_mccfr_graph_mode", "scopa_debug_lds_limit", "scopa_sdcfr_frontier_width", "scopa_sdcfr_features", "scopa_sdcfr_expand",
     "scopa_sdcfr_terminal_values", "scopa_sdcfr_backward", "scopa_sdcfr_visits", "scopa_sdcfr_traverse_fused", "scopa_sdcfr_image_floats", "scopa_sdcfr_pack_weights", "scopa_sdcfr_tuning", "scopa_sdcfr_mode", "scopa_sdcfr_train_params", "scopa_sdcfr_train_step", "scopa_sdcfr_train_steps", "scopa_features_from_states",
-    "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_eval_tabular_prepare", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
+    "scopa_eval_init_states", "scopa_eval_step", "scopa_eval_tabular_step", "scopa_eval_tabular_prepare", "scopa_eval_tabular_match", "scopa_cfr_sync_iterate", "scopa_multi_create", "scopa_multi_destroy",
     "scopa_multi_deal_py_seeds", "scopa_multi_set_perms", "scopa_multi_perms_get", "scopa_multi_build", "scopa_multi_cfr_exact_iterate",
     "scopa_multi_cfr_exact_iterate_lanes", "scopa_multi_cfr_sync_iterate", "scopa_multi_mccfr_iterate", "scopa_multi_exploitability", "scopa_multi_tables_get", "scopa_multi_counters", "scopa_full_deal_py_seed",
     "scopa_full_state_init", "scopa_full_state_step", "scopa_full_state_legal", "scopa_full_state_infoset_string",
@@ -144,6 +144,7 @@ def lib():
         "scopa_eval_step": (i32, [vp, vp, i64, vp, vp, u32, u32]),
         "scopa_eval_tabular_step": (i32, [vp, vp, vp, i64, i32, vp, vp, u32]),
         "scopa_eval_tabular_prepare": (i32, [vp, vp]),
+        "scopa_eval_tabular_match": (i32, [vp, i64, i64, u32, vp, vp, vp]),
         "scopa_cfr_sync_iterate": (i32, [vp, i32]),
         "scopa_multi_create": (i32, [vp, i32, C.POINTER(vp)]),
         "scopa_multi_destroy": (i32, [vp]),
@@ -472,6 +473,14 @@ class Context:
     def eval_tabular_step(self, states_ptr, idx_ptr, n, ply, policy_ptr, seat_ptr, stream_id):
         self._ck(self._L.scopa_eval_tabular_step(self._h, C.c_void_p(states_ptr), C.c_void_p(idx_ptr), n, ply, C.c_void_p(policy_ptr) if policy_ptr else None,
                                                  C.c_void_p(seat_ptr), stream_id), "scopa_eval_tabular_step")
+
+    def eval_tabular_match(self, n, n_seat0, stream_id, states_ptr=0, idx_ptr=0):
+        """the whole match of the prepared policy vs uniform random in one launch -> int64 [2][5]: per seat half (episodes, sum r x2, sum (r x2)^2,
+        sum trained scopas, sum opponent scopas); optionally the final states / terminal indices into device buffers"""
+        st = np.zeros((2, 5), np.int64)
+        self._ck(self._L.scopa_eval_tabular_match(self._h, int(n), int(n_seat0), stream_id, C.c_void_p(states_ptr) if states_ptr else None,
+                                                  C.c_void_p(idx_ptr) if idx_ptr else None, _ptr(st)), "scopa_eval_tabular_match")
+        return st
 
     def cfr_sync_iterate(self, n_iters):
         self._ck(self._L.scopa_cfr_sync_iterate(self._h, int(n_iters)), "scopa_cfr_sync_iterate")

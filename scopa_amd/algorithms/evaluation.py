@@ -2,9 +2,9 @@
 
 The reference's evaluate_agent (vanilla_cfr.py:157-216, mc_cfr.py:146-206) plays episodes one by one in Python and is
 where its experiment scripts spend most of their wall time (500 episodes every 5 iterations,
-run_mccfr_experiment.py:101-105).  Here all episodes advance in lockstep: the packed states are stepped by the device
-step function, the trained seat's action comes from its policy row (np.random.choice arithmetic) and the opponent's is
-uniform.  Seats are swapped at half time as in the reference.  Draws are Philox, so the numbers are statistically -- not
+run_mccfr_experiment.py:101-105).  Here all episodes of a match run in one launch as walks over the deal's tree (or, per_ply,
+advance in lockstep as packed states stepped by the device step function): the trained seat's action comes from its policy
+row (np.random.choice arithmetic) and the opponent's is uniform.  Seats are swapped at half time as in the reference.  Draws are Philox, so the numbers are statistically -- not
 bitwise -- equivalent to the reference's np.random stream; `evaluate_agent` in vanilla_cfr / mc_cfr remains the
 bit-reproducing host version."""
 import numpy as np
@@ -58,8 +58,25 @@ def head_to_head(game, trained_policy, opponent_policy, num_episodes, choose=Non
     return tally.result(num_episodes)
 
 
-def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16):
-    """-> (avg_reward, scopa_stats) for `trainer`'s average policy (or an explicit [n_infosets][4] table)."""
+def _halves_from_sums(st):
+    """per seat half of a match, from the integer sums scopa_eval_tabular_match returns (episodes, sum r x2, sum (r x2)^2, scopas of either side)"""
+    out = []
+    for m, r2, q2, t, o in st.tolist():
+        if m:
+            var4 = max(m * q2 - r2 * r2, 0) / (m * m)                        # 4 x the variance, from exact integers
+            out.append({"episodes": m, "reward": r2 / 2 / m, "reward_std_error": float(np.sqrt(var4) / 2 / np.sqrt(m)),
+                        "trained_scopas": t / m, "opponent_scopas": o / m})
+        else:
+            out.append({"episodes": 0, "reward": 0.0, "reward_std_error": 0.0, "trained_scopas": 0.0, "opponent_scopas": 0.0})
+    return out
+
+
+def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16, per_ply=False):
+    """-> (avg_reward, scopa_stats) for `trainer`'s average policy (or an explicit [n_infosets][4] table).
+
+    Default: the whole match in ONE launch (scopa_eval_tabular_match) -- every episode plays the trainer's deal, so it is a walk over the deal's
+    tree nodes, and the statistics are summed on the device as integers.  per_ply=True: the same episodes bit for bit (same draws, same thresholds)
+    as eight launches of the packed-state step kernel with the statistics reduced by torch -- the form whose states stay inspectable between plies."""
     import torch
     eng = trainer._engine
     ctx = eng.ctx
@@ -68,12 +85,23 @@ def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16
         policy = ctx.exploitability(return_policy=True)["policy"]     # the average policy, computed on device
     dev = f"cuda:{ctx.device}"
     pol = torch.as_tensor(np.ascontiguousarray(policy, np.float64), device=dev)
+    first = (n + 1) // 2                                              # episodes e < n / 2: the trained agent sits in seat 0 (vanilla_cfr.py:173-176)
+    if n == 0:
+        return 0.0, {"trained_avg": 0.0, "opponent_avg": 0.0, "difference": 0.0, "data_collected": False, "reward_std_error": 0.0, "by_seat": _halves_from_sums(np.zeros((2, 5), np.int64))}
+    torch.cuda.synchronize()
+    ctx.eval_tabular_prepare(pol.data_ptr())                  # the policy's sampling thresholds, once: the plies compare integers (same actions, bit for bit)
+    if not per_ply:
+        st = ctx.eval_tabular_match(n, first, stream_id)
+        m, r2, q2, t, o = (int(x) for x in st.sum(axis=0))
+        var4 = max(m * q2 - r2 * r2, 0) / (m * m)
+        stats = {"trained_avg": t / m, "opponent_avg": o / m, "difference": t / m - o / m, "data_collected": True,
+                 "reward_std_error": float(np.sqrt(var4) / 2 / np.sqrt(m)), "by_seat": _halves_from_sums(st)}
+        return r2 / 2 / m, stats
     states = torch.zeros((n, 4), dtype=torch.int32, device=dev)
     ctx.eval_init_states(states.data_ptr(), n)
     idx = torch.zeros(n, dtype=torch.int32, device=dev)
-    seat = (torch.arange(n, device=dev) >= (n + 1) // 2).to(torch.int32)      # episode e < n / 2: the trained agent sits in seat 0 (vanilla_cfr.py:173-176)
+    seat = (torch.arange(n, device=dev) >= first).to(torch.int32)
     torch.cuda.synchronize()
-    ctx.eval_tabular_prepare(pol.data_ptr())                  # the policy's sampling thresholds, once: the plies compare integers (same actions, bit for bit)
     for ply in range(8):
         ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0, seat.data_ptr(), stream_id)
     ctx.synchronize()
@@ -88,7 +116,6 @@ def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16
     sc = b[:, 14:16].to(torch.float64)
     t_sc, o_sc = sc.gather(1, sl).squeeze(1), sc.gather(1, 1 - sl).squeeze(1)
     by_seat = []
-    first = (n + 1) // 2                                                       # episodes e < n / 2 sit in seat 0
     for lo, hi in ((0, first), (first, n)):
         m = hi - lo
         if m:
@@ -97,8 +124,6 @@ def evaluate_agent_device(trainer, num_episodes=10000, policy=None, stream_id=16
                             "trained_scopas": float(t_sc[lo:hi].mean()), "opponent_scopas": float(o_sc[lo:hi].mean())})
         else:
             by_seat.append({"episodes": 0, "reward": 0.0, "reward_std_error": 0.0, "trained_scopas": 0.0, "opponent_scopas": 0.0})
-    if n == 0:
-        return 0.0, {"trained_avg": 0.0, "opponent_avg": 0.0, "difference": 0.0, "data_collected": False, "reward_std_error": 0.0, "by_seat": by_seat}
     stats = {"trained_avg": float(t_sc.mean()), "opponent_avg": float(o_sc.mean()),
              "difference": float(t_sc.mean() - o_sc.mean()), "data_collected": True,
              "reward_std_error": float(mine.std(unbiased=False) / np.sqrt(n)),

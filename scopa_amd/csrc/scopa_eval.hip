@@ -287,6 +287,66 @@ k_eval_tabular_step(scopa_state *__restrict__ states, int32_t *__restrict__ node
     node_idx[i] = idx * nl + k;
 }
 
+// The whole seat-swapped match in ONE launch.  Every episode plays the context's deal, so its state after any prefix of moves is a node of the deal's tree: an
+// episode is a walk over node indices -- per ply one Philox draw (the per-ply kernels' stream: episode, ply, stream_id) and, for the trained seat, three integer
+// compares against its infoset's thresholds, both tables in LDS; plies 6 and 7 have one legal card and draw nothing.  No state is read or written per ply (the
+// per-ply form moves 44 B per episode-ply and is bound by the vector instructions of the move itself); the episode's final state is the tree's terminal node,
+// and what evaluate_agent reports is summed here as integers (rewards x2: exact), per seat half: stats[seat][0..4] = episodes, sum r2, sum r2^2, sum of the
+// trained side's scopas, sum of the opponent's.  Episode i < n_seat0 has the trained policy in seat 0.
+__global__ void __launch_bounds__(256)
+k_eval_tabular_match(long long n, long long n_seat0, const uint16_t *__restrict__ g_infoset, const unsigned long long *__restrict__ g_thr /*[I][3]*/, int n_infosets,
+                     const scopa_state *__restrict__ tree_states, uint32_t seed_lo, uint32_t seed_hi, uint32_t stream,
+                     scopa_state *__restrict__ out_states, int32_t *__restrict__ out_idx, unsigned long long *__restrict__ stats /*[2][5]*/) {
+    extern __shared__ __align__(16) unsigned char smem[];
+    unsigned long long *s_thr = reinterpret_cast<unsigned long long *>(smem);                 // [n_infosets][3]
+    uint16_t *s_inf = reinterpret_cast<uint16_t *>(smem + (size_t)n_infosets * 24);           // [kDecision]
+    __shared__ unsigned long long s_stats[10];
+    for (int t = threadIdx.x; t < n_infosets * 3; t += blockDim.x) s_thr[t] = g_thr[t];
+    for (int t = threadIdx.x; t < kDecision; t += blockDim.x) s_inf[t] = g_infoset[t];
+    if (threadIdx.x < 10) s_stats[threadIdx.x] = 0ull;
+    __syncthreads();
+    long long acc[2][5] = {{0, 0, 0, 0, 0}, {0, 0, 0, 0, 0}};
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const int seat = i >= n_seat0;
+        int idx = 0;
+#pragma unroll
+        for (int ply = 0; ply < 6; ply++) {
+            const int nl = nlegal_at(ply);
+            const philox_out x = philox4x32_10((uint32_t)i, (uint32_t)(i >> 32), (uint32_t)ply, stream, seed_lo, seed_hi);
+            int a;
+            if ((ply & 1) == seat) {  // np.random.choice(actions, p=probs) through the prepared thresholds (k_eval_tabular_step<true>)
+                const unsigned long long *t = s_thr + (size_t)s_inf[level_offset(ply) + idx] * 3;
+                const unsigned long long N = ((unsigned long long)(x.x0 >> 5) << 26) | (unsigned long long)(x.x1 >> 6);
+                a = (int)(t[0] <= N) + (int)(t[1] <= N) + (int)(t[2] <= N);
+            } else {                  // uniform opponent
+                a = (int)(u53(x.x0, x.x1) * (double)nl);
+            }
+            idx = idx * nl + (a < nl - 1 ? a : nl - 1);
+        }
+        const uint4 tw = reinterpret_cast<const uint4 *>(tree_states)[kDecision + idx];      // terminal node idx of ply 8 (plies 6, 7: one child each)
+        const int r0 = (int)(tw.w & 255u) + 2 * (int)((tw.w >> 16) & 255u), r1 = (int)((tw.w >> 8) & 255u) + 2 * (int)(tw.w >> 24);
+        const int mine = seat ? r1 - r0 : r0 - r1;                                           // evaluate_game x 2: 2 r_i - (r_0 + r_1)
+        const int sc_t = (int)((tw.w >> (16 + 8 * seat)) & 255u), sc_o = (int)((tw.w >> (24 - 8 * seat)) & 255u);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const bool on = seat == h;
+            acc[h][0] += on ? 1 : 0; acc[h][1] += on ? mine : 0; acc[h][2] += on ? mine * mine : 0; acc[h][3] += on ? sc_t : 0; acc[h][4] += on ? sc_o : 0;
+        }
+        if (out_states) reinterpret_cast<uint4 *>(out_states)[i] = tw;
+        if (out_idx) out_idx[i] = idx;
+    }
+#pragma unroll
+    for (int j = 0; j < 10; j++) {
+        long long v = acc[j / 5][j % 5];
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+        if ((threadIdx.x & 63) == 0 && v != 0) atomicAdd(&s_stats[j], (unsigned long long)v);
+    }
+    __syncthreads();
+    if (threadIdx.x < 10 && s_stats[threadIdx.x] != 0ull) atomicAdd(&stats[threadIdx.x], s_stats[threadIdx.x]);
+}
+
 extern "C" {
 
 int32_t scopa_cfr_sync_iterate(scopa_ctx *ctx, int32_t n_iters) {
@@ -332,6 +392,29 @@ int32_t scopa_eval_tabular_step(scopa_ctx *ctx, scopa_state *d_states, int32_t *
                            ctx->d_infoset, (const double *)nullptr, (const unsigned long long *)ctx->d_eval_thr, d_trained_seat, (uint32_t)ctx->seed,
                            (uint32_t)(ctx->seed >> 32), stream_id);
     SC_HIP(ctx, hipGetLastError());
+    return SCOPA_OK;
+}
+
+int32_t scopa_eval_tabular_match(scopa_ctx *ctx, int64_t n, int64_t n_seat0, uint32_t stream_id, scopa_state *d_states_out, int32_t *d_node_idx_out,
+                                 int64_t h_stats[10]) {
+    if (!ctx || !h_stats || n < 0 || n_seat0 < 0 || n_seat0 > n) return SCOPA_EINVAL;
+    SC_REQUIRE(ctx, ctx->has_deal, SCOPA_ESTATE, "scopa_eval_tabular_match: no deal set");
+    SC_REQUIRE(ctx, ctx->eval_thr_valid, SCOPA_ESTATE, "scopa_eval_tabular_match: no policy prepared (scopa_eval_tabular_prepare)");
+    SC_REQUIRE(ctx, !d_states_out || ((uintptr_t)d_states_out & 15) == 0, SCOPA_EINVAL, "scopa_eval_tabular_match: states must be 16-byte aligned");
+    for (int j = 0; j < 10; j++) h_stats[j] = 0;
+    if (!n) return SCOPA_OK;
+    SC_HIP(ctx, hipSetDevice(ctx->device));
+    { const int32_t rc = ensure_scratch(ctx, 128); if (rc != SCOPA_OK) return rc; }
+    unsigned long long *d_stats = reinterpret_cast<unsigned long long *>(ctx->d_scratch);   // 80 bytes of the context's scratch
+    SC_HIP(ctx, hipMemsetAsync(d_stats, 0, sizeof(unsigned long long) * 10, ctx->stream));
+    const size_t lds = (size_t)ctx->n_infosets * 24 + sizeof(uint16_t) * kDecision;
+    const long long blocks = std::min<long long>((n + 255) / 256, 4096);
+    hipLaunchKernelGGL(k_eval_tabular_match, dim3((unsigned)blocks), dim3(256), lds, ctx->stream, (long long)n, (long long)n_seat0, ctx->d_infoset,
+                       (const unsigned long long *)ctx->d_eval_thr, ctx->n_infosets, ctx->d_states, (uint32_t)ctx->seed, (uint32_t)(ctx->seed >> 32), stream_id,
+                       d_states_out, d_node_idx_out, d_stats);
+    SC_HIP(ctx, hipGetLastError());
+    SC_HIP(ctx, hipMemcpyAsync(h_stats, d_stats, sizeof(int64_t) * 10, hipMemcpyDeviceToHost, ctx->stream));
+    SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return SCOPA_OK;
 }
 

@@ -304,6 +304,59 @@ def test_tabular_evaluator_thresholds_sample_like_the_float_divisions(game):
         assert torch.equal(finals[0][0], finals[1][0]) and torch.equal(finals[0][1], finals[1][1]), name
 
 
+def test_one_launch_match_is_the_per_ply_evaluator_episode_for_episode(game):
+    """scopa_eval_tabular_match -- a whole seat-swapped match as walks over the deal's tree nodes, statistics summed in the kernel -- against eight
+    scopa_eval_tabular_step launches on packed states: the same final state and terminal index for every episode (odd and small episode counts, another
+    deal, a policy with all-zero rows), integer sums equal to what the final states give, and evaluate_agent_device's two forms agreeing."""
+    import torch
+    from scopa_amd import _lib
+    from scopa_amd.algorithms import CFRTrainer, evaluate_agent_device
+    tr = CFRTrainer(game)
+    tr.train(steps=40)
+    ctx = tr._engine.ctx
+    trained = ctx.exploitability(return_policy=True)["policy"]
+    holes = trained.copy()
+    holes[::3] = 0.0
+    for name, P, n, sid in (("trained", trained, 300001, 77), ("zero rows", holes, 70000, 5), ("few", trained, 3, 9), ("one", trained, 1, 2)):
+        first = (n + 1) // 2
+        pol = torch.as_tensor(np.ascontiguousarray(P, np.float64), device="cuda:0")
+        seat = (torch.arange(n, device="cuda:0") >= first).to(torch.int32)
+        states = torch.zeros((n, 4), dtype=torch.int32, device="cuda:0")
+        idx = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        ctx.eval_init_states(states.data_ptr(), n)
+        torch.cuda.synchronize()
+        ctx.eval_tabular_prepare(pol.data_ptr())
+        for ply in range(8):
+            ctx.eval_tabular_step(states.data_ptr(), idx.data_ptr(), n, ply, 0, seat.data_ptr(), sid)
+        ctx.synchronize()
+        w_states = torch.full((n, 4), -1, dtype=torch.int32, device="cuda:0")
+        w_idx = torch.full((n,), -1, dtype=torch.int32, device="cuda:0")
+        st = ctx.eval_tabular_match(n, first, sid, w_states.data_ptr(), w_idx.data_ptr())
+        assert torch.equal(w_states, states) and torch.equal(w_idx, idx), name
+        assert (ctx.eval_tabular_match(n, first, sid) == st).all(), name        # without the optional outputs: the same sums
+        h = states.cpu().numpy().view(_lib.STATE_DTYPE).reshape(-1)
+        r = h["ncap"].astype(np.int64) + 2 * h["scopas"].astype(np.int64)
+        sv = seat.cpu().numpy().astype(np.int64)
+        e = np.arange(n)
+        mine = r[e, sv] - r[e, 1 - sv]
+        for half in (0, 1):
+            k = sv == half
+            want = [int(k.sum()), int(mine[k].sum()), int((mine[k] ** 2).sum()), int(h["scopas"][e, sv][k].sum()), int(h["scopas"][e, 1 - sv][k].sum())]
+            assert st[half].tolist() == want, (name, half)
+    a1, s1 = evaluate_agent_device(tr, 200001, stream_id=31)
+    a2, s2 = evaluate_agent_device(tr, 200001, stream_id=31, per_ply=True)
+    close = lambda x, y: abs(x - y) <= 1e-13 * abs(y) + 1e-15      # the sums are the same integers; torch's mean and std round differently from sum / n
+    assert close(a1, a2) and close(s1["trained_avg"], s2["trained_avg"]) and close(s1["opponent_avg"], s2["opponent_avg"])
+    assert abs(s1["reward_std_error"] - s2["reward_std_error"]) < 1e-11 * s2["reward_std_error"] + 1e-15
+    for b1, b2 in zip(s1["by_seat"], s2["by_seat"]):
+        assert b1["episodes"] == b2["episodes"] and close(b1["reward"], b2["reward"]) and close(b1["trained_scopas"], b2["trained_scopas"]) and close(b1["opponent_scopas"], b2["opponent_scopas"])
+    with pytest.raises(_lib.ScopaError):
+        ctx.eval_tabular_match(10, 11, 1)                                       # more seat-0 episodes than episodes
+    ctx.set_deal(_lib.deal_py_seed(7))                                          # a new deal invalidates the prepared thresholds
+    with pytest.raises(_lib.ScopaError):
+        ctx.eval_tabular_match(10, 5, 1)
+
+
 def test_device_clock_profile_of_sampled_traversal_launches(ctx, sl):
     ctx.set_deal(sl.deal_py_seed(42))
     ctx.mccfr_seed(5)
