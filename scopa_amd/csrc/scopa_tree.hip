@@ -176,7 +176,12 @@ int32_t scopa_step_batch(scopa_ctx *ctx, scopa_state *d_states, const uint8_t *d
     SC_REQUIRE(ctx, ((uintptr_t)d_states & 15) == 0, SCOPA_EINVAL, "scopa_step_batch: states must be 16-byte aligned");
     SC_HIP(ctx, hipSetDevice(ctx->device));
     int64_t blocks = (n + 255) / 256;
-    const int64_t cap = (int64_t)ctx->n_cus * 8;  // grid-stride beyond 8 blocks per CU
+#ifndef SCOPA_STEP_BLOCKS_PER_CU
+#define SCOPA_STEP_BLOCKS_PER_CU 128
+#endif
+    // grid-stride beyond that many blocks per CU.  (8 -- one resident round of workgroups -- left the launch's tail to its slowest wavefronts and the whole
+    // game at 0.64 of the HBM peak; 64-128 give 0.70-0.71, a flat grid 0.69: gpurun_out/step_grid*.log, round 4.)
+    const int64_t cap = (int64_t)ctx->n_cus * SCOPA_STEP_BLOCKS_PER_CU;
     if (blocks > cap) blocks = cap;
     hipLaunchKernelGGL(k_step_batch, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, d_states, d_actions, n);
     SC_HIP(ctx, hipGetLastError());
