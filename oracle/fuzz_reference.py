@@ -127,6 +127,35 @@ for k in range(min(N, 60)):
     checks += 2 * len(va)
 print("mini_scopa: states wrapped around ended envs agree")
 
+# the PettingZoo-side surface of MiniScopaEnv: get_state() dicts after every step, set_state() into a fresh env on both sides (which keeps that env's own
+# max_steps = 8: mini_scopa_game.py:181-194 restores everything but the limit), env-level step() incl. dead steps, rewards / terminations / agent_selection
+def env_view(e):
+    d = e.get_state()
+    d = {k: ([list(x) if isinstance(x, (list, tuple)) and x and isinstance(x[0], (list, tuple)) else x for x in v] if isinstance(v, list) else v) for k, v in d.items()}
+    return dict(state=repr(d), sel=e.agent_selection, rew={a: float(r) for a, r in e.rewards.items()}, term=dict(e.terminations), trunc=dict(e.truncations),
+                step=int(e.step_count), max_steps=int(e.max_steps), agents=list(e.agents))
+
+
+from scopa_amd.envs.mini_scopa_game import MiniScopaEnv as MyMiniEnv  # noqa: E402
+for k in range(min(N, 120)):
+    sd = SEEDS[k % len(SEEDS)]
+    ea, eb = ns.game.MiniScopaEnv(seed=sd), MyMiniEnv(seed=sd)
+    for ply in range(12):
+        if rng.rand() < 0.25:                       # round trip through get_state / set_state into fresh envs (another seed: everything is overwritten)
+            fa, fb = ns.game.MiniScopaEnv(seed=5), MyMiniEnv(seed=5)
+            fa.set_state(ea.get_state()); fb.set_state(eb.get_state())
+            ea, eb = fa, fb
+        pa = ea.game.players[ea.agent_name_mapping[ea.agent_selection]]
+        done = ea.terminations[ea.agent_selection]
+        act = int(mini_cid(pa.hand[rng.randint(len(pa.hand))])) if (len(pa.hand) and rng.rand() >= 0.3) else int(rng.randint(16))
+        if done:
+            break                                   # (a dead env step goes to the AECEnv base class, which the stand-in leaves empty)
+        ea.step(act); eb.step(act)
+        va, vb = env_view(ea), env_view(eb)
+        assert va == vb, ("env", k, ply, act, {x: (va[x], vb[x]) for x in va if va[x] != vb[x]})
+        checks += len(va)
+print("mini_scopa: MiniScopaEnv get_state / set_state / step agree")
+
 ORDERED_CAPS = False
 # ---- Team MiniScopa TPI (default deal) ----------------------------------------------------------------------------------------------
 importlib.import_module("envs.openspiel_team_mini_scopa")
