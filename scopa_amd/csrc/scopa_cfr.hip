@@ -184,7 +184,7 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
     uint16_t *s_path = s_st + ((n_steps + 2 + 7) & ~7);                         // [kDecision][8]
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_path + kDecision * 8);         // [kTerminal]
     for (int i = tid; i < cells; i += kSchedThreads) { R[i] = g_regret[i]; S[i] = g_strat[i]; L[i] = g_local[i]; }
-    for (int i = tid; i < kDecision; i += kSchedThreads) { s_inf[i] = g_infoset[i]; s_ev[i] = g_events[i]; }
+    for (int i = tid; i < kDecision; i += kSchedThreads) s_ev[i] = g_events[i];   // (the infoset ids ride in the path records' eighth slot)
     for (int i = tid; i <= n_steps; i += kSchedThreads) s_st[i] = g_steps[i];
     for (int i = tid; i < kDecision * 4; i += kSchedThreads) reinterpret_cast<uint32_t *>(s_path)[i] = reinterpret_cast<const uint32_t *>(g_paths)[i];
     for (int i = tid; i < kTerminal; i += kSchedThreads) s_pay[i] = g_payoff[i];
@@ -198,6 +198,13 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
         g_counters[1] += (unsigned long long)n_traversals * kTerminal;
     }
     __syncthreads();
+    // The records of a step's first 64 events are read one step AHEAD (they are static, and stored per event): the step's own chain then starts at the
+    // table cells it reads, not three dependent LDS reads earlier (step offsets -> event -> path cells / infoset): 0.099 -> 0.090 s per 1000 iterations (a step
+    // stays a chain of ~150 dependent-issue instructions on wavefronts alone on their SIMD: 0.6 us).
+    const int quad = tid >> 2, slot = tid & 3;
+    int e0 = s_st[0], e1 = s_st[1];
+    uint32_t cur_ev = s_ev[e0 + quad < e1 ? e0 + quad : e0];
+    uint4 cur_pw = *reinterpret_cast<const uint4 *>(s_path + (e0 + quad < e1 ? e0 + quad : e0) * 8);
     for (int t = 0; t < n_traversals; t++) {
         const int trav = (first_traverser + t) & 1;   // train(): for i in range(num_players) (:108-110)
         for (int s = 0; s < n_steps; s++) {
@@ -206,21 +213,29 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
             // left to right) are done by every lane on quad-broadcast operands.  Branch-free: slots >= n and quads without an event
             // are SELECTED away (never added as zeros: x + 0.0 would turn -0.0 into +0.0), stores are predicated.  With one lane per
             // node a step cost ~500 instructions on wavefronts that sit alone on their SIMD (1.2 us); a quad per node issues ~150.
-            const int e0 = s_st[s], e1 = s_st[s + 1], slot = tid & 3;
+            const int sn = s + 1 < n_steps ? s + 1 : 0;                      // the next step (of this traversal or the next one: same schedule)
+            const int n0 = s_st[sn], n1 = s_st[sn + 1];
+            const int ne = n0 + quad < n1 ? n0 + quad : n0;
+            const uint32_t nxt_ev = s_ev[ne];
+            const uint4 nxt_pw = *reinterpret_cast<const uint4 *>(s_path + ne * 8);
             for (int eb = e0; eb < e1; eb += kSchedThreads / 4) {
-                const int e = eb + (tid >> 2);
+                const int e = eb + quad;
                 const bool live = e < e1;
-                const uint32_t ev = s_ev[live ? e : e0];
+                uint32_t ev = cur_ev;
+                uint4 pw = cur_pw;
+                if (eb != e0) {                                              // a step of more than 64 events: the later passes read their records here
+                    ev = s_ev[live ? e : e0];
+                    pw = *reinterpret_cast<const uint4 *>(s_path + (live ? e : e0) * 8);
+                }
                 const int node = (int)(ev & 2047u), d = (int)((ev >> 11) & 7u), n = 4 - (d >> 1), cbase = (int)(ev >> 16);
                 const bool on = slot < n;
                 // reach probabilities: the product, root first, of the ancestors' local_strategy entries along the path (:79-85)
-                const uint4 pw = *reinterpret_cast<const uint4 *>(s_path + node * 8);   // the 7 path cells in one 16-byte read
-                const uint32_t pcw[4] = {pw.x, pw.y, pw.z, pw.w};
+                const uint32_t pcw[4] = {pw.x, pw.y, pw.z, pw.w};             // the 7 path cells and the infoset id
                 double pl[kPlies - 1], r0 = 1.0, r1 = 1.0;
 #pragma unroll
                 for (int k = 0; k < kPlies - 1; k++) pl[k] = L[(pcw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];   // all seven reads in flight (cells beyond the ply are 0: a valid address)
                 const bool leafp = d == kPlies - 1;
-                const int off = on ? slot : 0, I = s_inf[node];
+                const int off = on ? slot : 0, I = (int)(pw.w >> 16);
                 const int p0 = s_pay[leafp ? cbase + off : 0];
                 const double child = val[leafp ? 0 : cbase + off];
                 const double ls = L[I * 4 + slot], Rc = R[I * 4 + slot], Sc = S[I * 4 + slot];   // rows are zero-padded beyond n
@@ -253,6 +268,7 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
                     if (slot == 0) val[node] = v;
                 }
             }
+            e0 = n0; e1 = n1; cur_ev = nxt_ev; cur_pw = nxt_pw;
             __syncthreads();
         }
         if (tid == 0 && root_values) root_values[t] = val[0];
@@ -319,9 +335,17 @@ static int32_t build_exact_schedule(scopa_ctx *ctx) {
                 paths[(size_t)(level_offset(d) + idx) * 8 + (k - 1)] = (uint16_t)(inf[level_offset(k - 1) + x] * 4 + act);
             }
         }
+    // ... stored per EVENT (the order the kernel walks them in: the address of the next step's record never depends on the record itself), with the
+    // node's infoset id in the unused eighth slot -- one 16-byte read per event
+    std::vector<uint16_t> paths_e((size_t)kDecision * 8, 0);
+    for (int e = 0; e < kDecision; e++) {
+        const int node = (int)(events[e] & 2047u);
+        for (int k = 0; k < 7; k++) paths_e[(size_t)e * 8 + k] = paths[(size_t)node * 8 + k];
+        paths_e[(size_t)e * 8 + 7] = inf[node];
+    }
     // one buffer (uint16 units): [2 * kDecision] events as uint32 | [kDecision + 2] step offsets | [kDecision][8] path cells (16-byte aligned)
     if (!ctx->d_sched) SC_HIP(ctx, hipMalloc(&ctx->d_sched, (size_t)(kSchedPaths + kDecision * 8) * sizeof(uint16_t)));
-    SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched + kSchedPaths, paths.data(), paths.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
+    SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched + kSchedPaths, paths_e.data(), paths_e.size() * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched, events.data(), kDecision * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipMemcpyAsync(ctx->d_sched + kSchedSteps, steps.data(), (size_t)(T + 1) * sizeof(uint16_t), hipMemcpyHostToDevice, ctx->stream));
     SC_HIP(ctx, hipStreamSynchronize(ctx->stream));
