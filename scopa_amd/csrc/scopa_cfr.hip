@@ -185,6 +185,7 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
     int8_t *s_pay = reinterpret_cast<int8_t *>(s_path + kDecision * 8);         // [kTerminal]
     for (int i = tid; i < cells; i += kSchedThreads) { R[i] = g_regret[i]; S[i] = g_strat[i]; L[i] = g_local[i]; }
     for (int i = tid; i < kDecision; i += kSchedThreads) s_ev[i] = g_events[i];   // (the infoset ids ride in the path records' eighth slot)
+    if (tid == 0) *reinterpret_cast<double *>(s_inf) = 1.0;                         // the cell path entries beyond a node's ply point at (sched_one_cell)
     for (int i = tid; i <= n_steps; i += kSchedThreads) s_st[i] = g_steps[i];
     for (int i = tid; i < kDecision * 4; i += kSchedThreads) reinterpret_cast<uint32_t *>(s_path)[i] = reinterpret_cast<const uint32_t *>(g_paths)[i];
     for (int i = tid; i < kTerminal; i += kSchedThreads) s_pay[i] = g_payoff[i];
@@ -233,16 +234,15 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
                 const uint32_t pcw[4] = {pw.x, pw.y, pw.z, pw.w};             // the 7 path cells and the infoset id
                 double pl[kPlies - 1], r0 = 1.0, r1 = 1.0;
 #pragma unroll
-                for (int k = 0; k < kPlies - 1; k++) pl[k] = L[(pcw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];   // all seven reads in flight (cells beyond the ply are 0: a valid address)
+                for (int k = 0; k < kPlies - 1; k++) pl[k] = L[(pcw[k >> 1] >> (16 * (k & 1))) & 0xFFFFu];   // all seven reads in flight (cells beyond the ply: the 1.0 cell)
                 const bool leafp = d == kPlies - 1;
                 const int off = on ? slot : 0, I = (int)(pw.w >> 16);
                 const int p0 = s_pay[leafp ? cbase + off : 0];
                 const double child = val[leafp ? 0 : cbase + off];
                 const double ls = L[I * 4 + slot], Rc = R[I * 4 + slot], Sc = S[I * 4 + slot];   // rows are zero-padded beyond n
 #pragma unroll
-                for (int k = 0; k < kPlies - 1; k++) {   // x * 1.0 is x: plies beyond the node's leave the product untouched
-                    const double f = k < d ? pl[k] : 1.0;
-                    if ((k & 1) == 0) r0 = r0 * f; else r1 = r1 * f;
+                for (int k = 0; k < kPlies - 1; k++) {   // x * 1.0 is x: the cells of plies beyond the node's read 1.0 and leave the product untouched
+                    if ((k & 1) == 0) r0 = r0 * pl[k]; else r1 = r1 * pl[k];
                 }
                 const bool is_trav = (d & 1) == trav;
                 const double reach = trav == 0 ? r0 : r1, opp = trav == 0 ? r1 : r0;
@@ -279,6 +279,10 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
 
 // as-soon-as-possible levelling of the EXIT events of one deal's tree under the per-infoset order (see the head of this file)
 constexpr int kSchedSteps = 2 * kDecision, kSchedPaths = (3 * kDecision + 2 + 7) & ~7;   // offsets into d_sched, in uint16 units
+
+// index, in float64 cells from the local_strategy table's base, of the cell k_cfr_exact_sched keeps at 1.0: the first 8 bytes of the (otherwise unused) node ->
+// infoset area behind the tables, the node values and the event words
+static int sched_one_cell(int n_infosets) { return n_infosets * 4 + kDecision + (kDecision + 1) / 2; }
 
 static int32_t build_exact_schedule(scopa_ctx *ctx) {
     if (ctx->sched_valid) return SCOPA_OK;
@@ -337,10 +341,12 @@ static int32_t build_exact_schedule(scopa_ctx *ctx) {
         }
     // ... stored per EVENT (the order the kernel walks them in: the address of the next step's record never depends on the record itself), with the
     // node's infoset id in the unused eighth slot -- one 16-byte read per event
+    // -- and the cells BEYOND the node's ply point at a cell that holds 1.0 (sched_one_cell: x * 1.0 is x, so the reach products need no selects)
     std::vector<uint16_t> paths_e((size_t)kDecision * 8, 0);
+    const uint16_t one = (uint16_t)sched_one_cell(ctx->n_infosets);
     for (int e = 0; e < kDecision; e++) {
-        const int node = (int)(events[e] & 2047u);
-        for (int k = 0; k < 7; k++) paths_e[(size_t)e * 8 + k] = paths[(size_t)node * 8 + k];
+        const int node = (int)(events[e] & 2047u), d = (int)((events[e] >> 11) & 7u);
+        for (int k = 0; k < 7; k++) paths_e[(size_t)e * 8 + k] = k < d ? paths[(size_t)node * 8 + k] : one;
         paths_e[(size_t)e * 8 + 7] = inf[node];
     }
     // one buffer (uint16 units): [2 * kDecision] events as uint32 | [kDecision + 2] step offsets | [kDecision][8] path cells (16-byte aligned)
