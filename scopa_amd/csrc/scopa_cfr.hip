@@ -200,10 +200,11 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
     }
     __syncthreads();
     // The records of a step's first 64 events are read one step AHEAD (they are static, and stored per event): the step's own chain then starts at the
-    // table cells it reads, not three dependent LDS reads earlier (step offsets -> event -> path cells / infoset): 0.099 -> 0.090 s per 1000 iterations (a step
+    // table cells it reads, not three dependent LDS reads earlier (step offsets -> event -> path cells / infoset): 0.099 -> 0.086 s per 1000 iterations (a step
     // stays a chain of ~150 dependent-issue instructions on wavefronts alone on their SIMD: 0.6 us).
     const int quad = tid >> 2, slot = tid & 3;
     int e0 = s_st[0], e1 = s_st[1];
+    int n0 = s_st[1 < n_steps ? 1 : 0], n1 = s_st[(1 < n_steps ? 1 : 0) + 1];       // the offsets themselves two steps ahead: no address of a step waits on a read
     uint32_t cur_ev = s_ev[e0 + quad < e1 ? e0 + quad : e0];
     uint4 cur_pw = *reinterpret_cast<const uint4 *>(s_path + (e0 + quad < e1 ? e0 + quad : e0) * 8);
     for (int t = 0; t < n_traversals; t++) {
@@ -214,11 +215,11 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
             // left to right) are done by every lane on quad-broadcast operands.  Branch-free: slots >= n and quads without an event
             // are SELECTED away (never added as zeros: x + 0.0 would turn -0.0 into +0.0), stores are predicated.  With one lane per
             // node a step cost ~500 instructions on wavefronts that sit alone on their SIMD (1.2 us); a quad per node issues ~150.
-            const int sn = s + 1 < n_steps ? s + 1 : 0;                      // the next step (of this traversal or the next one: same schedule)
-            const int n0 = s_st[sn], n1 = s_st[sn + 1];
-            const int ne = n0 + quad < n1 ? n0 + quad : n0;
+            const int ne = n0 + quad < n1 ? n0 + quad : n0;                   // the next step's record (of this traversal or the next one: same schedule)
             const uint32_t nxt_ev = s_ev[ne];
             const uint4 nxt_pw = *reinterpret_cast<const uint4 *>(s_path + ne * 8);
+            const int sm = s + 2 < n_steps ? s + 2 : s + 2 - n_steps;         // ... and the offsets of the one after
+            const int m0 = s_st[sm], m1 = s_st[sm + 1];
             for (int eb = e0; eb < e1; eb += kSchedThreads / 4) {
                 const int e = eb + quad;
                 const bool live = e < e1;
@@ -268,7 +269,7 @@ k_cfr_exact_sched(const uint16_t *__restrict__ g_infoset, const int8_t *__restri
                     if (slot == 0) val[node] = v;
                 }
             }
-            e0 = n0; e1 = n1; cur_ev = nxt_ev; cur_pw = nxt_pw;
+            e0 = n0; e1 = n1; cur_ev = nxt_ev; cur_pw = nxt_pw; n0 = m0; n1 = m1;
             __syncthreads();
         }
         if (tid == 0 && root_values) root_values[t] = val[0];
